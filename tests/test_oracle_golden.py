@@ -1,0 +1,226 @@
+"""The oracle (oracle/css_oracle.py) against the golden vectors captured from the
+reference itself (tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import css_oracle as O
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    a, b = torch.as_tensor(a).double(), torch.as_tensor(b).double()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if a.numel() == 0:
+        return
+    err = (a - b).abs().max().item()
+    scale = b.abs().max().item()
+    assert err <= atol + rtol * scale, f"max err {err:.3e} vs scale {scale:.3e}"
+
+
+def probe_slice(t):
+    return t.detach().flatten()[:: max(1, t.numel() // 2048)][:2048]
+
+
+@pytest.mark.parametrize("tag,backbone", [("net_tv_65", "tv"), ("net_stem_65", "stem"), ("net_tv_97", "tv")])
+def test_network_forward_backward(golden, tag, backbone):
+    g = golden(tag)
+    K, seed = int(g["K"]), int(g["seed"])
+    sd = O.init_state(backbone, K, 256, seed)
+    names = O.param_names(backbone, K, 256)
+    for n in names:
+        sd[n].requires_grad_(True)
+    x = T(g["x"])
+    pred, rep = O.deeplab_forward(sd, x, backbone, True, K, 256)
+    close(pred, g["pred"], 1e-4, 1e-5)
+    close(rep, g["rep"], 1e-4, 1e-5)
+    loss = (pred * T(g["wp"])).sum() + (rep * T(g["wr"])).sum()
+    loss.backward()
+    for key in g:
+        if key.startswith("grad::"):
+            close(probe_slice(sd[key[6:]].grad), g[key], 2e-3, 1e-5)
+    for key in g:
+        if key.startswith("rm::"):
+            close(sd[key[4:] + ".running_mean"], g[key], 1e-4, 1e-6)
+        if key.startswith("rv::"):
+            close(sd[key[4:] + ".running_var"], g[key], 1e-4, 1e-6)
+    with torch.no_grad():
+        pe, re_ = O.deeplab_forward(sd, x, backbone, False, K, 256)
+    close(pe, g["pred_eval"], 1e-4, 1e-5)
+    close(re_[:, ::16], g["rep_eval_sub"], 1e-4, 1e-5)
+
+
+def test_param_order_and_count():
+    # 59.52 M (tv) / 59.64 M (stem) parameters, SURVEY section 2.3(a)
+    for bb, K, expect in (("tv", 21, 59.52e6), ("stem", 19, 59.64e6)):
+        sd = O.init_state(bb, K, 256, 0)
+        n = sum(sd[k].numel() for k in O.param_names(bb, K, 256))
+        assert abs(n - expect) / expect < 2e-3, n
+
+
+@pytest.mark.parametrize("name", ["rand", "zero"])
+def test_pseudo_labels(golden, name):
+    g = golden("pseudo_labels")
+    pred_u, rep_u, protos = T(g[f"{name}::pred_u"]), T(g[f"{name}::rep_u"]), T(g[f"{name}::protos"])
+    close(O.similarity(rep_u, protos), g[f"{name}::sim"], 1e-5, 1e-6)
+    lg_rep, lb_rep, lg_cls, lb_cls, pseudo = O.pseudo_labels_mix(pred_u, rep_u, protos, 0.5, (65, 65), 21)
+    close(lg_rep, g[f"{name}::lg_rep"], 1e-5, 1e-6)
+    close(lg_cls, g[f"{name}::lg_cls"], 1e-5, 1e-6)
+    assert torch.equal(lb_rep, T(g[f"{name}::lb_rep"]))
+    assert torch.equal(lb_cls, T(g[f"{name}::lb_cls"]))
+    assert torch.equal(pseudo, T(g[f"{name}::pseudo"]))
+    close(O.prob_all_from_rep(rep_u, protos, 0.5), g[f"{name}::prob_all"], 1e-5, 1e-6)
+
+
+def _contrast_case(g, name):
+    rep = T(g[f"{name}::rep"]).clone().requires_grad_(True)
+    K = 21
+    label = torch.nn.functional.one_hot(T(g[f"{name}::label_idx"]).long(), K).permute(0, 3, 1, 2).float()
+    mask = T(g[f"{name}::mask"]).float()
+    prob = T(g[f"{name}::prob"])
+    protos = T(g[f"{name}::protos_in"]).clone()
+    Q, N = [int(v) for v in g[f"{name}::QN"]]
+    return rep, label, mask, prob, protos, Q, N
+
+
+@pytest.mark.parametrize("name", ["first", "ema", "nohard", "single"])
+def test_contrast_loss_injected(golden, name):
+    g = golden("contrast_loss")
+    rep, label, mask, prob, protos, Q, N = _contrast_case(g, name)
+    na = int(g[f"{name}::n_anchor"])
+    rec = {}
+    # discover which present classes have hard pixels to line the recorded draws up
+    O.contrast_loss(rep.detach(), label, mask, prob, protos.clone(), Q, N, 0.5, 0.8, 0.99, record=rec) if na else None
+    inj = None
+    if na:
+        anchors, negs, j = [], [], 0
+        for v, hn in enumerate(rec["hard_num"]):
+            if hn > 0:
+                anchors.append(g[f"{name}::anchor{j}"].astype(np.int64))
+                negs.append(g[f"{name}::negative{j}"].astype(np.int64))
+                j += 1
+            else:
+                anchors.append(None)
+                negs.append(None)
+        assert j == na
+        inj = dict(anchor=anchors, negative=negs)
+    loss = O.contrast_loss(rep, label, mask, prob, protos, Q, N, 0.5, 0.8, 0.99, injected=inj)
+    close(loss, g[f"{name}::loss"], 1e-5, 1e-6)
+    close(protos, g[f"{name}::protos_out"], 1e-5, 1e-6)
+    loss.backward()
+    gr = rep.grad.permute(0, 2, 3, 1).reshape(-1, rep.shape[1])
+    rows = T(g[f"{name}::grad_rows"]).long()
+    close(gr[rows], g[f"{name}::grad_vals"], 1e-4, 1e-8)
+    other = torch.ones(gr.shape[0], dtype=torch.bool)
+    other[rows] = False
+    assert gr[other].abs().max().item() == 0 if other.any() else True
+
+
+@pytest.mark.parametrize("name", ["first", "stress"])
+def test_contrast_loss_rng_replay(golden, name):
+    """Same three RNG streams, same seeds -> the oracle's own sampler reproduces the reference's draws."""
+    g = golden("contrast_loss")
+    rep, label, mask, prob, protos, Q, N = _contrast_case(g, name)
+    seed = int(g["rng_seed"])
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    loss = O.contrast_loss(rep, label, mask, prob, protos, Q, N, 0.5, 0.8, 0.99)
+    close(loss, g[f"{name}::loss"], 1e-5, 1e-6)
+    close(protos, g[f"{name}::protos_out"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["normal", "allignored"])
+def test_attention_threshold_loss(golden, name):
+    g = golden("losses")
+    pred = T(g[f"att_{name}::pred"]).clone().requires_grad_(True)
+    lab = T(g[f"att_{name}::lab"]).long()
+    loss = O.attention_threshold_loss(pred, lab, T(g[f"att_{name}::logits"]), 0.7)
+    loss.backward()
+    if name == "allignored":
+        assert torch.isnan(loss) and np.isnan(g[f"att_{name}::loss"])
+        assert pred.grad.abs().max() == 0 and np.abs(g[f"att_{name}::grad"]).max() == 0
+    else:
+        close(loss, g[f"att_{name}::loss"], 1e-6, 1e-7)
+        close(pred.grad, g[f"att_{name}::grad"], 1e-5, 1e-9)
+
+
+def test_ce_and_ohem(golden):
+    g = golden("losses")
+    pred = T(g["ce::pred"]).clone().requires_grad_(True)
+    loss = O.ce_loss(pred, T(g["ce::lab"]).long())
+    loss.backward()
+    close(loss, g["ce::loss"], 1e-6, 1e-7)
+    close(pred.grad, g["ce::grad"], 1e-5, 1e-9)
+    for name in ("raise", "keep", "toofew"):
+        pred = T(g[f"ohem_{name}::pred"]).clone().requires_grad_(True)
+        loss = O.prob_ohem_ce(pred, T(g[f"ohem_{name}::lab"]).long(), -1, 0.7, int(g[f"ohem_{name}::min_kept"]))
+        loss.backward()
+        close(loss, g[f"ohem_{name}::loss"], 1e-6, 1e-7)
+        close(pred.grad, g[f"ohem_{name}::grad"], 1e-5, 1e-9)
+
+
+@pytest.mark.parametrize("H,h", [(65, 17), (129, 33), (97, 25)])
+def test_label_mask(golden, H, h):
+    g = golden("label_mask")
+    label_all, mask_all = O.build_label_mask(T(g[f"{H}::l_lab"]).long(), T(g[f"{H}::u_lab"]).long(),
+                                             T(g[f"{H}::u_logits"]), 0.7, 21, (h, h))
+    assert torch.equal(label_all.to(torch.uint8), T(g[f"{H}::label_all"]))
+    assert torch.equal(mask_all.to(torch.uint8), T(g[f"{H}::mask_all"]))
+
+
+def test_schedules(golden):
+    g = golden("schedules")
+    lrs = [O.poly_lr(6.4e-3, it, 1000, 0.9, 1e-4) for it in range(1000)]
+    close(lrs, g["poly"], 1e-6, 0)
+    close([O.rampdown_value(e) for e in range(210)], g["ramp"], 1e-7, 0)
+    e, p, step, ema = [torch.zeros(1)], [torch.ones(1)], 0, []
+    for _ in range(150):
+        step = O.ema_update(e, p, step, 0.99)
+        ema.append(float(e[0]))
+    close(ema, g["ema"], 1e-6, 0)
+    prm, bufs = [torch.tensor([1.0, -2.0, 0.5])], [None]
+    for i in range(5):
+        O.sgd_nesterov_step(prm, [T(g["sgd_grads"])[i]], bufs, 0.01)
+        close(prm[0], g["sgd_traj"][i], 1e-6, 1e-7)
+
+
+def test_train_trace(golden):
+    """Two iterations of the mix_label.train body vs the reference's Model_mix-driven trace."""
+    g = golden("train_trace")
+    st = O.MixState("tv", 21, 256, int(g["seed"]))
+    probes = ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]
+    for it in range(2):
+        na = int(g[f"{it}::n_anchor"])
+        # first pass discovers which present classes have hard pixels, on a throw-away copy
+        import copy
+        rec = {}
+        st_probe = copy.deepcopy(st)
+        lr = O.poly_lr(6.4e-3, it, 100)
+        args = dict(lr=lr, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97,
+                    num_queries=64, num_negatives=128)
+        O.train_step_mix(st_probe, T(g[f"{it}::l_img"]), T(g[f"{it}::l_lab"]).long(), T(g[f"{it}::u_img"]),
+                         record=rec, **args)
+        anchors, negs, j = [], [], 0
+        for hn in rec["hard_num"]:
+            if hn > 0:
+                anchors.append(g[f"{it}::anchor{j}"].astype(np.int64))
+                negs.append(g[f"{it}::negative{j}"].astype(np.int64))
+                j += 1
+            else:
+                anchors.append(None)
+                negs.append(None)
+        assert j == na
+        r = O.train_step_mix(st, T(g[f"{it}::l_img"]), T(g[f"{it}::l_lab"]).long(), T(g[f"{it}::u_img"]),
+                             injected=dict(anchor=anchors, negative=negs), **args)
+        close(r["sup"], g[f"{it}::sup"], 1e-4, 1e-6)
+        close(r["unsup"], g[f"{it}::unsup"], 1e-4, 1e-6)
+        close(r["contrast"], g[f"{it}::con"], 1e-4, 1e-6)
+        assert torch.equal(r["pseudo"], T(g[f"{it}::ulab"]).long())
+        close(st.prototypes, g[f"{it}::protos"], 1e-4, 1e-6)
+        for p in probes:
+            close(probe_slice(st.student[p]), g[f"{it}::student::{p}"], 1e-4, 1e-6)
+            close(probe_slice(st.teacher[p]), g[f"{it}::teacher::{p}"], 1e-4, 1e-6)
+        close(st.teacher["resnet_bn1.running_mean"], g[f"{it}::teacher_rm::resnet_bn1"], 1e-4, 1e-6)
