@@ -1,0 +1,308 @@
+// extern "C" surface of libcss_hip.so (declared in include/css_hip.h).  Thin: argument packing, device
+// selection, optional HIP-event bracketing of the hot kernels; never allocates, never synchronises
+// (css_prof_read is the one documented exception: it waits for the recorded events).
+#include "../../include/css_hip.h"
+#include "launchers.h"
+
+#include <mutex>
+#include <vector>
+
+namespace {
+inline hipStream_t S(css_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+inline void set_dev(int device) {
+  if (device >= 0) (void)hipSetDevice(device);
+}
+int g_cu_count[64] = {0};
+int cu_count(int device) {
+  int d = device;
+  if (d < 0) (void)hipGetDevice(&d);
+  if (d < 0 || d >= 64) return 256;
+  if (!g_cu_count[d]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || v <= 0) v = 256;
+    g_cu_count[d] = v;
+  }
+  return g_cu_count[d];
+}
+
+// ---- profiling ----
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+constexpr int PROF_KINDS = 8;
+bool g_prof_on = false;
+std::mutex g_prof_mu;
+std::vector<ProfRec> g_prof;       // recorded this epoch
+std::vector<ProfRec> g_prof_pool;  // reusable event pairs
+constexpr size_t PROF_MAX = 1u << 18;
+
+struct ProfScope {
+  bool on;
+  ProfRec r;
+  hipStream_t st;
+  ProfScope(int kind, double work, hipStream_t s) : on(g_prof_on), st(s) {
+    if (!on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    if (g_prof.size() >= PROF_MAX) { on = false; return; }
+    if (!g_prof_pool.empty()) { r = g_prof_pool.back(); g_prof_pool.pop_back(); }
+    else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
+    r.kind = kind;
+    r.work = work;
+    (void)hipEventRecord(r.a, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(r.b, st);
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof.push_back(r);
+  }
+};
+}  // namespace
+
+extern "C" {
+
+int css_abi_version(void) { return 1; }
+int css_device_cu_count(int device) { return cu_count(device); }
+
+int css_prof_enable(int on) { g_prof_on = on != 0; return 0; }
+int css_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto& r : g_prof) g_prof_pool.push_back(r);
+  g_prof.clear();
+  return 0;
+}
+int css_prof_read(int kind, double* total_ms, double* launches, double* alg_work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  double ms = 0, n = 0, w = 0;
+  for (auto& r : g_prof) {
+    if (r.kind != kind) continue;
+    if (hipEventSynchronize(r.b) != hipSuccess) return CSS_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return CSS_ERR_LAUNCH;
+    ms += t; n += 1; w += r.work;
+  }
+  if (total_ms) *total_ms = ms;
+  if (launches) *launches = n;
+  if (alg_work) *alg_work = w;
+  return 0;
+}
+
+// ---- convolution ----
+int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
+                       int ldy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  ConvArgs a;
+  a.src = x; a.wt = w; a.dst = y; a.bias = bias;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.lds = ldx;
+  a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldd = ldy;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
+  a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
+  ProfScope ps(0, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, S(stream));
+}
+int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
+                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  if (stride != 1 && stride != 2) return CSS_ERR_ARG;
+  ConvArgs a;
+  a.src = dy; a.wt = w_t; a.dst = dx; a.bias = nullptr;
+  a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.lds = lddy;
+  a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1;
+  a.M = N * H * W; a.Ktot = R * Sk * Cout;
+  ProfScope ps(1, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, S(stream));
+}
+int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy, int R,
+                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  WgradArgs a;
+  a.x = x; a.dy = dy; a.dw = dw;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.ldx = ldx;
+  a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldy = lddy;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin; a.m_per_split = a.M;
+  ProfScope ps(2, alg_flops, S(stream));
+  return css_launch_wgrad(a, dtype, cu_count(device), S(stream));
+}
+int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_weight_layout(w, out, Cout, taps, Cin, CinPad, dgrad, dtype, S(stream));
+}
+
+// ---- batch norm ----
+int css_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_stats(y, M, C, ld, sum, sumsq, dtype, S(stream));
+}
+int css_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device,
+                    css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_finalize(sum, sumsq, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
+}
+int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
+                      float* shift, int C, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift, C, S(stream));
+}
+int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C, int relu,
+                 int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, dtype, S(stream));
+}
+int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int M, int C,
+                      int relu, double* sum_dz, double* sum_dzx, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, sum_dz, sum_dzx, dtype, S(stream));
+}
+int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
+                     const float* mean, const float* invstd, const float* gamma, const double* sum_dz, const double* sum_dzx, double count, int M,
+                     int C, int relu, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sum_dz, sum_dzx, count, M, C, relu, dtype,
+                                 S(stream));
+}
+int css_bn_param_grad(const double* sum_dz, const double* sum_dzx, float* dgamma, float* dbeta, int C, int accumulate, int device,
+                      css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_param_grad(sum_dz, sum_dzx, dgamma, dbeta, C, accumulate, S(stream));
+}
+
+// ---- pooling / resize / concat ----
+int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad, int dtype,
+                    int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_maxpool_fwd(x, out, argmax, N, H, W, C, Ho, Wo, ks, stride, pad, dtype, S(stream));
+}
+int css_maxpool_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
+                    int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_maxpool_bwd(dout, argmax, dx, N, H, W, C, Ho, Wo, ks, stride, pad, dtype, S(stream));
+}
+int css_bilinear(const void* x, int ldx, void* out, int ldo, int N, int Hs, int Ws, int C, int Hd, int Wd, int dtype_in, int dtype_out, int backward,
+                 int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bilinear(x, ldx, out, ldo, N, Hs, Ws, C, Hd, Wd, dtype_in, dtype_out, backward, S(stream));
+}
+int css_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_spatial_sum(x, ldx, out, N, HW, C, scale, dtype, S(stream));
+}
+int css_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_spatial_bcast(x, out, ldo, N, HW, C, scale, dtype, S(stream));
+}
+int css_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_copy_channels(src, lds, dst, ldd, M, C, dtype_in, dtype_out, S(stream));
+}
+int css_colsum(const void* x, int ld, long M, int C, float* out, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_colsum(x, ld, M, C, out, dtype, S(stream));
+}
+int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_nchw_to_nhwc(x, out, N, C, HW, Cpad, dtype, S(stream));
+}
+int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_cast(x, out, n, dtype_in, dtype_out, S(stream));
+}
+int css_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
+                float grad_scale, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_sgd_ema(p, g, buf, ema, n, lr, momentum, wd, first, decay, grad_scale, S(stream));
+}
+int css_ema(float* ema, const float* p, long n, float decay, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ema(ema, p, n, decay, S(stream));
+}
+
+// ---- similarity / pseudo labels ----
+int css_proto_normalize(const float* proto, void* out, int K, int C, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_proto_normalize(proto, out, K, C, dtype, S(stream));
+}
+int css_similarity(const void* rep, int ld, const void* proto_n, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
+                   float temp, float strong_thr, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  ProfScope ps(4, (double)P * C * (dtype == CSS_BF16 ? 2 : 4), S(stream));
+  return css_launch_similarity(rep, ld, proto_n, sim, prob, cls, hard, P, K, C, temp, strong_thr, dtype, cu_count(device), S(stream));
+}
+int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
+                     int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_pseudo_label(sim, pred, ldp, B, h, w, K, H, W, temp, logits_rep, labels_rep, logits_cls, labels_cls, pseudo, dtype, S(stream));
+}
+int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w, int* cls,
+                  int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_class_map(l_lab, u_lab, u_logits, weak_thr, B, H, W, h, w, cls, S(stream));
+}
+
+// ---- cross entropy ----
+int css_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
+               double* stats, float* gtprob_out, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ce_fwd(logits, label, conf, conf_thr, keep_thr, K, P, HW, stats, gtprob_out, S(stream));
+}
+int css_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ce_finalize(stats, B, mode, loss, coef, S(stream));
+}
+int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef, const float* gscale,
+               int pos_only, float* dlogits, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ce_bwd(logits, label, keep_thr, K, P, HW, coef, gscale, pos_only, dlogits, S(stream));
+}
+size_t css_ohem_state_bytes(void) { return css_ohem_state_bytes_(); }
+size_t css_ohem_thr_offset(void) { return css_ohem_thr_offset_(); }
+int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,
+                       css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ohem_threshold(gtprob, P, stats, B, min_kept, thresh, state, S(stream));
+}
+
+// ---- contrastive loss ----
+size_t css_contrast_meta_bytes(void) { return css_contrast_meta_bytes_(); }
+int css_contrast_nchunks(int P) { return css_contrast_nchunks_(P); }
+int css_contrast_classify(const float* label, const float* mask, const float* prob, long sb, long sk, long sp, long psb, long psk, long psp, int P,
+                          int HW, int K, float strong_thr, int* cls, uint8_t* hard, void* meta, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_classify(label, mask, prob, sb, sk, sp, psb, psk, psp, P, HW, K, strong_thr, cls, hard, meta, S(stream));
+}
+int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_class_sums(rep, ld, cls, P, K, C, out, dtype, S(stream));
+}
+int css_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta, int device,
+                         css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_compact(cls, hard, P, K, chunkhist, listV, listH, meta, S(stream));
+}
+int css_contrast_proto_update(float* proto, const double* sums, int K, int C, float alpha, const void* meta, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_proto_update(proto, sums, K, C, alpha, meta, S(stream));
+}
+int css_contrast_sample(const float* proto, int C, const void* meta, float temp, float* cdf, const int* listV, const int* listH, int Q, int N,
+                        unsigned long long seed, unsigned long long offset, int* anchor_pix, int* neg_pix, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_sample(proto, C, meta, temp, cdf, listV, listH, Q, N, seed, offset, anchor_pix, neg_pix, S(stream));
+}
+int css_contrast_resolve(const void* meta, const int* listV, const int* listH, int Q, int N, const int* anchor_idx, const int* neg_idx,
+                         int* anchor_pix, int* neg_pix, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_resolve(meta, listV, listH, Q, N, anchor_idx, neg_idx, anchor_pix, neg_pix, S(stream));
+}
+int css_contrast_loss(const void* rep, int ld, const float* proto, int K, int C, const void* meta, const int* anchor_pix, const int* neg_pix, int Q,
+                      int N, float temp, float* loss_vq, float* gradbuf, float* loss, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  ProfScope ps(3, (double)K * Q * (N + 1) * C * (dtype == CSS_BF16 ? 2 : 4), S(stream));
+  return css_launch_contrast_loss(rep, ld, proto, K, C, meta, anchor_pix, neg_pix, Q, N, temp, loss_vq, gradbuf, loss, dtype, S(stream));
+}
+int css_contrast_scatter_grad(const float* gradbuf, const int* anchor_pix, const void* meta, int K, int Q, const float* gscale, void* drep, int ld,
+                              int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_contrast_scatter_grad(gradbuf, anchor_pix, meta, K, Q, gscale, drep, ld, dtype, S(stream));
+}
+
+}  // extern "C"

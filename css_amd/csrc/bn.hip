@@ -1,0 +1,308 @@
+// Train/eval BatchNorm for NHWC activations [M][ld] on gfx950 (HBM-bound).
+// Replaces nn.BatchNorm2d / nn.SyncBatchNorm as used on the reference hot path
+// (generalframeworks/networks/resnet.py:110-137, deeplabv3/aspp.py:21,32,49,62,
+//  deeplabv3/deeplabv3.py:117,123,130; SyncBN conversion at mix_label.py:76):
+//   bn_stats      per-channel sum / sum-of-squares (fp64 accumulators; cross-rank
+//                 all-reduce of these 2C numbers replaces SyncBN's all_gather)
+//   bn_finalize   mean / invstd / fused scale+shift, running-stat update
+//   bn_apply      a = act(scale*y + shift [+ residual])
+//   bn_bwd_reduce sum(dz), sum(dz*xhat) with dz = da * (a > 0)
+//   bn_bwd_apply  dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), optional residual grad
+#include "common.h"
+
+// generic two-value per-channel reduction over rows ------------------------------------
+template <typename T, typename F>
+__device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_block, double* out0, double* out1) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const int TPC = CV < 256 ? CV : 256;
+  const int RPB = 256 / TPC;
+  const int tid = threadIdx.x;
+  const int cvi = tid % TPC, rg = tid / TPC;
+  const int cv = blockIdx.y * TPC + cvi;
+  const bool active = rg < RPB && cv < CV;
+  float s0[VEC], s1[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.f;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(M, row0 + rows_per_block);
+  if (active) {
+    for (int r = row0 + rg; r < row1; r += RPB) f(r, cv * VEC, s0, s1);
+  }
+  __shared__ float red[2][256 * VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    red[0][tid * VEC + e] = s0[e];
+    red[1][tid * VEC + e] = s1[e];
+  }
+  __syncthreads();
+  if (rg == 0 && cv < CV) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      double a0 = 0, a1 = 0;
+      for (int g = 0; g < RPB; ++g) {
+        a0 += red[0][(g * TPC + cvi) * VEC + e];
+        a1 += red[1][(g * TPC + cvi) * VEC + e];
+      }
+      atomicAdd(out0 + cv * VEC + e, a0);
+      atomicAdd(out1 + cv * VEC + e, a1);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int M, int C, int ld,
+                                                       int rows_per_block, double* sum, double* sumsq) {
+  constexpr int VEC = 16 / sizeof(T);
+  auto f = [&](int r, int c, float* s0, float* s1) {
+    Vec16<T> v;
+    v.load(y + (size_t)r * ld + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v.f(e);
+      s0[e] += x;
+      s1[e] += x * x;
+    }
+  };
+  channel_reduce2<T>(f, M, C, rows_per_block, sum, sumsq);
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float* running_mean, float* running_var, float momentum, float eps,
+                                   float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double mean = sum[c] / count;
+  double var = sumsq[c] / count - mean * mean;
+  if (var < 0) var = 0;
+  float fmean = (float)mean, fvar = (float)var;
+  float invstd = 1.0f / sqrtf(fvar + eps);
+  mean_out[c] = fmean;
+  invstd_out[c] = invstd;
+  float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - fmean * sc;
+  if (running_mean) {
+    double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// eval mode: scale/shift from running statistics
+__global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                     const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                     float eps, float* scale_out, float* shift_out, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - running_mean[c] * sc;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
+                                                       T* __restrict__ out, int ldo, const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int M, int C, int relu) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)M * CV;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
+    Vec16<T> v, o, rr;
+    v.load(y + (size_t)r * ldy + c);
+    if (res) rr.load(res + (size_t)r * ldr + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float x = v.f(e) * scale[c + e] + shift[c + e];
+      if (res) x += rr.f(e);
+      if (relu) x = fmaxf(x, 0.f);
+      o.set(e, x);
+    }
+    o.store(out + (size_t)r * ldo + c);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a,
+                                                            int lda, const T* __restrict__ y, int ldy,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            int M, int C, int relu, int rows_per_block, double* sum_dz,
+                                                            double* sum_dzx) {
+  constexpr int VEC = 16 / sizeof(T);
+  auto f = [&](int r, int c, float* s0, float* s1) {
+    Vec16<T> g, av, yv;
+    g.load(da + (size_t)r * ldda + c);
+    yv.load(y + (size_t)r * ldy + c);
+    if (relu) av.load(a + (size_t)r * lda + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float dz = g.f(e);
+      if (relu && !(av.f(e) > 0.f)) dz = 0.f;
+      float xh = (yv.f(e) - mean[c + e]) * invstd[c + e];
+      s0[e] += dz;
+      s1[e] += dz * xh;
+    }
+  };
+  channel_reduce2<T>(f, M, C, rows_per_block, sum_dz, sum_dzx);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a, int lda,
+                                                           const T* __restrict__ y, int ldy, T* __restrict__ dy, int lddy,
+                                                           T* __restrict__ dres, int lddr, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx,
+                                                           double count, int M, int C, int relu) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)M * CV;
+  const float inv_n = (float)(1.0 / count);
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
+    Vec16<T> g, av, yv, o, dr;
+    g.load(da + (size_t)r * ldda + c);
+    yv.load(y + (size_t)r * ldy + c);
+    if (relu) av.load(a + (size_t)r * lda + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      float dz = g.f(e);
+      if (relu && !(av.f(e) > 0.f)) dz = 0.f;
+      const float is = invstd[c + e];
+      const float xh = (yv.f(e) - mean[c + e]) * is;
+      const float m1 = (float)sum_dz[c + e] * inv_n, m2 = (float)sum_dzx[c + e] * inv_n;
+      o.set(e, gamma[c + e] * is * (dz - m1 - xh * m2));
+      dr.set(e, dz);
+    }
+    o.store(dy + (size_t)r * lddy + c);
+    if (dres) dr.store(dres + (size_t)r * lddr + c);
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, float* dgamma,
+                                     float* dbeta, int C, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (accumulate) {
+    dgamma[c] += (float)sum_dzx[c];
+    dbeta[c] += (float)sum_dz[c];
+  } else {
+    dgamma[c] = (float)sum_dzx[c];
+    dbeta[c] = (float)sum_dz[c];
+  }
+}
+
+// ---- launchers -----------------------------------------------------------
+static inline int pick_rows_per_block(int M, int C, int vec) {
+  const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
+  int rpb = RPB * 64;                       // <= 64 rows per thread in fp32 before the fp64 atomics
+  const int ybl = (CV + TPC - 1) / TPC;
+  while (rpb > RPB * 4 && (long)cdiv(M, rpb) * ybl < 1024) rpb /= 2;
+  return rpb;
+}
+
+template <typename T>
+static int bn_stats_T(const void* y, int M, int C, int ld, double* sum, double* sumsq, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (C % VEC || ld % VEC) return CSS_ERR_ARG;
+  const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
+  const int rpb = pick_rows_per_block(M, C, VEC);
+  dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
+  hipLaunchKernelGGL(bn_stats_kernel<T>, g, dim3(256), 0, st, (const T*)y, M, C, ld, rpb, sum, sumsq);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_OK;
+  return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, M, C, ld, sum, sumsq, st)
+         : dtype == CSS_F32 ? bn_stats_T<float>(y, M, C, ld, sum, sumsq, st) : CSS_ERR_DTYPE;
+}
+
+int css_launch_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                           float* scale, float* shift, int C, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sum, sumsq, count, gamma, beta, running_mean,
+                     running_var, momentum, eps, mean, invstd, scale, shift, C);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale,
+                             float* shift, int C, hipStream_t st) {
+  hipLaunchKernelGGL(bn_eval_coeff_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, gamma, beta, rm, rv, eps, scale, shift, C);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+static inline int ew_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
+}
+
+template <typename T>
+static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
+                      const float* shift, int M, int C, int relu, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
+  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)y, ldy,
+                     (const T*)res, ldr, (T*)out, ldo, scale, shift, M, C, relu);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
+                        const float* shift, int M, int C, int relu, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_OK;
+  return dtype == CSS_BF16 ? bn_apply_T<bf16_t>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, st)
+         : dtype == CSS_F32 ? bn_apply_T<float>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, st) : CSS_ERR_DTYPE;
+}
+
+template <typename T>
+static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
+                           const float* invstd, int M, int C, int relu, double* s0, double* s1, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (C % VEC || ldda % VEC || ldy % VEC || (relu && lda % VEC)) return CSS_ERR_ARG;
+  const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
+  const int rpb = pick_rows_per_block(M, C, VEC);
+  dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean,
+                     invstd, M, C, relu, rpb, s0, s1);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
+                             const float* invstd, int M, int C, int relu, double* s0, double* s1, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_OK;
+  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, s0, s1, st)
+         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, s0, s1, st)
+                            : CSS_ERR_DTYPE;
+}
+
+template <typename T>
+static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
+                          void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* s0,
+                          const double* s1, double count, int M, int C, int relu, hipStream_t st) {
+  constexpr int VEC = 16 / sizeof(T);
+  if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && lda % VEC) || (dres && lddr % VEC)) return CSS_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)da, ldda,
+                     (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, (T*)dres, lddr, mean, invstd, gamma, s0, s1, count, M, C,
+                     relu);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
+                            void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* s0,
+                            const double* s1, double count, int M, int C, int relu, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_OK;
+  return dtype == CSS_BF16
+             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, s0, s1, count, M, C, relu, st)
+         : dtype == CSS_F32
+             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, s0, s1, count, M, C, relu, st)
+             : CSS_ERR_DTYPE;
+}
+int css_launch_bn_param_grad(const double* s0, const double* s1, float* dgamma, float* dbeta, int C, int accumulate,
+                             hipStream_t st) {
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, s0, s1, dgamma, dbeta, C, accumulate);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}

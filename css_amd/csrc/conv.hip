@@ -1,0 +1,471 @@
+// Implicit-GEMM convolution for NHWC activations on gfx950 (CDNA4):
+//   conv_igemm_kernel : forward and data-gradient (one kernel, two gather modes)
+//   conv_wgrad_kernel : weight gradient (split over pixels, fp32 atomic accumulate)
+//
+// Replaces the cuDNN convolutions the reference reaches through nn.Conv2d in
+//   generalframeworks/networks/resnet.py:24-40,119-139 (Bottleneck 1x1 / 3x3 dilated),
+//   generalframeworks/networks/deeplabv3/aspp.py:17-72 (ASPP 1x1 + dilated 3x3),
+//   generalframeworks/networks/deeplabv3/deeplabv3.py:115-133,151-169 (decoder heads).
+//
+// Data layout: activations [N][H][W][ld] (channels innermost, ld >= C), weights
+// [Cout][R][S][Cin] (= torch channels_last physical layout of an nn.Conv2d weight).
+// GEMM view: Out[M = N*Ho*Wo][Cout] = A[M][K = R*S*Cin] * W[Cout][K]^T, both operands
+// K-contiguous, so every MFMA fragment is one 16-byte LDS read.
+//
+// MFMA: v_mfma_f32_32x32x16_bf16 (bf16 in, fp32 accumulate) for the throughput path and
+// v_mfma_f32_32x32x2_f32 (exact fp32) for the parity path. The weight tile is the MFMA
+// "A" operand and the activation tile the "B" operand, so a lane owns one output pixel and
+// four consecutive output channels per accumulator quad: the epilogue packs those and goes
+// through LDS to full 16-byte row-contiguous stores.
+#include "common.h"
+#include "launchers.h"
+
+// --------------------------------------------------------------------------
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+  static constexpr int KS = 16;  // reduction elements consumed per MFMA
+  typedef bf16x8 frag;
+  static __device__ __forceinline__ frag load(const bf16_t* row_k, int h) {
+    return *reinterpret_cast<const frag*>(row_k + h * 8);
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct Mma<float> {
+  static constexpr int KS = 2;
+  typedef float frag;
+  static __device__ __forceinline__ frag load(const float* row_k, int h) { return row_k[h]; }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
+  using MT = Mma<T>;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int KV = BK / VEC;       // 16-B vectors per tile row
+  constexpr int STR = BK + VEC;      // LDS row stride in elements (pad = one vector: conflict-free b128 reads)
+  constexpr int RPP = 256 / KV;      // tile rows covered per pass of the 256 threads
+  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int CSTR = WTN + VEC;
+  constexpr int AB_ELEMS = 2 * (BM + BN) * STR;
+  constexpr int C_ELEMS = 4 * WTM * CSTR;
+  constexpr int SM_ELEMS = AB_ELEMS > C_ELEMS ? AB_ELEMS : C_ELEMS;
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves");
+  static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/thread mapping");
+  __shared__ __attribute__((aligned(16))) T smem[SM_ELEMS];
+  T* As = smem;
+  T* Bs = smem + 2 * BM * STR;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+
+  const int kv = tid % KV;
+  const int prow = tid / KV;
+
+  // ---- per-row bookkeeping for this thread's A_IT activation rows -------
+  int a_base[A_IT], a_h[A_IT], a_w[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    int m = m0 + prow + i * RPP;
+    if (m < a.M) {
+      int hw = a.Hd * a.Wd;
+      int n_img = m / hw;
+      int rem = m - n_img * hw;
+      int hd = rem / a.Wd;
+      int wd = rem - hd * a.Wd;
+      a_base[i] = n_img * a.Hs * a.Ws;
+      if (a.mode == 0) {
+        a_h[i] = hd * a.stride - a.pad;
+        a_w[i] = wd * a.stride - a.pad;
+      } else {
+        a_h[i] = hd + a.pad;
+        a_w[i] = wd + a.pad;
+      }
+    } else {
+      a_base[i] = 0;
+      a_h[i] = -0x40000000;
+      a_w[i] = -0x40000000;
+    }
+  }
+  // ---- running (tap, channel) position of this thread's vector column ---
+  int kc = kv * VEC, tr = 0, ts = 0;
+  while (kc >= a.Cs) {
+    kc -= a.Cs;
+    if (++ts == a.S) { ts = 0; ++tr; }
+  }
+  int kglob = kv * VEC;  // global k of this thread's vector (for the weight tile)
+
+  uint4 ra[A_IT], rb[B_IT];
+  auto load_tiles = [&]() {
+    const bool tap_ok = tr < a.R;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int hs, ws;
+      bool ok = tap_ok;
+      if (a.mode == 0) {
+        hs = a_h[i] + tr * a.dil;
+        ws = a_w[i] + ts * a.dil;
+      } else {
+        int th = a_h[i] - tr * a.dil, tw = a_w[i] - ts * a.dil;
+        ok = ok && th >= 0 && tw >= 0;
+        if (a.stride == 2) {
+          ok = ok && !((th | tw) & 1);
+          hs = th >> 1;
+          ws = tw >> 1;
+        } else {
+          hs = th;
+          ws = tw;
+        }
+      }
+      ok = ok && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
+      if (ok) {
+        size_t off = (size_t)(a_base[i] + hs * a.Ws + ws) * a.lds + kc;
+        ra[i] = *reinterpret_cast<const uint4*>(src + off);
+      } else {
+        ra[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+      int n = n0 + prow + i * RPP;
+      if (n < a.Cd && kglob < a.Ktot) {
+        rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)n * a.Ktot + kglob);
+      } else {
+        rb[i] = make_uint4(0, 0, 0, 0);
+      }
+    }
+  };
+  auto advance_k = [&]() {
+    kglob += BK;
+    kc += BK;
+    while (kc >= a.Cs) {
+      kc -= a.Cs;
+      if (++ts == a.S) { ts = 0; ++tr; }
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    T* Ab = As + buf * BM * STR;
+    T* Bb = Bs + buf * BN * STR;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i)
+      *reinterpret_cast<uint4*>(Ab + (prow + i * RPP) * STR + kv * VEC) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i)
+      *reinterpret_cast<uint4*>(Bb + (prow + i * RPP) * STR + kv * VEC) = rb[i];
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (a.Ktot + BK - 1) / BK;
+  load_tiles();
+  store_tiles(0);
+  __syncthreads();
+  const int l31 = lane & 31, lh = lane >> 5;
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      advance_k();
+      load_tiles();
+    }
+    const T* Ab = As + cur * BM * STR + (wm * WTM + l31) * STR;
+    const T* Bb = Bs + cur * BN * STR + (wn * WTN + l31) * STR;
+#pragma unroll
+    for (int ks = 0; ks < BK / MT::KS; ++ks) {
+      typename MT::frag fw[TN], fa[TM];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fw[i] = MT::load(Bb + i * 32 * STR + ks * MT::KS, lh);
+#pragma unroll
+      for (int j = 0; j < TM; ++j) fa[j] = MT::load(Ab + j * 32 * STR + ks * MT::KS, lh);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = MT::mma(fw[i], fa[j], acc[i][j]);
+    }
+    if (kt + 1 < nk) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: accumulators -> LDS (wave-private) -> 16-byte row stores
+  // D[row -> n][col -> m]: lane owns pixel m = l31, channels 8*q + 4*lh + {0..3} per quad q.
+  T* Cw = smem + wave * (WTM * CSTR);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = i * 32 + 8 * q + 4 * lh;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int n = n0 + wn * WTN + nl + e;
+          bv[e] = n < a.Cd ? a.bias[n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        T* p = Cw + (j * 32 + l31) * CSTR + nl;
+        union { T e[4]; uint2 u2; uint4 u4; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.e[e] = ElemT<T>::from_f(acc[i][j][4 * q + e] + bv[e]);
+        if constexpr (sizeof(T) == 2) *reinterpret_cast<uint2*>(p) = pk.u2;
+        else *reinterpret_cast<uint4*>(p) = pk.u4;
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  constexpr int CV = WTN / VEC;  // vectors per staged row
+  const bool vec_ok = (a.ldd % VEC) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
+#pragma unroll 4
+  for (int idx = lane; idx < WTM * CV; idx += 64) {
+    const int row = idx / CV, cv = idx - row * CV;
+    const int m = m0 + wm * WTM + row;
+    const int n = n0 + wn * WTN + cv * VEC;
+    if (m >= a.M || n >= a.Cd) continue;
+    const T* p = Cw + row * CSTR + cv * VEC;
+    T* o = dst + (size_t)m * a.ldd + n;
+    if (vec_ok && n + VEC <= a.Cd) {
+      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p);
+    } else {
+      for (int e = 0; e < VEC && n + e < a.Cd; ++e) o[e] = p[e];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
+// Weight gradient: dW[n][k] += sum_m dY[m][n] * X(m, k)     (k = (r, s, c))
+// Both operands are contiguous along the NON-reduced index in memory, so the bf16 path
+// keeps the tiles as loaded ([pixel][channel]) and reads MFMA fragments with the gfx950
+// transposing LDS read (ds_read_b64_tr_b16); the fp32 path uses ds_read_b32.
+// --------------------------------------------------------------------------
+template <typename T> struct WgFrag;
+template <> struct WgFrag<bf16_t> {
+  static constexpr int KS = 16;
+  typedef bf16x8 frag;
+  // tile[kk][col] with row stride RS (elements). Operand element (idx = lane&31, kk = 8*(lane>>5)+j).
+  static __device__ __forceinline__ frag load(const bf16_t* tile, int RS, int kk0, int col0, int lane) {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+    const bf16_t* ad = tile + (kk0 + 8 * (g >> 1) + q) * RS + col0 + 16 * (g & 1) + 4 * p;
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad + 4 * RS));
+    union { struct { s16x4 a, b; } s; frag f; } u;
+    u.s.a = lo;
+    u.s.b = hi;
+    return u.f;
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct WgFrag<float> {
+  static constexpr int KS = 2;
+  typedef float frag;
+  static __device__ __forceinline__ frag load(const float* tile, int RS, int kk0, int col0, int lane) {
+    return tile[(kk0 + (lane >> 5)) * RS + col0 + (lane & 31)];
+  }
+  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+  }
+};
+
+// BN_: output-channel tile, BKC: k-column tile, BP: pixels per iteration
+template <typename T, int BN_, int BKC, int BP>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
+  using WF = WgFrag<T>;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int YV = BN_ / VEC, XV = BKC / VEC;        // vectors per tile row
+  constexpr int YS = BN_ + 64 / (int)sizeof(T);        // row stride: +64 B keeps the 4 rows of a tr-read on disjoint banks
+  constexpr int XS = BKC + 64 / (int)sizeof(T);
+  constexpr int Y_RPP = 256 / YV, X_RPP = 256 / XV;
+  constexpr int Y_IT = BP / Y_RPP, X_IT = BP / X_RPP;
+  constexpr int WTN = BN_ / 2, WTK = BKC / 2;          // 2x2 waves
+  constexpr int TN = WTN / 32, TK = WTK / 32;
+  static_assert(BP % Y_RPP == 0 && BP % X_RPP == 0, "mapping");
+  __shared__ __attribute__((aligned(16))) T smem[2 * BP * (YS + XS)];
+  T* Ysm = smem;                 // [2][BP][YS]
+  T* Xsm = smem + 2 * BP * YS;   // [2][BP][XS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 1, wk = wave & 1;
+  const int k0 = blockIdx.x * BKC, n0 = blockIdx.y * BN_;
+  const int m_begin = blockIdx.z * a.m_per_split;
+  const int m_end = min(a.M, m_begin + a.m_per_split);
+  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
+
+  // X-tile column owned by this thread: fixed (tap, channel) for the whole reduction
+  const int xv = tid % XV, xrow = tid / XV;
+  const int kcol = k0 + xv * VEC;
+  const bool k_ok = kcol < a.Ktot;
+  int tap = k_ok ? kcol / a.Cs : 0;
+  const int xc = k_ok ? kcol - tap * a.Cs : 0;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
+  const int yv = tid % YV, yrow = tid / YV;
+  const int ncol = n0 + yv * VEC;
+  const bool n_ok = ncol < a.Cd;
+
+  uint4 rx[X_IT], ry[Y_IT];
+  auto load_tiles = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i) {
+      const int m = mb + xrow + i * X_RPP;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (k_ok && m < m_end) {
+        const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
+        const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
+        const uint32_t hd = fdiv(rem, a.fd_w);
+        const uint32_t wd = rem - hd * a.fd_w.d;
+        const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
+        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws) {
+          size_t off = (size_t)((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc;
+          v = *reinterpret_cast<const uint4*>(x + off);
+        }
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i) {
+      const int m = mb + yrow + i * Y_RPP;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (n_ok && m < m_end) v = *reinterpret_cast<const uint4*>(dy + (size_t)m * a.ldy + ncol);
+      ry[i] = v;
+    }
+  };
+  auto store_tiles = [&](int buf) {
+    T* Yb = Ysm + buf * BP * YS;
+    T* Xb = Xsm + buf * BP * XS;
+#pragma unroll
+    for (int i = 0; i < X_IT; ++i)
+      *reinterpret_cast<uint4*>(Xb + (xrow + i * X_RPP) * XS + xv * VEC) = rx[i];
+#pragma unroll
+    for (int i = 0; i < Y_IT; ++i)
+      *reinterpret_cast<uint4*>(Yb + (yrow + i * Y_RPP) * YS + yv * VEC) = ry[i];
+  };
+
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nit = (m_end - m_begin + BP - 1) / BP;
+  if (nit > 0) {
+    load_tiles(m_begin);
+    store_tiles(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < nit; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < nit) load_tiles(m_begin + (it + 1) * BP);
+    const T* Yb = Ysm + cur * BP * YS;
+    const T* Xb = Xsm + cur * BP * XS;
+#pragma unroll
+    for (int ks = 0; ks < BP / WF::KS; ++ks) {
+      typename WF::frag fy[TN], fx[TK];
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fy[i] = WF::load(Yb, YS, ks * WF::KS, wn * WTN + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fx[j] = WF::load(Xb, XS, ks * WF::KS, wk * WTK + j * 32, lane);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = WF::mma(fy[i], fx[j], acc[i][j]);
+    }
+    if (it + 1 < nit) store_tiles(cur ^ 1);
+    __syncthreads();
+  }
+  if (nit == 0) return;
+  // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int k = k0 + wk * WTK + j * 32 + l31;
+      if (k >= a.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
+      }
+    }
+}
+
+// --------------------------------------------------------------------------
+// host-side launchers (called from abi.cpp through these C++ entry points)
+// --------------------------------------------------------------------------
+int css_launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
+  if (dtype == CSS_BF16) {
+    if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
+      return CSS_ERR_ARG;
+    if (a.Cd > 64) {
+      dim3 g(cdiv(a.M, 128), cdiv(a.Cd, 128));
+      hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, a);
+    } else {
+      dim3 g(cdiv(a.M, 128), cdiv(a.Cd, 64));
+      hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, a);
+    }
+  } else if (dtype == CSS_F32) {
+    if (a.Cs % 4 || a.lds % 4 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
+      return CSS_ERR_ARG;
+    dim3 g(cdiv(a.M, 64), cdiv(a.Cd, 64));
+    hipLaunchKernelGGL((conv_igemm_kernel<float, 64, 64, 16, 2, 2>), g, dim3(256), 0, st, a);
+  } else {
+    return CSS_ERR_DTYPE;
+  }
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
+  if (a.M <= 0) return CSS_OK;
+  a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
+  a.fd_w = make_fastdiv((uint32_t)a.Wd);
+  int bn, bkc, bp;
+  if (dtype == CSS_BF16) {
+    bn = 128; bkc = 128; bp = 64;
+    if (a.Cs % 8 || a.ldx % 8 || a.ldy % 8 || a.Cd % 8) return CSS_ERR_ARG;
+  } else if (dtype == CSS_F32) {
+    bn = 64; bkc = 64; bp = 16;
+    if (a.Cs % 4 || a.ldx % 4 || a.ldy % 4 || a.Cd % 4) return CSS_ERR_ARG;
+  } else {
+    return CSS_ERR_DTYPE;
+  }
+  if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.dy) & 15)) return CSS_ERR_ARG;
+  const int tiles = cdiv(a.Ktot, bkc) * cdiv(a.Cd, bn);
+  // enough splits over the pixel dimension to fill the chip ~4x, but >= 8 iterations each
+  int splits = (4 * n_cu + tiles - 1) / tiles;
+  int max_splits = cdiv(a.M, 8 * bp);
+  if (splits > max_splits) splits = max_splits;
+  if (splits < 1) splits = 1;
+  int mps = cdiv(a.M, splits);
+  mps = cdiv(mps, bp) * bp;
+  splits = cdiv(a.M, mps);
+  a.m_per_split = mps;
+  dim3 g(cdiv(a.Ktot, bkc), cdiv(a.Cd, bn), splits);
+  if (dtype == CSS_BF16)
+    hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}

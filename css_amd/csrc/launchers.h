@@ -1,0 +1,97 @@
+// Internal: argument structs and the C++ launch entry points each .hip file exports to abi.hip.
+#pragma once
+#include "common.h"
+
+struct ConvArgs {
+  const void* src;    // gathered tensor   [N][Hs][Ws][lds]
+  const void* wt;     // [Cd][Ktot]  (Ktot = R*S*Cs, Cs innermost)
+  void* dst;          // [N][Hd][Wd][ldd]
+  const float* bias;  // [Cd] or null
+  int N, Hs, Ws, Cs, lds;
+  int Hd, Wd, Cd, ldd;
+  int R, S, stride, pad, dil;
+  int mode;  // 0: forward gather  hs = hd*stride - pad + r*dil
+             // 1: dgrad gather    hs = (hd + pad - r*dil) / stride   (must divide)
+  int M, Ktot;
+};
+
+struct WgradArgs {
+  const void* x;   // [N][Hs][Ws][ldx]
+  const void* dy;  // [M][ldy]
+  float* dw;       // [Cd][Ktot] fp32, accumulated with atomics
+  int N, Hs, Ws, Cs, ldx;
+  int Hd, Wd, Cd, ldy;
+  int R, S, stride, pad, dil;
+  int M, Ktot, m_per_split;
+  FastDiv fd_hw, fd_w;
+};
+
+
+int css_launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
+int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st);
+
+int css_launch_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, hipStream_t st);
+int css_launch_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
+                           hipStream_t st);
+int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int C,
+                             hipStream_t st);
+int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
+                        int relu, int dtype, hipStream_t st);
+int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int M,
+                             int C, int relu, double* s0, double* s1, int dtype, hipStream_t st);
+int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
+                            const float* mean, const float* invstd, const float* gamma, const double* s0, const double* s1, double count, int M,
+                            int C, int relu, int dtype, hipStream_t st);
+int css_launch_bn_param_grad(const double* s0, const double* s1, float* dgamma, float* dbeta, int C, int accumulate, hipStream_t st);
+
+int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
+                           int dtype, hipStream_t st);
+int css_launch_maxpool_bwd(const void* dout, const uint8_t* arg, void* dx, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
+                           int dtype, hipStream_t st);
+int css_launch_bilinear(const void* x, int ldx, void* out, int ldo, int N, int Hs, int Ws, int C, int Hd, int Wd, int dtype_in, int dtype_out,
+                        int backward, hipStream_t st);
+int css_launch_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, hipStream_t st);
+int css_launch_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, hipStream_t st);
+int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out, hipStream_t st);
+int css_launch_colsum(const void* x, int ld, long M, int C, float* out, int dtype, hipStream_t st);
+int css_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, hipStream_t st);
+int css_launch_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, hipStream_t st);
+int css_launch_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, hipStream_t st);
+int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
+                       float grad_scale, hipStream_t st);
+int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t st);
+
+int css_launch_proto_normalize(const float* proto, void* out, int K, int C, int dtype, hipStream_t st);
+int css_launch_similarity(const void* rep, int ld, const void* pn, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
+                          float temp, float strong_thr, int dtype, int n_cu, hipStream_t st);
+int css_launch_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
+                            int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, hipStream_t st);
+int css_launch_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w,
+                         int* cls, hipStream_t st);
+
+int css_launch_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
+                      double* stats, float* gtprob_out, hipStream_t st);
+int css_launch_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, hipStream_t st);
+int css_launch_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef,
+                      const float* gscale, int pos_only, float* dlogits, hipStream_t st);
+size_t css_ohem_state_bytes_();
+size_t css_ohem_thr_offset_();
+int css_launch_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, hipStream_t st);
+
+size_t css_contrast_meta_bytes_();
+int css_contrast_nchunks_(int P);
+int css_launch_contrast_classify(const float* label, const float* mask, const float* prob, long sb, long sk, long sp, long psb, long psk, long psp,
+                                 int P, int HW, int K, float strong_thr, int* cls, uint8_t* hard, void* meta, hipStream_t st);
+int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, hipStream_t st);
+int css_launch_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta,
+                                hipStream_t st);
+int css_launch_contrast_proto_update(float* proto, const double* sums, int K, int C, float alpha, const void* meta, hipStream_t st);
+int css_launch_contrast_sample(const float* proto, int C, const void* meta, float temp, float* cdf, const int* listV, const int* listH, int Q, int N,
+                               unsigned long long seed, unsigned long long offset, int* anchor_pix, int* neg_pix, hipStream_t st);
+int css_launch_contrast_resolve(const void* meta, const int* listV, const int* listH, int Q, int N, const int* anchor_idx, const int* neg_idx,
+                                int* anchor_pix, int* neg_pix, hipStream_t st);
+int css_launch_contrast_loss(const void* rep, int ld, const float* proto, int K, int C, const void* meta, const int* anchor_pix, const int* neg_pix,
+                             int Q, int N, float temp, float* loss_vq, float* gradbuf, float* loss, int dtype, hipStream_t st);
+int css_launch_contrast_scatter_grad(const float* gradbuf, const int* anchor_pix, const void* meta, int K, int Q, const float* gscale, void* drep,
+                                     int ld, int dtype, hipStream_t st);

@@ -1,0 +1,503 @@
+// HBM-bound data-movement kernels of the network path (NHWC):
+//   max-pool 3x3/s2 (deeplabv3.py:153), bilinear resize align_corners=True
+//   (deeplabv3.py:164, ddp_model.py:111,113,141,144), global average pool + broadcast
+//   (aspp.py:27-38), channel concat / slice (aspp.py:71, deeplabv3.py:165-166),
+//   NCHW<->NHWC image staging, dtype casts and weight re-layout, fused SGD(nesterov)+EMA
+//   (mix_label.py:96-97,194-195; ddp_model.py:93-97).
+#include "common.h"
+
+static inline int ew_grid(size_t total) {
+  size_t b = (total + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+#define GRID_STRIDE(idx, total) \
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < (total); idx += (size_t)gridDim.x * blockDim.x)
+
+// ---- max pool -----------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, uint8_t* __restrict__ arg,
+                                                          int N, int H, int W, int C, int Ho, int Wo, int ks, int stride,
+                                                          int pad) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)N * Ho * Wo * CV;
+  GRID_STRIDE(idx, total) {
+    const int cv = (int)(idx % CV);
+    size_t p = idx / CV;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho), n = (int)(p / Ho);
+    float best[VEC];
+    uint8_t bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+    for (int r = 0; r < ks; ++r) {
+      const int hi = ho * stride - pad + r;
+      if ((unsigned)hi >= (unsigned)H) continue;
+      for (int s = 0; s < ks; ++s) {
+        const int wi = wo * stride - pad + s;
+        if ((unsigned)wi >= (unsigned)W) continue;
+        Vec16<T> v;
+        v.load(x + ((size_t)(n * H + hi) * W + wi) * C + cv * VEC);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float f = v.f(e);
+          if (f > best[e] || f != f) { best[e] = f; bi[e] = (uint8_t)(r * ks + s); }
+        }
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, best[e]);
+    const size_t ob = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VEC;
+    o.store(out + ob);
+    if (arg) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) arg[ob + e] = bi[e];
+    }
+  }
+}
+
+// gather form: each input element sums the gradients of the windows whose arg-max it is
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg,
+                                                          T* __restrict__ dx, int N, int H, int W, int C, int Ho, int Wo, int ks,
+                                                          int stride, int pad) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)N * H * W * CV;
+  GRID_STRIDE(idx, total) {
+    const int cv = (int)(idx % CV);
+    size_t p = idx / CV;
+    const int wi = (int)(p % W);
+    p /= W;
+    const int hi = (int)(p % H), n = (int)(p / H);
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    for (int r = 0; r < ks; ++r) {
+      const int th = hi + pad - r;
+      if (th < 0 || th % stride) continue;
+      const int ho = th / stride;
+      if (ho >= Ho) continue;
+      for (int s = 0; s < ks; ++s) {
+        const int tw = wi + pad - s;
+        if (tw < 0 || tw % stride) continue;
+        const int wo = tw / stride;
+        if (wo >= Wo) continue;
+        const size_t ob = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VEC;
+        Vec16<T> g;
+        g.load(dout + ob);
+        const uint8_t want = (uint8_t)(r * ks + s);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (arg[ob + e] == want) acc[e] += g.f(e);
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+    o.store(dx + idx * VEC);
+  }
+}
+
+// ---- bilinear, align_corners=True ---------------------------------------
+// src index of dst d: f = d * (S-1)/(D-1) (0 if D == 1); i0 = (int)f, i1 = min(i0+1, S-1), w1 = f - i0
+struct Lin { int i0, i1; float w0, w1; };
+__device__ __forceinline__ Lin lin_coord(int d, int S, float scale) {
+  Lin l;
+  float f = scale * (float)d;
+  l.i0 = (int)f;
+  if (l.i0 > S - 1) l.i0 = S - 1;
+  l.i1 = l.i0 + (l.i0 < S - 1 ? 1 : 0);
+  l.w1 = f - (float)l.i0;
+  l.w0 = 1.f - l.w1;
+  return l;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const TI* __restrict__ x, int ldx, TO* __restrict__ out, int ldo, int N,
+                                                           int Hs, int Ws, int C, int Hd, int Wd, float sh, float sw) {
+  const size_t total = (size_t)N * Hd * Wd * C;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % C);
+    size_t p = idx / C;
+    const int wd = (int)(p % Wd);
+    p /= Wd;
+    const int hd = (int)(p % Hd), n = (int)(p / Hd);
+    const Lin ly = lin_coord(hd, Hs, sh), lx = lin_coord(wd, Ws, sw);
+    const TI* b = x + (size_t)n * Hs * Ws * ldx + c;
+    const float v00 = (float)b[((size_t)ly.i0 * Ws + lx.i0) * ldx], v01 = (float)b[((size_t)ly.i0 * Ws + lx.i1) * ldx];
+    const float v10 = (float)b[((size_t)ly.i1 * Ws + lx.i0) * ldx], v11 = (float)b[((size_t)ly.i1 * Ws + lx.i1) * ldx];
+    const float v = ly.w0 * (lx.w0 * v00 + lx.w1 * v01) + ly.w1 * (lx.w0 * v10 + lx.w1 * v11);
+    out[((size_t)(n * Hd + hd) * Wd + wd) * ldo + c] = (TO)v;
+  }
+}
+
+// gather form of the adjoint: each source element collects from the destination range that references it
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const TI* __restrict__ dout, int ldo, TO* __restrict__ dx, int ldx, int N,
+                                                           int Hs, int Ws, int C, int Hd, int Wd, float sh, float sw) {
+  const size_t total = (size_t)N * Hs * Ws * C;
+  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % C);
+    size_t p = idx / C;
+    const int ws = (int)(p % Ws);
+    p /= Ws;
+    const int hs = (int)(p % Hs), n = (int)(p / Hs);
+    int h_lo, h_hi, w_lo, w_hi;
+    if (sh > 0.f) {
+      h_lo = max(0, (int)floorf((float)(hs - 1) * ish) - 1);
+      h_hi = min(Hd - 1, (int)ceilf((float)(hs + 1) * ish) + 1);
+    } else { h_lo = 0; h_hi = Hd - 1; }
+    if (sw > 0.f) {
+      w_lo = max(0, (int)floorf((float)(ws - 1) * isw) - 1);
+      w_hi = min(Wd - 1, (int)ceilf((float)(ws + 1) * isw) + 1);
+    } else { w_lo = 0; w_hi = Wd - 1; }
+    float acc = 0.f;
+    for (int hd = h_lo; hd <= h_hi; ++hd) {
+      const Lin ly = lin_coord(hd, Hs, sh);
+      float wy = 0.f;
+      if (ly.i0 == hs) wy += ly.w0;
+      if (ly.i1 == hs) wy += ly.w1;
+      if (wy == 0.f) continue;
+      const TI* row = dout + ((size_t)(n * Hd + hd) * Wd) * ldo + c;
+      for (int wd = w_lo; wd <= w_hi; ++wd) {
+        const Lin lx = lin_coord(wd, Ws, sw);
+        float wx = 0.f;
+        if (lx.i0 == ws) wx += lx.w0;
+        if (lx.i1 == ws) wx += lx.w1;
+        if (wx != 0.f) acc += wy * wx * (float)row[(size_t)wd * ldo];
+      }
+    }
+    dx[((size_t)(n * Hs + hs) * Ws + ws) * ldx + c] = (TO)acc;
+  }
+}
+
+// ---- global average pool / broadcast ------------------------------------
+// out[n][c] = scale * sum_{hw} x[n][hw][c]     (scale = 1/HW for the pool, 1 for the broadcast adjoint)
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_sum_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int HW, int C,
+                                                          float scale) {
+  const int n = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;  // 4 row partitions
+  float acc = 0.f;
+  if (c < C)
+    for (int p = part; p < HW; p += 4) acc += (float)x[((size_t)n * HW + p) * ldx + c];
+  __shared__ float red[4][64];
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && c < C) out[(size_t)n * C + c] = (T)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+}
+// out[n][hw][c] = scale * x[n][c]
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_bcast_kernel(const T* __restrict__ x, T* __restrict__ out, int ldo, int N, int HW,
+                                                            int C, float scale) {
+  const size_t total = (size_t)N * HW * C;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % C);
+    const size_t p = idx / C;
+    const int n = (int)(p / HW);
+    out[p * ldo + c] = (T)((float)x[(size_t)n * C + c] * scale);
+  }
+}
+
+// ---- column sum: out[c] += sum_m x[m][c]  (bias gradients) ---------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int part = threadIdx.x >> 6;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc = 0.f;
+  if (c < C)
+    for (long r = r0 + part; r < r1; r += 4) acc += (float)x[(size_t)r * ld + c];
+  __shared__ float red[4][64];
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+
+// ---- strided channel copy (concat / slice), optional cast ---------------
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void copy_channels_kernel(const TI* __restrict__ src, int lds, TO* __restrict__ dst, int ldd, size_t M,
+                                                            int C) {
+  const size_t total = M * (size_t)C;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % C);
+    const size_t r = idx / C;
+    dst[r * ldd + c] = (TO)(float)src[r * lds + c];
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void copy_channels_vec_kernel(const T* __restrict__ src, int lds, T* __restrict__ dst, int ldd,
+                                                                size_t M, int C) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = M * (size_t)CV;
+  GRID_STRIDE(idx, total) {
+    const int cv = (int)(idx % CV);
+    const size_t r = idx / CV;
+    *reinterpret_cast<uint4*>(dst + r * ldd + cv * VEC) = *reinterpret_cast<const uint4*>(src + r * lds + cv * VEC);
+  }
+}
+
+// ---- NCHW fp32 image -> NHWC (channel-padded) T -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int HW,
+                                                           int Cpad) {
+  const size_t total = (size_t)N * HW * Cpad;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % Cpad);
+    const size_t p = idx / Cpad;
+    const int n = (int)(p / HW);
+    const int hw = (int)(p - (size_t)n * HW);
+    out[idx] = c < C ? (T)x[((size_t)n * C + c) * HW + hw] : (T)0.f;
+  }
+}
+
+// ---- weight re-layout ----------------------------------------------------
+// master fp32 [Cout][taps][Cin] -> T [Cout][taps][CinPad]  (fwd layout; CinPad >= Cin zero-filled)
+template <typename T>
+__global__ __launch_bounds__(256) void weight_fwd_layout_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int taps,
+                                                                int Cin, int CinPad) {
+  const size_t total = (size_t)Cout * taps * CinPad;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % CinPad);
+    const size_t kt = idx / CinPad;
+    out[idx] = c < Cin ? (T)w[kt * Cin + c] : (T)0.f;
+  }
+}
+// master fp32 [Cout][taps][Cin] -> T [Cin][taps][Cout]   (dgrad layout)
+template <typename T>
+__global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int taps,
+                                                                  int Cin) {
+  __shared__ float tile[32][33];
+  // grid: (ceil(Cin/32), ceil(Cout/32), taps); block 32x8
+  const int t = blockIdx.z;
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int k = k0 + j, c = c0 + threadIdx.x;
+    tile[j][threadIdx.x] = (k < Cout && c < Cin) ? w[((size_t)k * taps + t) * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = threadIdx.y; j < 32; j += 8) {
+    const int c = c0 + j, k = k0 + threadIdx.x;
+    if (c < Cin && k < Cout) out[((size_t)c * taps + t) * Cout + k] = (T)tile[threadIdx.x][j];
+  }
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ out, size_t n) {
+  GRID_STRIDE(idx, n) out[idx] = (TO)(float)x[idx];
+}
+
+// ---- fused SGD(nesterov, weight decay) + EMA teacher update ---------------
+// torch.optim.SGD semantics (mix_label.py:96-97): d = g + wd*p; buf = first ? d : mom*buf + d;
+// p -= lr * (d + mom*buf); then ema = decay*ema + (1-decay)*p (ddp_model.py:93-97).
+__global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
+                                                      float* __restrict__ ema, size_t n, float lr, float momentum, float wd,
+                                                      int first, float decay, float grad_scale) {
+  const size_t n4 = n / 4;
+  GRID_STRIDE(idx, n4) {
+    float4 pv = reinterpret_cast<float4*>(p)[idx];
+    const float4 gv = reinterpret_cast<const float4*>(g)[idx];
+    float4 bv = first ? make_float4(0, 0, 0, 0) : reinterpret_cast<float4*>(buf)[idx];
+    float pe[4] = {pv.x, pv.y, pv.z, pv.w}, ge[4] = {gv.x, gv.y, gv.z, gv.w}, be[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float d = ge[e] * grad_scale + wd * pe[e];
+      be[e] = first ? d : momentum * be[e] + d;
+      pe[e] -= lr * (d + momentum * be[e]);
+    }
+    reinterpret_cast<float4*>(p)[idx] = make_float4(pe[0], pe[1], pe[2], pe[3]);
+    reinterpret_cast<float4*>(buf)[idx] = make_float4(be[0], be[1], be[2], be[3]);
+    if (ema) {
+      float4 ev = reinterpret_cast<float4*>(ema)[idx];
+      ev.x = decay * ev.x + (1.f - decay) * pe[0];
+      ev.y = decay * ev.y + (1.f - decay) * pe[1];
+      ev.z = decay * ev.z + (1.f - decay) * pe[2];
+      ev.w = decay * ev.w + (1.f - decay) * pe[3];
+      reinterpret_cast<float4*>(ema)[idx] = ev;
+    }
+  }
+  // tail (n not a multiple of 4)
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const size_t i = n4 * 4 + threadIdx.x;
+    const float d = g[i] * grad_scale + wd * p[i];
+    const float b = first ? d : momentum * buf[i] + d;
+    buf[i] = b;
+    const float pn = p[i] - lr * (d + momentum * b);
+    p[i] = pn;
+    if (ema) ema[i] = decay * ema[i] + (1.f - decay) * pn;
+  }
+}
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, size_t n, float decay) {
+  GRID_STRIDE(idx, n) ema[idx] = decay * ema[idx] + (1.f - decay) * p[idx];
+}
+
+// ---- launchers -----------------------------------------------------------
+#define DISPATCH_T(dtype, CALL)                  \
+  do {                                           \
+    if ((dtype) == CSS_BF16) { using T = bf16_t; CALL; } \
+    else if ((dtype) == CSS_F32) { using T = float; CALL; } \
+    else return CSS_ERR_DTYPE;                   \
+  } while (0)
+
+int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride,
+                           int pad, int dtype, hipStream_t st) {
+  DISPATCH_T(dtype, {
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC) return CSS_ERR_ARG;
+    hipLaunchKernelGGL(maxpool_fwd_kernel<T>, dim3(ew_grid((size_t)N * Ho * Wo * (C / VEC))), dim3(256), 0, st, (const T*)x, (T*)out,
+                       arg, N, H, W, C, Ho, Wo, ks, stride, pad);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_maxpool_bwd(const void* dout, const uint8_t* arg, void* dx, int N, int H, int W, int C, int Ho, int Wo, int ks,
+                           int stride, int pad, int dtype, hipStream_t st) {
+  DISPATCH_T(dtype, {
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC) return CSS_ERR_ARG;
+    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / VEC))), dim3(256), 0, st, (const T*)dout, arg,
+                       (T*)dx, N, H, W, C, Ho, Wo, ks, stride, pad);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+static inline float ac_scale(int S, int D) { return D > 1 ? (float)(S - 1) / (float)(D - 1) : 0.f; }
+
+// dtype_in/out: CSS_F32 or CSS_BF16 (any combination)
+int css_launch_bilinear(const void* x, int ldx, void* out, int ldo, int N, int Hs, int Ws, int C, int Hd, int Wd, int dtype_in,
+                        int dtype_out, int backward, hipStream_t st) {
+  const float sh = ac_scale(Hs, Hd), sw = ac_scale(Ws, Wd);
+#define BIL(TI, TO)                                                                                                        \
+  do {                                                                                                                     \
+    if (!backward)                                                                                                         \
+      hipLaunchKernelGGL((bilinear_fwd_kernel<TI, TO>), dim3(ew_grid((size_t)N * Hd * Wd * C)), dim3(256), 0, st,          \
+                         (const TI*)x, ldx, (TO*)out, ldo, N, Hs, Ws, C, Hd, Wd, sh, sw);                                  \
+    else /* x = dout [N,Hd,Wd,ldx], out = dx [N,Hs,Ws,ldo] */                                                              \
+      hipLaunchKernelGGL((bilinear_bwd_kernel<TI, TO>), dim3(ew_grid((size_t)N * Hs * Ws * C)), dim3(256), 0, st,          \
+                         (const TI*)x, ldx, (TO*)out, ldo, N, Hs, Ws, C, Hd, Wd, sh, sw);                                  \
+  } while (0)
+  if (dtype_in == CSS_F32 && dtype_out == CSS_F32) BIL(float, float);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_BF16) BIL(bf16_t, bf16_t);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_F32) BIL(bf16_t, float);
+  else if (dtype_in == CSS_F32 && dtype_out == CSS_BF16) BIL(float, bf16_t);
+  else return CSS_ERR_DTYPE;
+#undef BIL
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, hipStream_t st) {
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(spatial_sum_kernel<T>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const T*)x, ldx, (T*)out, HW, C, scale);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, hipStream_t st) {
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(spatial_bcast_kernel<T>, dim3(ew_grid((size_t)N * HW * C)), dim3(256), 0, st, (const T*)x, (T*)out, ldo, N, HW,
+                       C, scale);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out,
+                             hipStream_t st) {
+  if (M <= 0 || C <= 0) return CSS_OK;
+  if (dtype_in == dtype_out) {
+    const int vec = dtype_in == CSS_BF16 ? 8 : 4;
+    const bool al = !(C % vec) && !(lds % vec) && !(ldd % vec) && !(reinterpret_cast<uintptr_t>(src) & 15) &&
+                    !(reinterpret_cast<uintptr_t>(dst) & 15);
+    if (al) {
+      DISPATCH_T(dtype_in, {
+        hipLaunchKernelGGL(copy_channels_vec_kernel<T>, dim3(ew_grid((size_t)M * (C / vec))), dim3(256), 0, st, (const T*)src, lds,
+                           (T*)dst, ldd, (size_t)M, C);
+      });
+      CSS_CHECK_LAUNCH();
+      return CSS_OK;
+    }
+  }
+#define CPY(TI, TO)                                                                                                   \
+  hipLaunchKernelGGL((copy_channels_kernel<TI, TO>), dim3(ew_grid((size_t)M * C)), dim3(256), 0, st, (const TI*)src, lds, \
+                     (TO*)dst, ldd, (size_t)M, C)
+  if (dtype_in == CSS_F32 && dtype_out == CSS_F32) CPY(float, float);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_BF16) CPY(bf16_t, bf16_t);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_F32) CPY(bf16_t, float);
+  else if (dtype_in == CSS_F32 && dtype_out == CSS_BF16) CPY(float, bf16_t);
+  else return CSS_ERR_DTYPE;
+#undef CPY
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_colsum(const void* x, int ld, long M, int C, float* out, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_OK;
+  const long rpb = 512;
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), cdiv(M, rpb)), dim3(256), 0, st, (const T*)x, ld, M, C, rpb, out);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, hipStream_t st) {
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(ew_grid((size_t)N * HW * Cpad)), dim3(256), 0, st, x, (T*)out, N, C, HW, Cpad);
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype,
+                             hipStream_t st) {
+  DISPATCH_T(dtype, {
+    if (!dgrad) {
+      hipLaunchKernelGGL(weight_fwd_layout_kernel<T>, dim3(ew_grid((size_t)Cout * taps * CinPad)), dim3(256), 0, st, w, (T*)out, Cout,
+                         taps, Cin, CinPad);
+    } else {
+      hipLaunchKernelGGL(weight_dgrad_layout_kernel<T>, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(32, 8), 0, st, w, (T*)out,
+                         Cout, taps, Cin);
+    }
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, hipStream_t st) {
+  if (n <= 0) return CSS_OK;
+#define CST(TI, TO) hipLaunchKernelGGL((cast_kernel<TI, TO>), dim3(ew_grid((size_t)n)), dim3(256), 0, st, (const TI*)x, (TO*)out, (size_t)n)
+  if (dtype_in == CSS_F32 && dtype_out == CSS_BF16) CST(float, bf16_t);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_F32) CST(bf16_t, float);
+  else if (dtype_in == CSS_F32 && dtype_out == CSS_F32) CST(float, float);
+  else if (dtype_in == CSS_BF16 && dtype_out == CSS_BF16) CST(bf16_t, bf16_t);
+  else return CSS_ERR_DTYPE;
+#undef CST
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first,
+                       float decay, float grad_scale, hipStream_t st) {
+  if (n <= 0) return CSS_OK;
+  if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf) |
+       reinterpret_cast<uintptr_t>(ema)) & 15)
+    return CSS_ERR_ARG;
+  hipLaunchKernelGGL(sgd_ema_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, st, p, g, buf, ema, (size_t)n, lr, momentum, wd,
+                     first, decay, grad_scale);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t st) {
+  if (n <= 0) return CSS_OK;
+  hipLaunchKernelGGL(ema_kernel, dim3(ew_grid((size_t)n)), dim3(256), 0, st, ema, p, (size_t)n, decay);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}

@@ -1,0 +1,44 @@
+"""ASPP head on HIP kernels (reference generalframeworks/networks/deeplabv3/aspp.py:17-72)."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from ... import ops
+from ...nn import ConvBNReLU, HipBatchNorm2d, HipConv2d
+
+
+class ASPPConv(ConvBNReLU):
+    def __init__(self, in_channels, out_channels, dilation):
+        super().__init__(HipConv2d(in_channels, out_channels, 3, padding=dilation, dilation=dilation, bias=False),
+                         HipBatchNorm2d(out_channels))
+
+
+class ASPPPooling(nn.Sequential):
+    """global average pool -> 1x1 conv -> BN -> ReLU -> broadcast back (aspp.py:27-38).  Child indices
+    0 (pool), 1 (conv), 2 (bn), 3 (relu) match the reference's state_dict keys ``convs.4.{1,2}.*``."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(nn.AdaptiveAvgPool2d(1), HipConv2d(in_channels, out_channels, 1, bias=False),
+                         HipBatchNorm2d(out_channels), nn.ReLU())
+
+    def forward(self, x):
+        h, w = x.shape[1], x.shape[2]
+        p = ops.global_avg_pool(x)
+        p = self[2](self[1](p), relu=True)
+        return ops.broadcast_hw(p, h, w)   # bilinear(align_corners=False) from a 1x1 map == broadcast
+
+
+class ASPP(nn.Module):
+    def __init__(self, in_channels, atrous_rates):
+        super().__init__()
+        out_channels = 256
+        modules = nn.ModuleList()
+        modules.append(ConvBNReLU(HipConv2d(in_channels, out_channels, 1, bias=False), HipBatchNorm2d(out_channels)))
+        for rate in tuple(atrous_rates):
+            modules.append(ASPPConv(in_channels, out_channels, rate))
+        modules.append(ASPPPooling(in_channels, out_channels))
+        self.convs = modules
+        self.project = ConvBNReLU(HipConv2d(5 * out_channels, out_channels, 1, bias=False), HipBatchNorm2d(out_channels))
+
+    def forward(self, x):
+        return self.project(ops.cat_channels(*[conv(x) for conv in self.convs]))

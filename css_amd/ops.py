@@ -1,0 +1,373 @@
+"""torch.autograd.Function wrappers over the C ABI (``include/css_hip.h``).
+
+Internal activation format: contiguous ``[N, H, W, C]`` tensors (NHWC), fp32 (parity path) or
+bf16 (throughput path).  PyTorch is used only for device memory, streams and autograd
+bookkeeping; every arithmetic operation below is a HIP kernel in ``css_amd/csrc``.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from ._lib import call, dev_stream, dtype_code
+
+BN_EPS = 1e-5
+
+
+def vec_of(dt: torch.dtype) -> int:
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def pad_to(c: int, v: int) -> int:
+    return (c + v - 1) // v * v
+
+
+# --------------------------------------------------------------------------
+# weight preparation cache (fp32 master [Cout,Cin,R,S] channels_last -> compute layouts)
+# --------------------------------------------------------------------------
+_wcache = {}
+_epoch = 0
+
+
+def invalidate_weight_cache():
+    """Call after parameters were modified behind autograd's back (fused SGD / EMA kernels)."""
+    global _epoch
+    _epoch += 1
+
+
+def _phys(weight: torch.Tensor) -> torch.Tensor:
+    """[Cout,R,S,Cin] contiguous fp32 view (or copy) of a conv weight."""
+    w = weight.detach().permute(0, 2, 3, 1)
+    if not w.is_contiguous():
+        w = w.contiguous()
+    return w
+
+
+def prepared_weight(weight: torch.Tensor, dtype: torch.dtype, cin_pad: int, dgrad: bool) -> torch.Tensor:
+    key = (id(weight), dtype, cin_pad, dgrad)
+    stamp = (weight.data_ptr(), weight._version, _epoch)
+    hit = _wcache.get(key)
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    cout, cin, r, s = weight.shape
+    w = _phys(weight)
+    dev, st = dev_stream(w)
+    v = vec_of(dtype)
+    if not dgrad:
+        if dtype == torch.float32 and cin_pad == cin:
+            out = w
+        else:
+            out = torch.empty((cout, r, s, cin_pad), dtype=dtype, device=w.device)
+            call("css_weight_layout", w, out, cout, r * s, cin, cin_pad, 0, dtype_code(dtype), dev, st)
+    else:
+        cout_pad = pad_to(cout, v)
+        if cout_pad != cout:
+            wp = torch.zeros((cout_pad, r, s, cin), dtype=torch.float32, device=w.device)
+            wp[:cout] = w
+            w = wp
+        out = torch.empty((cin, r, s, cout_pad), dtype=dtype, device=w.device)
+        call("css_weight_layout", w, out, cout_pad, r * s, cin, cin, 1, dtype_code(dtype), dev, st)
+    _wcache[key] = (stamp, out)
+    return out
+
+
+def conv_out_size(h, k, stride, pad, dil):
+    return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
+
+
+# --------------------------------------------------------------------------
+# convolution
+# --------------------------------------------------------------------------
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, dil):
+        n, h, w_, cp = x.shape
+        cout, cin, r, s = weight.shape
+        dt = x.dtype
+        assert x.is_contiguous() and cp == pad_to(cin, vec_of(dt)), (x.shape, weight.shape)
+        ho, wo = conv_out_size(h, r, stride, pad, dil), conv_out_size(w_, s, stride, pad, dil)
+        wf = prepared_weight(weight, dt, cp, False)
+        y = torch.empty((n, ho, wo, cout), dtype=dt, device=x.device)
+        dev, st = dev_stream(x)
+        flops = 2.0 * n * ho * wo * cout * r * s * cin
+        call("css_conv2d_forward", x, wf, bias, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
+             dtype_code(dt), dev, st)
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, pad, dil, bias is not None, flops)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, dil, has_bias, flops = ctx.cfg
+        n, h, w_, cp = x.shape
+        cout, cin, r, s = weight.shape
+        dt = x.dtype
+        v = vec_of(dt)
+        dy = dy.contiguous()
+        ho, wo = dy.shape[1], dy.shape[2]
+        dev, st = dev_stream(dy)
+        dc = dtype_code(dt)
+        cout_pad = pad_to(cout, v)
+        dyp = dy
+        if cout_pad != cout:   # heads with K classes: pad the reduced / vectorised dimension
+            dyp = torch.zeros((n, ho, wo, cout_pad), dtype=dt, device=dy.device)
+            call("css_copy_channels", dy, cout, dyp, cout_pad, n * ho * wo, cout, dc, dc, dev, st)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = prepared_weight(weight, dt, cp, True)
+            dx = torch.empty_like(x)
+            call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
+                 dc, dev, st)
+        if ctx.needs_input_grad[1]:
+            dwp = torch.zeros((cout_pad, r, s, cp), dtype=torch.float32, device=dy.device)
+            call("css_conv2d_wgrad", x, dyp, dwp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
+                 dc, dev, st)
+            dw = dwp[:cout, :, :, :cin].permute(0, 3, 1, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
+            call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):
+    return _Conv2d.apply(x, weight, bias, stride, pad, dil)
+
+
+# --------------------------------------------------------------------------
+# batch norm (+ residual, + ReLU)
+# --------------------------------------------------------------------------
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync):
+        c = y.shape[-1]
+        m = y.numel() // c
+        dt = y.dtype
+        dev, st = dev_stream(y)
+        dc = dtype_code(dt)
+        assert y.is_contiguous() and (res is None or res.is_contiguous())
+        f32 = dict(dtype=torch.float32, device=y.device)
+        scale, shift = torch.empty(c, **f32), torch.empty(c, **f32)
+        mean = invstd = None
+        count = float(m)
+        if training:
+            stats = torch.zeros(2 * c, dtype=torch.float64, device=y.device)
+            call("css_bn_stats", y, m, c, c, stats, stats[c:], dc, dev, st)
+            if sync and _world() > 1:
+                dist.all_reduce(stats)
+                count = float(m) * _world()
+            mean, invstd = torch.empty(c, **f32), torch.empty(c, **f32)
+            call("css_bn_finalize", stats, stats[c:], count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                 mean, invstd, scale, shift, c, dev, st)
+        else:
+            call("css_bn_eval_coeff", gamma, beta, running_mean, running_var, float(eps), scale, shift, c, dev, st)
+        out = torch.empty_like(y)
+        call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), dc, dev, st)
+        if training:
+            ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
+        ctx.cfg = (relu, training, count, sync, res is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, da):
+        relu, training, count, sync, has_res = ctx.cfg
+        if not training:
+            raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
+        y, a, mean, invstd, gamma = ctx.saved_tensors
+        c = y.shape[-1]
+        m = y.numel() // c
+        dt = y.dtype
+        da = da.contiguous()
+        dev, st = dev_stream(da)
+        dc = dtype_code(dt)
+        sums = torch.zeros(2 * c, dtype=torch.float64, device=y.device)
+        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, m, c, int(relu), sums, sums[c:], dc, dev, st)
+        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+        # parameter gradients are LOCAL sums (DDP / the trainer all-reduce them with the rest)
+        call("css_bn_param_grad", sums, sums[c:], dgamma, dbeta, c, 0, dev, st)
+        if sync and _world() > 1:
+            dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat)
+        dy = torch.empty_like(y)
+        dres = torch.empty_like(y) if has_res else None
+        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, sums[c:], count, m, c, int(relu),
+             dc, dev, st)
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None
+
+
+def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True):
+    return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync)
+
+
+# --------------------------------------------------------------------------
+# pooling / resize / concat
+# --------------------------------------------------------------------------
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ks, stride, pad, ceil_mode):
+        n, h, w, c = x.shape
+
+        def osz(i):
+            num = i + 2 * pad - ks
+            o = (-(-num // stride) if ceil_mode else num // stride) + 1
+            if ceil_mode and (o - 1) * stride >= i + pad:
+                o -= 1
+            return o
+
+        ho, wo = osz(h), osz(w)
+        out = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+        arg = torch.empty((n, ho, wo, c), dtype=torch.uint8, device=x.device) if ctx.needs_input_grad[0] else None
+        dev, st = dev_stream(x)
+        call("css_maxpool_fwd", x, out, arg, n, h, w, c, ho, wo, ks, stride, pad, dtype_code(x.dtype), dev, st)
+        ctx.save_for_backward(arg)
+        ctx.cfg = (x.shape, ks, stride, pad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (arg,) = ctx.saved_tensors
+        (n, h, w, c), ks, stride, pad = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=dout.dtype, device=dout.device)
+        dev, st = dev_stream(dout)
+        call("css_maxpool_bwd", dout, arg, dx, n, h, w, c, dout.shape[1], dout.shape[2], ks, stride, pad,
+             dtype_code(dout.dtype), dev, st)
+        return dx, None, None, None, None
+
+
+def maxpool(x, ks=3, stride=2, pad=1, ceil_mode=False):
+    return _MaxPool.apply(x, ks, stride, pad, ceil_mode)
+
+
+class _Bilinear(torch.autograd.Function):
+    """F.interpolate(mode='bilinear', align_corners=True) on NHWC tensors; output dtype selectable."""
+
+    @staticmethod
+    def forward(ctx, x, hd, wd, out_dtype):
+        n, hs, ws, c = x.shape
+        out = torch.empty((n, hd, wd, c), dtype=out_dtype, device=x.device)
+        dev, st = dev_stream(x)
+        call("css_bilinear", x, c, out, c, n, hs, ws, c, hd, wd, dtype_code(x.dtype), dtype_code(out_dtype), 0, dev, st)
+        ctx.cfg = (x.shape, x.dtype)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (n, hs, ws, c), in_dtype = ctx.cfg
+        dout = dout.contiguous()
+        hd, wd = dout.shape[1], dout.shape[2]
+        dx = torch.empty((n, hs, ws, c), dtype=in_dtype, device=dout.device)
+        dev, st = dev_stream(dout)
+        call("css_bilinear", dout, c, dx, c, n, hs, ws, c, hd, wd, dtype_code(dout.dtype), dtype_code(in_dtype), 1, dev, st)
+        return dx, None, None, None
+
+
+def bilinear(x, hd, wd, out_dtype=None):
+    return _Bilinear.apply(x, hd, wd, out_dtype or x.dtype)
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        n, h, w, c = x.shape
+        out = torch.empty((n, 1, 1, c), dtype=x.dtype, device=x.device)
+        dev, st = dev_stream(x)
+        call("css_spatial_sum", x, c, out, n, h * w, c, 1.0 / (h * w), dtype_code(x.dtype), dev, st)
+        ctx.cfg = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n, h, w, c = ctx.cfg
+        dout = dout.contiguous()
+        dx = torch.empty((n, h, w, c), dtype=dout.dtype, device=dout.device)
+        dev, st = dev_stream(dout)
+        call("css_spatial_bcast", dout, dx, c, n, h * w, c, 1.0 / (h * w), dtype_code(dout.dtype), dev, st)
+        return dx
+
+
+def global_avg_pool(x):
+    return _GlobalAvgPool.apply(x)
+
+
+class _Broadcast(torch.autograd.Function):
+    """[N,1,1,C] -> [N,H,W,C] (bilinear resize of a 1x1 map, aspp.py:38)."""
+
+    @staticmethod
+    def forward(ctx, x, h, w):
+        n, _, _, c = x.shape
+        out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
+        dev, st = dev_stream(x)
+        call("css_spatial_bcast", x, out, c, n, h * w, c, 1.0, dtype_code(x.dtype), dev, st)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        n, h, w, c = dout.shape
+        dx = torch.empty((n, 1, 1, c), dtype=dout.dtype, device=dout.device)
+        dev, st = dev_stream(dout)
+        call("css_spatial_sum", dout, c, dx, n, h * w, c, 1.0, dtype_code(dout.dtype), dev, st)
+        return dx, None, None
+
+
+def broadcast_hw(x, h, w):
+    return _Broadcast.apply(x, h, w)
+
+
+class _CatChannels(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, *xs):
+        n, h, w, _ = xs[0].shape
+        cs = [x.shape[-1] for x in xs]
+        ct = sum(cs)
+        dt = xs[0].dtype
+        out = torch.empty((n, h, w, ct), dtype=dt, device=xs[0].device)
+        dev, st = dev_stream(out)
+        off = 0
+        esz = out.element_size()
+        for x, c in zip(xs, cs):
+            call("css_copy_channels", x, c, out.data_ptr() + off * esz, ct, n * h * w, c, dtype_code(dt), dtype_code(dt), dev, st)
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        n, h, w, ct = dout.shape
+        dev, st = dev_stream(dout)
+        dc = dtype_code(dout.dtype)
+        esz = dout.element_size()
+        outs, off = [], 0
+        for i, c in enumerate(ctx.cs):
+            if ctx.needs_input_grad[i]:
+                g = torch.empty((n, h, w, c), dtype=dout.dtype, device=dout.device)
+                call("css_copy_channels", dout.data_ptr() + off * esz, ct, g, c, n * h * w, c, dc, dc, dev, st)
+                outs.append(g)
+            else:
+                outs.append(None)
+            off += c
+        return tuple(outs)
+
+
+def cat_channels(*xs):
+    return _CatChannels.apply(*xs)
+
+
+def stage_input(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """[B,C,H,W] fp32 NCHW image -> [B,H,W,Cpad] ``dtype`` (zero-padded channels). No gradient."""
+    x = x.detach()
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        x = x.float().contiguous()
+    b, c, h, w = x.shape
+    cp = pad_to(c, vec_of(dtype))
+    out = torch.empty((b, h, w, cp), dtype=dtype, device=x.device)
+    dev, st = dev_stream(x)
+    call("css_nchw_to_nhwc", x, out, b, c, h * w, cp, dtype_code(dtype), dev, st)
+    return out

@@ -1,0 +1,137 @@
+/* css_hip.h -- C ABI of libcss_hip.so: the MI355X (gfx950) kernels behind the CSS hot path.
+ *
+ * Boundary rules: plain pointers and sizes, no torch types; every buffer is caller
+ * owned device memory; no hidden allocation and no host synchronisation inside any entry point; every
+ * entry point takes the device index and the hipStream_t to launch on (backward runs on autograd-engine
+ * threads, so nothing may depend on thread-local device/stream state); returns 0 or a negative CSS_ERR_*.
+ *
+ * Layout: activations are NHWC ("[N][H][W][ld]", channels innermost, ld >= C elements between pixels),
+ * conv weights [Cout][R][S][Cin].  dtype: 0 = fp32 (parity path, exact-fp32 MFMA), 1 = bf16 (fp32 accumulate).
+ *
+ * Each group cites the reference interface it replaces (paths relative to the reference root).
+ */
+#ifndef CSS_HIP_H
+#define CSS_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CSS_API __attribute__((visibility("default")))
+typedef void* css_stream_t; /* hipStream_t */
+
+#define CSS_DTYPE_F32 0
+#define CSS_DTYPE_BF16 1
+
+CSS_API int css_abi_version(void);
+CSS_API int css_device_cu_count(int device);
+
+/* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------------
+ * kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad, 3 = contrast loss gather, 4 = similarity */
+CSS_API int css_prof_enable(int on);
+CSS_API int css_prof_reset(void);
+CSS_API int css_prof_read(int kind, double* total_ms, double* launches, double* alg_work);
+
+/* ---- convolution: nn.Conv2d forward/backward as used by
+ *      generalframeworks/networks/resnet.py:24-40,119-139 (Bottleneck), deeplabv3/aspp.py:17-72 (ASPP),
+ *      deeplabv3/deeplabv3.py:115-133,151-169 (stem, decoder heads).  alg_flops is only recorded for profiling. */
+CSS_API int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
+                               int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device,
+                               css_stream_t stream);
+/* w_t: weights re-laid out as [Cin][R][S][Cout] (css_weight_layout dgrad=1); stride 1 or 2 */
+CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy,
+                             int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
+/* dw: fp32 [Cout][R][S][Cin], ACCUMULATED (atomic adds): zero it first unless accumulating on purpose */
+CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
+                             int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
+/* fp32 master [Cout][taps][Cin] -> compute dtype; dgrad=0: [Cout][taps][CinPad], dgrad=1: [Cin][taps][Cout] */
+CSS_API int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device,
+                              css_stream_t stream);
+
+/* ---- batch norm: nn.BatchNorm2d / nn.SyncBatchNorm (mix_label.py:76) in train and eval mode -------- */
+CSS_API int css_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
+                            int device, css_stream_t stream);
+CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
+                              float* shift, int C, int device, css_stream_t stream);
+CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
+                         int relu, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
+                              int M, int C, int relu, double* sum_dz, double* sum_dzx, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
+                             const float* mean, const float* invstd, const float* gamma, const double* sum_dz, const double* sum_dzx,
+                             double count, int M, int C, int relu, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_param_grad(const double* sum_dz, const double* sum_dzx, float* dgamma, float* dbeta, int C, int accumulate, int device,
+                              css_stream_t stream);
+
+/* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
+CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
+                            int dtype, int device, css_stream_t stream);
+CSS_API int css_maxpool_bwd(const void* dout, const uint8_t* argmax, void* dx, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride,
+                            int pad, int dtype, int device, css_stream_t stream);
+/* bilinear, align_corners=True.  backward=0: x [N,Hs,Ws,ldx] -> out [N,Hd,Wd,ldo]; backward=1: x = d(out) [N,Hd,Wd,ldx] -> out = d(x) [N,Hs,Ws,ldo] */
+CSS_API int css_bilinear(const void* x, int ldx, void* out, int ldo, int N, int Hs, int Ws, int C, int Hd, int Wd, int dtype_in, int dtype_out,
+                         int backward, int device, css_stream_t stream);
+CSS_API int css_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, int device, css_stream_t stream);
+CSS_API int css_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, int device, css_stream_t stream);
+CSS_API int css_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out, int device,
+                              css_stream_t stream);
+/* out[c] += sum_m x[m][c]  (bias gradient of the 1x1 heads, deeplabv3.py:125,132); out is fp32 and accumulated */
+CSS_API int css_colsum(const void* x, int ld, long M, int C, float* out, int dtype, int device, css_stream_t stream);
+CSS_API int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream);
+CSS_API int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int device, css_stream_t stream);
+
+/* ---- optimiser + EMA teacher: torch.optim.SGD(nesterov) mix_label.py:96-97,194; Model_mix.ema_update ddp_model.py:93-97 */
+CSS_API int css_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
+                        float grad_scale, int device, css_stream_t stream);
+CSS_API int css_ema(float* ema, const float* p, long n, float decay, int device, css_stream_t stream);
+
+/* ---- similarity / pseudo labels: ddp_model.py:104-118,147-154; mix_label.py:175-183 ------------------ */
+CSS_API int css_proto_normalize(const float* proto, void* out, int K, int C, int dtype, int device, css_stream_t stream);
+CSS_API int css_similarity(const void* rep, int ld, const void* proto_n, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
+                           float temp, float strong_thr, int dtype, int device, css_stream_t stream);
+CSS_API int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
+                             int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, int device,
+                             css_stream_t stream);
+CSS_API int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w,
+                          int* cls, int device, css_stream_t stream);
+
+/* ---- cross-entropy family: mix_label.py:81,169; loss/loss.py:19-46 (OHEM), :53-64 (Attention_Threshold_Loss) */
+CSS_API int css_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
+                       double* stats, float* gtprob_out, int device, css_stream_t stream);
+CSS_API int css_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream);
+CSS_API int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef,
+                       const float* gscale, int pos_only, float* dlogits, int device, css_stream_t stream);
+CSS_API size_t css_ohem_state_bytes(void);
+CSS_API size_t css_ohem_thr_offset(void);
+CSS_API int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,
+                               css_stream_t stream);
+
+/* ---- contrastive loss: loss/loss.py:75-149, 410-418 ---------------------------------------------------- */
+CSS_API size_t css_contrast_meta_bytes(void);
+CSS_API int css_contrast_nchunks(int P);
+CSS_API int css_contrast_classify(const float* label, const float* mask, const float* prob, long sb, long sk, long sp, long psb, long psk, long psp,
+                                  int P, int HW, int K, float strong_thr, int* cls, uint8_t* hard, void* meta, int device, css_stream_t stream);
+CSS_API int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, int device,
+                                    css_stream_t stream);
+CSS_API int css_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta, int device,
+                                 css_stream_t stream);
+CSS_API int css_contrast_proto_update(float* proto, const double* sums, int K, int C, float alpha, const void* meta, int device,
+                                      css_stream_t stream);
+CSS_API int css_contrast_sample(const float* proto, int C, const void* meta, float temp, float* cdf, const int* listV, const int* listH, int Q, int N,
+                                unsigned long long seed, unsigned long long offset, int* anchor_pix, int* neg_pix, int device,
+                                css_stream_t stream);
+CSS_API int css_contrast_resolve(const void* meta, const int* listV, const int* listH, int Q, int N, const int* anchor_idx, const int* neg_idx,
+                                 int* anchor_pix, int* neg_pix, int device, css_stream_t stream);
+CSS_API int css_contrast_loss(const void* rep, int ld, const float* proto, int K, int C, const void* meta, const int* anchor_pix, const int* neg_pix,
+                              int Q, int N, float temp, float* loss_vq, float* gradbuf, float* loss, int dtype, int device, css_stream_t stream);
+CSS_API int css_contrast_scatter_grad(const float* gradbuf, const int* anchor_pix, const void* meta, int K, int Q, const float* gscale, void* drep,
+                                      int ld, int dtype, int device, css_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CSS_HIP_H */

@@ -1,0 +1,31 @@
+import torch
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def to_nhwc(x_nchw, dtype, pad_to=None):
+    """CPU NCHW fp32 -> GPU NHWC ``dtype`` (optionally zero-padded channels)."""
+    x = x_nchw.permute(0, 2, 3, 1).contiguous()
+    if pad_to is not None and pad_to != x.shape[-1]:
+        xp = torch.zeros(*x.shape[:3], pad_to)
+        xp[..., : x.shape[-1]] = x
+        x = xp
+    return x.to(dev()).to(dtype).contiguous()
+
+
+def to_nchw_cpu(x_nhwc):
+    return x_nhwc.detach().float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+def bf16_round(x):
+    return x.to(torch.bfloat16).float()
+
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}

@@ -1,0 +1,201 @@
+"""Every HIP op through the C ABI against plain torch-CPU fp32 math on the same seeded inputs."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import TOL, bf16_round, dev, rel_err, to_nchw_cpu, to_nhwc  # noqa: E402
+
+DTYPES = [torch.float32, torch.bfloat16]
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, k, stride, pad, dil, bias
+    (2, 17, 17, 64, 64, 1, 1, 0, 1, False),
+    (2, 17, 17, 256, 128, 1, 1, 0, 1, False),
+    (1, 33, 33, 64, 64, 3, 1, 1, 1, False),
+    (2, 17, 17, 64, 128, 3, 2, 1, 1, False),
+    (2, 9, 9, 256, 256, 3, 1, 2, 2, False),
+    (2, 9, 9, 128, 64, 3, 1, 4, 4, False),
+    (2, 9, 9, 256, 256, 3, 1, 12, 12, False),
+    (2, 17, 17, 256, 512, 1, 2, 0, 1, False),
+    (2, 65, 65, 3, 64, 7, 2, 3, 1, False),
+    (2, 33, 33, 3, 64, 3, 2, 1, 1, False),
+    (2, 17, 17, 304, 256, 3, 1, 1, 1, False),
+    (2, 17, 17, 256, 21, 1, 1, 0, 1, True),
+    (2, 17, 17, 256, 48, 1, 1, 0, 1, False),
+    (3, 13, 11, 64, 320, 3, 1, 1, 1, True),
+    (1, 1, 1, 2048, 256, 1, 1, 0, 1, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_bwd(case, dtype):
+    from css_amd import ops
+    n, h, w, cin, cout, k, stride, pad, dil, bias = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    b = torch.randn(cout, generator=g) if bias else None
+    if dtype == torch.bfloat16:
+        x, wt = bf16_round(x), bf16_round(wt)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True) if bias else None
+    yr = F.conv2d(xr, wr, br, stride, pad, dil)
+    gy = torch.randn(yr.shape, generator=g)
+    if dtype == torch.bfloat16:
+        gy = bf16_round(gy)
+    yr.backward(gy)
+
+    v = ops.vec_of(dtype)
+    xg = to_nhwc(x, dtype, ops.pad_to(cin, v)).requires_grad_(cin % v == 0)
+    wg = wt.to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    bg = b.to(dev()).requires_grad_(True) if bias else None
+    y = ops.conv2d(xg, wg, bg, stride, pad, dil)
+    tol = TOL[dtype]
+    assert rel_err(to_nchw_cpu(y), yr.detach()) < tol
+    y.backward(to_nhwc(gy, dtype))
+    if xg.requires_grad:
+        assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < tol
+    assert rel_err(wg.grad.cpu(), wr.grad) < tol
+    if bias:
+        assert rel_err(bg.grad.cpu(), br.grad) < tol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,res,relu", [((2, 17, 17, 64), False, True), ((2, 9, 9, 256), True, True),
+                                            ((2, 1, 1, 256), False, True), ((3, 13, 7, 48), False, False),
+                                            ((2, 33, 33, 2048), True, True), ((4, 5, 5, 304), False, True)])
+def test_bn_act_train(shape, res, relu, dtype):
+    from css_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(c + h)
+    x = torch.randn(n, c, h, w, generator=g) * 2 + 0.5
+    r = torch.randn(n, c, h, w, generator=g) if res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+        r = bf16_round(r) if res else None
+    xr = x.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    o = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    if res:
+        o = o + rr
+    if relu:
+        o = F.relu(o)
+    go = torch.randn(o.shape, generator=g)
+    if dtype == torch.bfloat16:
+        go = bf16_round(go)
+    o.backward(go)
+
+    xg = to_nhwc(x, dtype).requires_grad_(True)
+    rg = to_nhwc(r, dtype).requires_grad_(True) if res else None
+    gg, bg = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+    rmg, rvg = rm.to(dev()), rv.to(dev())
+    og = ops.bn_act(xg, gg, bg, rmg, rvg, rg, relu, True, 0.1, 1e-5, False)
+    tol = TOL[dtype]
+    assert rel_err(to_nchw_cpu(og), o.detach()) < tol
+    assert rel_err(rmg.cpu(), rm_r) < 1e-5 and rel_err(rvg.cpu(), rv_r) < 1e-5
+    og.backward(to_nhwc(go, dtype))
+    btol = tol * 5
+    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < btol
+    assert rel_err(gg.grad.cpu(), gr.grad) < btol and rel_err(bg.grad.cpu(), br.grad) < btol
+    if res:
+        assert rel_err(to_nchw_cpu(rg.grad), rr.grad) < btol
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_eval(dtype):
+    from css_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 64, 9, 9, generator=g)
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.1
+    rm, rv = torch.randn(64, generator=g) * 0.1, torch.rand(64, generator=g) + 0.5
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    o = F.relu(F.batch_norm(x, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    og = ops.bn_act(to_nhwc(x, dtype), gamma.to(dev()), beta.to(dev()), rm.to(dev()), rv.to(dev()), None, True, False)
+    assert rel_err(to_nchw_cpu(og), o) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,ceil", [((2, 33, 33, 64), False), ((2, 33, 33, 128), True), ((1, 18, 20, 64), True),
+                                        ((2, 17, 17, 64), False)])
+def test_maxpool(shape, ceil, dtype):
+    from css_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(h)
+    x = F.relu(torch.randn(n, c, h, w, generator=g))     # ReLU output: many exact ties at 0
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    xr = x.clone().requires_grad_(True)
+    o = F.max_pool2d(xr, 3, 2, 1, ceil_mode=ceil)
+    go = torch.randn(o.shape, generator=g)
+    if dtype == torch.bfloat16:
+        go = bf16_round(go)
+    o.backward(go)
+    xg = to_nhwc(x, dtype).requires_grad_(True)
+    og = ops.maxpool(xg, 3, 2, 1, ceil)
+    assert og.shape[1:3] == o.shape[2:]
+    assert rel_err(to_nchw_cpu(og), o.detach()) == 0
+    og.backward(to_nhwc(go, dtype))
+    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hs,hd,c", [(17, 65, 21), (9, 17, 256), (33, 129, 19), (5, 5, 8), (1, 4, 8), (7, 10, 16)])
+def test_bilinear(hs, hd, c, dtype):
+    from css_amd import ops
+    g = torch.Generator().manual_seed(hs * hd)
+    x = torch.randn(2, c, hs, hs + 2, generator=g)
+    if dtype == torch.bfloat16:
+        x = bf16_round(x)
+    xr = x.clone().requires_grad_(True)
+    o = F.interpolate(xr, size=(hd, hd + 3), mode="bilinear", align_corners=True)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    xg = to_nhwc(x, dtype).requires_grad_(True)
+    og = ops.bilinear(xg, hd, hd + 3, torch.float32)
+    assert rel_err(to_nchw_cpu(og), o.detach()) < 2e-5 if dtype == torch.float32 else 1e-2
+    og.backward(to_nhwc(go, torch.float32))
+    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_pool_broadcast_cat(dtype):
+    from css_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 64, 9, 11, generator=g)
+    y = torch.randn(2, 48, 9, 11, generator=g)
+    if dtype == torch.bfloat16:
+        x, y = bf16_round(x), bf16_round(y)
+    xr, yr = x.clone().requires_grad_(True), y.clone().requires_grad_(True)
+    p = F.adaptive_avg_pool2d(xr, 1)
+    bb = F.interpolate(p, size=(9, 11), mode="bilinear", align_corners=False)
+    o = torch.cat([yr, bb, xr], 1)
+    go = torch.randn(o.shape, generator=g)
+    if dtype == torch.bfloat16:
+        go = bf16_round(go)
+    o.backward(go)
+    xg, yg = to_nhwc(x, dtype).requires_grad_(True), to_nhwc(y, dtype).requires_grad_(True)
+    pg = ops.global_avg_pool(xg)
+    og = ops.cat_channels(yg, ops.broadcast_hw(pg, 9, 11), xg)
+    tol = TOL[dtype]
+    assert rel_err(to_nchw_cpu(og), o.detach()) < tol
+    og.backward(to_nhwc(go, dtype))
+    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < tol and rel_err(to_nchw_cpu(yg.grad), yr.grad) < tol
+
+
+def test_stage_input():
+    from css_amd import ops
+    x = torch.randn(2, 3, 9, 7)
+    for dt, cp in ((torch.float32, 4), (torch.bfloat16, 8)):
+        o = ops.stage_input(x.to(dev()), dt)
+        assert o.shape == (2, 9, 7, cp)
+        ref = x.permute(0, 2, 3, 1)
+        assert rel_err(o[..., :3].float().cpu(), ref if dt == torch.float32 else bf16_round(ref)) == 0
+        assert o[..., 3:].abs().max() == 0
