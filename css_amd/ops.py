@@ -26,7 +26,6 @@ def pad_to(c: int, v: int) -> int:
 # --------------------------------------------------------------------------
 # weight preparation cache (fp32 master [Cout,Cin,R,S] channels_last -> compute layouts)
 # --------------------------------------------------------------------------
-_wcache = {}
 _epoch = 0
 
 
@@ -45,9 +44,12 @@ def _phys(weight: torch.Tensor) -> torch.Tensor:
 
 
 def prepared_weight(weight: torch.Tensor, dtype: torch.dtype, cin_pad: int, dgrad: bool) -> torch.Tensor:
-    key = (id(weight), dtype, cin_pad, dgrad)
+    # the cache lives ON the parameter object (a global dict keyed by id() can hand a new model the
+    # prepared weights of a dead one whose id and recycled device address coincide)
+    cache = weight.__dict__.setdefault("_css_wcache", {})
+    key = (dtype, cin_pad, dgrad)
     stamp = (weight.data_ptr(), weight._version, _epoch)
-    hit = _wcache.get(key)
+    hit = cache.get(key)
     if hit is not None and hit[0] == stamp:
         return hit[1]
     cout, cin, r, s = weight.shape
@@ -68,7 +70,7 @@ def prepared_weight(weight: torch.Tensor, dtype: torch.dtype, cin_pad: int, dgra
             w = wp
         out = torch.empty((cin, r, s, cout_pad), dtype=dtype, device=w.device)
         call("css_weight_layout", w, out, cout_pad, r * s, cin, cin, 1, dtype_code(dtype), dev, st)
-    _wcache[key] = (stamp, out)
+    cache[key] = (stamp, out)
     return out
 
 

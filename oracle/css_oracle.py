@@ -171,12 +171,14 @@ def all_layers(backbone: str, num_classes=21, output_dim=256) -> List[dict]:
     return out
 
 
-def init_state(backbone: str, num_classes=21, output_dim=256, seed=0) -> "OrderedDict[str, torch.Tensor]":
+def init_state(backbone: str, num_classes=21, output_dim=256, seed=0, residual_gain=1.0) -> "OrderedDict[str, torch.Tensor]":
     """Deterministic, non-degenerate state_dict with the reference's key names
     (SURVEY section 5 checkpoint row).  Conv: Kaiming-normal fan_out; BN gamma~U(.5,1.5),
     beta~N(0,.1), running_mean~N(0,.1), running_var~U(.5,1.5) (the reference's
     own init zeroes every bn3.weight, resnet.py:218-223, which would hide the
-    residual branches from a parity check)."""
+    residual branches from a parity check).  ``residual_gain`` scales every ``bn3.weight``: with 1.0 the
+    random network amplifies a 1-ulp input perturbation ~1000x by the ASPP output (fp32 itself is then only
+    good to ~1e-3 against fp64); 0.25 gives the well-conditioned regime of a trained network."""
     g = torch.Generator().manual_seed(seed)
     sd = OrderedDict()
     for L in all_layers(backbone, num_classes, output_dim):
@@ -190,6 +192,8 @@ def init_state(backbone: str, num_classes=21, output_dim=256, seed=0) -> "Ordere
         else:
             c = L["c"]
             sd[n + ".weight"] = torch.rand(c, generator=g) + 0.5
+            if n.endswith(".bn3"):
+                sd[n + ".weight"] *= residual_gain
             sd[n + ".bias"] = torch.randn(c, generator=g) * 0.1
             sd[n + ".running_mean"] = torch.randn(c, generator=g) * 0.1
             sd[n + ".running_var"] = torch.rand(c, generator=g) + 0.5

@@ -79,10 +79,10 @@ class TVResNet101(nn.Module):
         return nn.Sequential(*layers)
 
 
-def build_ref_net(backbone, K, seed):
+def build_ref_net(backbone, K, seed, residual_gain=1.0):
     bb = TVResNet101() if backbone == "tv" else ref_resnet.resnet101(pretrained=False)
     net = DeepLabv3Plus_with_rep(bb, dilate_scale=8, num_classes=K, output_dim=256)
-    sd = O.init_state(backbone, K, 256, seed)
+    sd = O.init_state(backbone, K, 256, seed, residual_gain)
     net.load_state_dict(sd, strict=True)
     return net, sd
 
@@ -113,10 +113,10 @@ def probe_slice(t):
     return t.detach().flatten()[:: max(1, t.numel() // 2048)][:2048].clone()
 
 
-def gen_network(backbone, size, K, seed, tag):
+def gen_network(backbone, size, K, seed, tag, residual_gain=1.0, batch=2):
     torch.manual_seed(seed)
-    net, sd = build_ref_net(backbone, K, seed)
-    x = torch.randn(2, 3, size, size)
+    net, sd = build_ref_net(backbone, K, seed, residual_gain)
+    x = torch.randn(batch, 3, size, size)
     net.train()
     pred, rep = net(x)
     wp = torch.randn_like(pred)
@@ -124,7 +124,7 @@ def gen_network(backbone, size, K, seed, tag):
     loss = (pred * wp).sum() + (rep * wr).sum()
     loss.backward()
     named = dict(net.named_parameters())
-    out = dict(x=x, pred=pred, rep=rep, wp=wp, wr=wr, seed=seed, K=K)
+    out = dict(x=x, pred=pred, rep=rep, wp=wp, wr=wr, seed=seed, K=K, residual_gain=residual_gain)
     for p in PROBES[backbone]:
         out["grad::" + p] = probe_slice(named[p].grad)
     bufs = dict(net.named_buffers())
@@ -443,6 +443,8 @@ if __name__ == "__main__":
         gen_network("tv", 65, 21, 101, "net_tv_65")
         gen_network("stem", 65, 19, 102, "net_stem_65")
         gen_network("tv", 97, 21, 103, "net_tv_97")
+        gen_network("tv", 65, 21, 104, "net_tv_65_damped", residual_gain=0.25, batch=3)
+        gen_network("stem", 65, 19, 105, "net_stem_65_damped", residual_gain=0.25, batch=3)
     if "pseudo" in which:
         gen_pseudo()
     if "contrast" in which:

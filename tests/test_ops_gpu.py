@@ -101,8 +101,11 @@ def test_bn_act_train(shape, res, relu, dtype):
     assert rel_err(to_nchw_cpu(og), o.detach()) < tol
     assert rel_err(rmg.cpu(), rm_r) < 1e-5 and rel_err(rvg.cpu(), rv_r) < 1e-5
     og.backward(to_nhwc(go, dtype))
-    btol = tol * 5
-    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < btol
+    # two samples per channel: invstd up to 1/sqrt(eps) amplifies the rounding of the bracketed difference
+    btol = max(1e-3, tol * 5) if n * h * w == 2 else tol * 5
+    # N*H*W == 2 makes d/dx cancel analytically (only eps-sized residue left): compare on the incoming-gradient scale
+    floor = 1e-3 * go.abs().max()
+    assert ((to_nchw_cpu(xg.grad) - xr.grad).abs().max() / max(xr.grad.abs().max(), floor)).item() < btol
     assert rel_err(gg.grad.cpu(), gr.grad) < btol and rel_err(bg.grad.cpu(), br.grad) < btol
     if res:
         assert rel_err(to_nchw_cpu(rg.grad), rr.grad) < btol

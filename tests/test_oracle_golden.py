@@ -25,11 +25,12 @@ def probe_slice(t):
     return t.detach().flatten()[:: max(1, t.numel() // 2048)][:2048]
 
 
-@pytest.mark.parametrize("tag,backbone", [("net_tv_65", "tv"), ("net_stem_65", "stem"), ("net_tv_97", "tv")])
+@pytest.mark.parametrize("tag,backbone", [("net_tv_65", "tv"), ("net_stem_65", "stem"), ("net_tv_97", "tv"),
+                                          ("net_tv_65_damped", "tv"), ("net_stem_65_damped", "stem")])
 def test_network_forward_backward(golden, tag, backbone):
     g = golden(tag)
     K, seed = int(g["K"]), int(g["seed"])
-    sd = O.init_state(backbone, K, 256, seed)
+    sd = O.init_state(backbone, K, 256, seed, float(g["residual_gain"]))
     names = O.param_names(backbone, K, 256)
     for n in names:
         sd[n].requires_grad_(True)
