@@ -248,10 +248,17 @@ __global__ __launch_bounds__(256) void contrast_resolve_kernel(const ContrastMet
   const int cid = meta->present[v];
   if (meta->cntH[cid] == 0) return;
   if (n == N) {
-    anchor_pix[v * Q + q] = listH[meta->baseH[cid] + anchor_idx[v * Q + q]];
+    // indices are reduced modulo the list length so that out-of-range test input cannot read outside the lists
+    anchor_pix[v * Q + q] = listH[meta->baseH[cid] + (unsigned)anchor_idx[v * Q + q] % (unsigned)meta->cntH[cid]];
     return;
   }
-  int idx = neg_idx[((size_t)v * Q + q) * N + n];
+  int total = 0;
+  for (int j = 0; j < V - 1; ++j) {
+    int o = v + 1 + j;
+    if (o >= V) o -= V;
+    total += meta->cntV[meta->present[o]];
+  }
+  int idx = (int)((unsigned)neg_idx[((size_t)v * Q + q) * N + n] % (unsigned)total);
   int pix = -1;
   for (int j = 0; j < V - 1; ++j) {
     int o = v + 1 + j;

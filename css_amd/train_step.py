@@ -1,0 +1,84 @@
+"""One training iteration of the CSS "mix_label" method on MI355X.
+
+``MixTrainer.step`` reproduces the body of ``train()`` in the reference's mix_label.py:162-196:
+
+    model(l, u, prototypes)                                   ddp_model.py:99-156
+    sup_loss   = CE | OHEM (pred_l_large, l_label)            mix_label.py:168-171
+    unsup_loss = Attention_Threshold_Loss(...)                mix_label.py:172
+    mask_all / label_all                                      mix_label.py:175-183  (as a class-id map)
+    contrast   = Contrast_Loss(rep_all, ...)                  mix_label.py:185
+    total = sup + unsup + contrast * ramp                     mix_label.py:187-190
+    zero_grad; backward; SGD(nesterov) step; ema_update; lr   mix_label.py:192-196
+
+Data parallelism (mix_label.py:76-77): one process per GPU; SyncBN statistics and the contrastive prototype sums are
+all-reduced inside the ops; the gradient of every student parameter lives in ONE flat fp32 buffer that is all-reduced
+(RCCL, averaged like DDP) in a single collective, followed by ONE fused SGD+EMA kernel over 59.5 M elements.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+from . import functional as Fn
+from . import ops
+from ._lib import call, dev_stream
+from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d
+from .scheduler.my_lr_scheduler import poly_lr
+
+
+class MixTrainer:
+    def __init__(self, model, num_classes=21, lr=6.4e-3, weight_decay=5e-4, momentum=0.9, total_iter=80000, min_lr=1e-4,
+                 num_queries=256, num_negatives=512, temp_loss=0.5, alpha_proto=0.99, strong_threshold=0.8, weak_threshold=0.7,
+                 un_threshold=0.97, sup="ce", ohem_min_kept=None, output_dim=256):
+        self.model = model
+        self.K = num_classes
+        self.base_lr, self.wd, self.momentum, self.total_iter, self.min_lr = lr, weight_decay, momentum, total_iter, min_lr
+        self.weak_threshold = weak_threshold
+        self.crit_ce = CrossEntropyLoss(-1)
+        self.crit_ohem = ProbOhemCrossEntropy2d(-1, thresh=0.7, min_kept=ohem_min_kept or 0) if sup == "ohem" else None
+        self.crit_unsup = Attention_Threshold_Loss(un_threshold)
+        self.crit_contrast = Contrast_Loss(num_queries, num_negatives, temp=temp_loss, strong_threshold=strong_threshold, alpha=alpha_proto)
+        dev = next(model.parameters()).device
+        self.prototypes = torch.zeros(num_classes, output_dim, device=dev)     # mix_label.py:93
+        self.it = 0
+        self.flat_p, self.flat_ema = model._ensure_flat()
+        self.flat_g = torch.zeros_like(self.flat_p)
+        self.flat_m = torch.zeros_like(self.flat_p)
+        for p, o in zip(model.model.parameters(), model.model._css_flat_offsets):
+            n = p.numel()
+            if p.dim() == 4:
+                co, ci, r, s = p.shape
+                p.grad = self.flat_g[o:o + n].view(co, r, s, ci).permute(0, 3, 1, 2)
+            else:
+                p.grad = self.flat_g[o:o + n].view(p.shape)
+
+    @property
+    def lr(self):
+        return poly_lr(self.base_lr, self.it, self.total_iter, 0.9, self.min_lr)
+
+    def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
+        m = self.model
+        self.flat_g.zero_()                                                  # optimizer.zero_grad()
+        pred_l_large, pred_u_large, u_lab, u_lc, u_lr, rep_all, _ = m.forward(l_img, u_img, self.prototypes, _want_prob=False)
+        sup = (self.crit_ohem or self.crit_ce)(pred_l_large, l_lab)
+        unsup = self.crit_unsup(pred_u_large, u_lab, u_lc)
+        b2, c, h, w = rep_all.shape
+        rep_rows = rep_all.permute(0, 2, 3, 1).reshape(b2 * h * w, c)         # zero-copy: rep_all is NHWC memory
+        with torch.no_grad():
+            cls = Fn.class_map(l_lab, u_lab, u_lc, self.weak_threshold, (h, w))
+            _, _, hard = Fn.similarity(rep_rows.view(b2, h, w, c), self.prototypes, m.temp, cls=cls,
+                                       strong_threshold=self.crit_contrast.strong_threshold)
+        con = self.crit_contrast.forward_fused(rep_rows, cls, hard, self.prototypes, self.K, _injected)
+        total = sup + unsup + con * ramp
+        total.backward()
+        world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+        if world > 1:
+            dist.all_reduce(self.flat_g)                                     # DDP gradient all-reduce (mean), one bucket
+        decay = min(1 - 1 / (m.step + 1), m.alpha)
+        dev, st = dev_stream(self.flat_p)
+        call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
+             float(self.wd), int(self.it == 0), float(decay), 1.0 / world, dev, st)
+        ops.invalidate_weight_cache()
+        m.step += 1
+        self.it += 1
+        return dict(sup=sup.detach(), unsup=unsup.detach(), contrast=con.detach(), total=total.detach(), pseudo=u_lab)

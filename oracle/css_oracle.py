@@ -571,9 +571,9 @@ def class_negative_probs(proto_rep, v, temp):
 class MixState:
     """Student + EMA teacher + optimiser state for the oracle's train step."""
 
-    def __init__(self, backbone="tv", num_classes=21, output_dim=256, seed=0):
+    def __init__(self, backbone="tv", num_classes=21, output_dim=256, seed=0, residual_gain=1.0):
         self.backbone, self.num_classes, self.output_dim = backbone, num_classes, output_dim
-        self.student = init_state(backbone, num_classes, output_dim, seed)
+        self.student = init_state(backbone, num_classes, output_dim, seed, residual_gain)
         self.teacher = OrderedDict((k, v.clone()) for k, v in self.student.items())   # copy.deepcopy, ddp_model.py:85
         self.pnames = param_names(backbone, num_classes, output_dim)
         self.mom = [None] * len(self.pnames)

@@ -366,7 +366,7 @@ def gen_schedules():
          sgd_traj=torch.stack(traj))
 
 
-def gen_train_trace(seed=41):
+def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
     """Two iterations of the mix_label.train body (mix_label.py:162-196) driven through the
     reference's Model_mix / Contrast_Loss / Attention_Threshold_Loss with identity augmentation
     (batch_transform_2 patched to label 255 -> -1, mix_mode 'none')."""
@@ -378,7 +378,7 @@ def gen_train_trace(seed=41):
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         model = ref_ddp.Model_mix(bb, num_classes=K, output_dim=256, config={"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}}, temp=0.5)
-    sd = O.init_state("tv", K, 256, seed)
+    sd = O.init_state("tv", K, 256, seed, gain)
     model.model.load_state_dict(sd, strict=True)
     model.ema_model.load_state_dict(sd, strict=True)
 
@@ -396,7 +396,7 @@ def gen_train_trace(seed=41):
     sch = PolyLR(opt, 100, min_lr=1e-4)
     protos = torch.zeros(K, 256)
     g = torch.Generator().manual_seed(seed)
-    out = dict(seed=seed)
+    out = dict(seed=seed, residual_gain=gain)
     probes = ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]
     for it in range(2):
         l_img = torch.randn(B, 3, S, S, generator=g)
@@ -434,7 +434,7 @@ def gen_train_trace(seed=41):
             out[f"{it}::student::{p}"] = probe_slice(sdm[p])
             out[f"{it}::teacher::{p}"] = probe_slice(sde[p])
         out[f"{it}::teacher_rm::resnet_bn1"] = sde["resnet_bn1.running_mean"].clone()
-    save("train_trace", **out)
+    save(tag, **out)
 
 
 if __name__ == "__main__":
@@ -457,3 +457,4 @@ if __name__ == "__main__":
         gen_schedules()
     if "trace" in which:
         gen_train_trace()
+        gen_train_trace(43, 0.25, "train_trace_damped")
