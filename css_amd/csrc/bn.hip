@@ -11,8 +11,11 @@
 #include "common.h"
 
 // generic two-value per-channel reduction over rows ------------------------------------
+// Stage 1: every block reduces its row range and STORES one partial row  partial[blockIdx.x][2][C]  (fp64, plain
+// stores: 1000 blocks doing fp64 atomics onto the same 2C addresses ran at ~390 GB/s, the contended-atomic regime).
+// Stage 2 (bn_reduce*_kernel below) sums the partial rows in fp64.
 template <typename T, typename F>
-__device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_block, double* out0, double* out1) {
+__device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256;
@@ -27,7 +30,12 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
   const int row0 = blockIdx.x * rows_per_block;
   const int row1 = min(M, row0 + rows_per_block);
   if (active) {
-    for (int r = row0 + rg; r < row1; r += RPB) f(r, cv * VEC, s0, s1);
+    int r = row0 + rg;
+    for (; r + RPB < row1; r += 2 * RPB) {   // two independent rows in flight
+      f(r, cv * VEC, s0, s1);
+      f(r + RPB, cv * VEC, s0, s1);
+    }
+    if (r < row1) f(r, cv * VEC, s0, s1);
   }
   __shared__ float red[2][256 * VEC];
 #pragma unroll
@@ -37,6 +45,7 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
   }
   __syncthreads();
   if (rg == 0 && cv < CV) {
+    double* p0 = partial + (size_t)blockIdx.x * 2 * C + cv * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       double a0 = 0, a1 = 0;
@@ -44,15 +53,70 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
         a0 += red[0][(g * TPC + cvi) * VEC + e];
         a1 += red[1][(g * TPC + cvi) * VEC + e];
       }
-      atomicAdd(out0 + cv * VEC + e, a0);
-      atomicAdd(out1 + cv * VEC + e, a1);
+      p0[e] = a0;
+      p0[C + e] = a1;
     }
+  }
+}
+
+// stage 2: sums[j] = sum_rb partial[rb][j]  for j in [0, 2C)  (fp64), optional fused train-mode finalize
+__device__ __forceinline__ void reduce_partials_pair(const double* __restrict__ partial, int nrb, int C, int c, int part, double& a0, double& a1) {
+  a0 = 0; a1 = 0;
+  if (c < C)
+    for (int rb = part; rb < nrb; rb += 4) {
+      a0 += partial[(size_t)rb * 2 * C + c];
+      a1 += partial[(size_t)rb * 2 * C + C + c];
+    }
+  __shared__ double red[2][4][64];
+  red[0][part][threadIdx.x & 63] = a0;
+  red[1][part][threadIdx.x & 63] = a1;
+  __syncthreads();
+  const int l = threadIdx.x & 63;
+  a0 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
+  a1 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+}
+// grid = ceil(C/64), block 256
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, double* __restrict__ sums,
+                                                        float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double a0, a1;
+  reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
+  if (part == 0 && c < C) {
+    if (sums) { sums[c] = a0; sums[C + c] = a1; }
+    if (g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat)
+      if (accumulate) { g0[c] += (float)a0; g1[c] += (float)a1; }
+      else { g0[c] = (float)a0; g1[c] = (float)a1; }
+    }
+  }
+}
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nrb, double count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* running_mean, float* running_var, float momentum, float eps,
+                                                                 float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  double a0, a1;
+  reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
+  if (part != 0 || c >= C) return;
+  double mean = a0 / count;
+  double var = a1 / count - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean, fvar = (float)var;
+  const float invstd = 1.0f / sqrtf(fvar + eps);
+  mean_out[c] = fmean;
+  invstd_out[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = beta[c] - fmean * sc;
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int M, int C, int ld,
-                                                       int rows_per_block, double* sum, double* sumsq) {
+                                                       int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> v;
@@ -64,7 +128,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
       s1[e] += x * x;
     }
   };
-  channel_reduce2<T>(f, M, C, rows_per_block, sum, sumsq);
+  channel_reduce2<T>(f, M, C, rows_per_block, partial);
 }
 
 __global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count,
@@ -129,8 +193,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a,
                                                             int lda, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int M, int C, int relu, int rows_per_block, double* sum_dz,
-                                                            double* sum_dzx) {
+                                                            int M, int C, int relu, int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> g, av, yv;
@@ -146,7 +209,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s1[e] += dz * xh;
     }
   };
-  channel_reduce2<T>(f, M, C, rows_per_block, sum_dz, sum_dzx);
+  channel_reduce2<T>(f, M, C, rows_per_block, partial);
 }
 
 template <typename T>
@@ -181,43 +244,52 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
-__global__ void bn_param_grad_kernel(const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx, float* dgamma,
-                                     float* dbeta, int C, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  if (accumulate) {
-    dgamma[c] += (float)sum_dzx[c];
-    dbeta[c] += (float)sum_dz[c];
-  } else {
-    dgamma[c] = (float)sum_dzx[c];
-    dbeta[c] = (float)sum_dz[c];
-  }
-}
-
 // ---- launchers -----------------------------------------------------------
+// rows per block such that ~768 blocks cover the tensor (>= 4 rows per thread)
 static inline int pick_rows_per_block(int M, int C, int vec) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
-  int rpb = RPB * 64;                       // <= 64 rows per thread in fp32 before the fp64 atomics
   const int ybl = (CV + TPC - 1) / TPC;
-  while (rpb > RPB * 4 && (long)cdiv(M, rpb) * ybl < 1024) rpb /= 2;
+  int want = 768 / ybl;
+  if (want < 1) want = 1;
+  int rpb = cdiv(M, want);
+  rpb = cdiv(rpb, RPB) * RPB;
+  if (rpb < 4 * RPB) rpb = 4 * RPB;
   return rpb;
+}
+int css_bn_nrb_(int M, int C, int dtype) {
+  const int vec = dtype == CSS_BF16 ? 8 : 4;
+  if (M <= 0) return 1;
+  return cdiv(M, pick_rows_per_block(M, C, vec));
 }
 
 template <typename T>
-static int bn_stats_T(const void* y, int M, int C, int ld, double* sum, double* sumsq, hipStream_t st) {
+static int bn_stats_T(const void* y, int M, int C, int ld, double* partial, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ld % VEC) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
   const int rpb = pick_rows_per_block(M, C, VEC);
   dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
-  hipLaunchKernelGGL(bn_stats_kernel<T>, g, dim3(256), 0, st, (const T*)y, M, C, ld, rpb, sum, sumsq);
+  hipLaunchKernelGGL(bn_stats_kernel<T>, g, dim3(256), 0, st, (const T*)y, M, C, ld, rpb, partial);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, hipStream_t st) {
-  if (M <= 0) return CSS_OK;
-  return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, M, C, ld, sum, sumsq, st)
-         : dtype == CSS_F32 ? bn_stats_T<float>(y, M, C, ld, sum, sumsq, st) : CSS_ERR_DTYPE;
+int css_launch_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_ERR_ARG;
+  return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, M, C, ld, partial, st)
+         : dtype == CSS_F32 ? bn_stats_T<float>(y, M, C, ld, partial, st) : CSS_ERR_DTYPE;
+}
+int css_launch_bn_reduce(const double* partial, int nrb, int C, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, partial, nrb, C, sums, g1, g0, accumulate);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
+                                  hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, partial, nrb, count, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, invstd, scale, shift, C);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
 }
 
 int css_launch_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta,
@@ -259,22 +331,22 @@ int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* 
 
 template <typename T>
 static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                           const float* invstd, int M, int C, int relu, double* s0, double* s1, hipStream_t st) {
+                           const float* invstd, int M, int C, int relu, double* partial, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldda % VEC || ldy % VEC || (relu && lda % VEC)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
   const int rpb = pick_rows_per_block(M, C, VEC);
   dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean,
-                     invstd, M, C, relu, rpb, s0, s1);
+                     invstd, M, C, relu, rpb, partial);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                             const float* invstd, int M, int C, int relu, double* s0, double* s1, int dtype, hipStream_t st) {
-  if (M <= 0) return CSS_OK;
-  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, s0, s1, st)
-         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, s0, s1, st)
+                             const float* invstd, int M, int C, int relu, double* partial, int dtype, hipStream_t st) {
+  if (M <= 0) return CSS_ERR_ARG;
+  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, partial, st)
+         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, partial, st)
                             : CSS_ERR_DTYPE;
 }
 
@@ -299,10 +371,4 @@ int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, co
          : dtype == CSS_F32
              ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, s0, s1, count, M, C, relu, st)
              : CSS_ERR_DTYPE;
-}
-int css_launch_bn_param_grad(const double* s0, const double* s1, float* dgamma, float* dbeta, int C, int accumulate,
-                             hipStream_t st) {
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, s0, s1, dgamma, dbeta, C, accumulate);
-  CSS_CHECK_LAUNCH();
-  return CSS_OK;
 }

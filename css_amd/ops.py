@@ -158,14 +158,20 @@ class _BNAct(torch.autograd.Function):
         mean = invstd = None
         count = float(m)
         if training:
-            stats = torch.zeros(2 * c, dtype=torch.float64, device=y.device)
-            call("css_bn_stats", y, m, c, c, stats, stats[c:], dc, dev, st)
-            if sync and _world() > 1:
-                dist.all_reduce(stats)
-                count = float(m) * _world()
+            nrb = _lib.query("css_bn_nrb", m, c, dc)
+            partial = torch.empty((nrb, 2 * c), dtype=torch.float64, device=y.device)
+            call("css_bn_stats", y, m, c, c, partial, dc, dev, st)
             mean, invstd = torch.empty(c, **f32), torch.empty(c, **f32)
-            call("css_bn_finalize", stats, stats[c:], count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
-                 mean, invstd, scale, shift, c, dev, st)
+            if sync and _world() > 1:
+                stats = torch.empty(2 * c, dtype=torch.float64, device=y.device)
+                call("css_bn_reduce", partial, nrb, c, stats, None, None, 0, dev, st)
+                dist.all_reduce(stats)          # SyncBN: (sum, sum of squares) of every rank; equal pixel counts per rank
+                count = float(m) * _world()
+                call("css_bn_finalize", stats, stats[c:], count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                     mean, invstd, scale, shift, c, dev, st)
+            else:
+                call("css_bn_reduce_finalize", partial, nrb, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                     mean, invstd, scale, shift, c, dev, st)
         else:
             call("css_bn_eval_coeff", gamma, beta, running_mean, running_var, float(eps), scale, shift, c, dev, st)
         out = torch.empty_like(y)
@@ -187,12 +193,14 @@ class _BNAct(torch.autograd.Function):
         da = da.contiguous()
         dev, st = dev_stream(da)
         dc = dtype_code(dt)
-        sums = torch.zeros(2 * c, dtype=torch.float64, device=y.device)
-        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, m, c, int(relu), sums, sums[c:], dc, dev, st)
+        nrb = _lib.query("css_bn_nrb", m, c, dc)
+        partial = torch.empty((nrb, 2 * c), dtype=torch.float64, device=y.device)
+        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, m, c, int(relu), partial, dc, dev, st)
+        sums = torch.empty(2 * c, dtype=torch.float64, device=y.device)
         dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
         # parameter gradients are LOCAL sums (DDP / the trainer all-reduce them with the rest)
-        call("css_bn_param_grad", sums, sums[c:], dgamma, dbeta, c, 0, dev, st)
+        call("css_bn_reduce", partial, nrb, c, sums, dgamma, dbeta, 0, dev, st)
         if sync and _world() > 1:
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat)
         dy = torch.empty_like(y)

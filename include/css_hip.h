@@ -51,7 +51,16 @@ CSS_API int css_weight_layout(const float* w, void* out, int Cout, int taps, int
                               css_stream_t stream);
 
 /* ---- batch norm: nn.BatchNorm2d / nn.SyncBatchNorm (mix_label.py:76) in train and eval mode -------- */
-CSS_API int css_bn_stats(const void* y, int M, int C, int ld, double* sum, double* sumsq, int dtype, int device, css_stream_t stream);
+/* two-stage per-channel reduction: css_bn_stats / css_bn_bwd_reduce store one fp64 partial row [2][C] per row-block
+ * (nrb = css_bn_nrb(M, C, dtype) rows; plain stores, no atomics); css_bn_reduce sums them in fp64 (and can emit the BN
+ * parameter gradients), css_bn_reduce_finalize fuses that sum with the train-mode finalize for the single-rank case. */
+CSS_API int css_bn_nrb(int M, int C, int dtype);
+CSS_API int css_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_reduce(const double* partial, int nrb, int C, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
+                          css_stream_t stream);
+CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
+                                   float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                   int C, int device, css_stream_t stream);
 CSS_API int css_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                             int device, css_stream_t stream);
@@ -60,12 +69,10 @@ CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
                          int relu, int dtype, int device, css_stream_t stream);
 CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
-                              int M, int C, int relu, double* sum_dz, double* sum_dzx, int dtype, int device, css_stream_t stream);
+                              int M, int C, int relu, double* partial, int dtype, int device, css_stream_t stream);
 CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                              const float* mean, const float* invstd, const float* gamma, const double* sum_dz, const double* sum_dzx,
                              double count, int M, int C, int relu, int dtype, int device, css_stream_t stream);
-CSS_API int css_bn_param_grad(const double* sum_dz, const double* sum_dzx, float* dgamma, float* dbeta, int C, int accumulate, int device,
-                              css_stream_t stream);
 
 /* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
 CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
