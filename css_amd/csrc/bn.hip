@@ -59,26 +59,37 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
   }
 }
 
-// stage 2: sums[j] = sum_rb partial[rb][j]  for j in [0, 2C)  (fp64), optional fused train-mode finalize
+// stage 2: sums[j] = sum_rb partial[rb][j]  for j in [0, 2C)  (fp64), optional fused train-mode finalize.
+// block = 256 threads = 16 channels x 16 row partitions (a 16-channel fp64 segment is one 128-byte line); 4 loads in flight.
 __device__ __forceinline__ void reduce_partials_pair(const double* __restrict__ partial, int nrb, int C, int c, int part, double& a0, double& a1) {
-  a0 = 0; a1 = 0;
-  if (c < C)
-    for (int rb = part; rb < nrb; rb += 4) {
-      a0 += partial[(size_t)rb * 2 * C + c];
-      a1 += partial[(size_t)rb * 2 * C + C + c];
+  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
+  if (c < C) {
+    int rb = part;
+    for (; rb + 48 < nrb; rb += 64) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s0[u] += partial[(size_t)(rb + 16 * u) * 2 * C + c];
+        s1[u] += partial[(size_t)(rb + 16 * u) * 2 * C + C + c];
+      }
     }
-  __shared__ double red[2][4][64];
-  red[0][part][threadIdx.x & 63] = a0;
-  red[1][part][threadIdx.x & 63] = a1;
+    for (; rb < nrb; rb += 16) {
+      s0[0] += partial[(size_t)rb * 2 * C + c];
+      s1[0] += partial[(size_t)rb * 2 * C + C + c];
+    }
+  }
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15;
+  red[0][part][cl] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
+  red[1][part][cl] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
   __syncthreads();
-  const int l = threadIdx.x & 63;
-  a0 = red[0][0][l] + red[0][1][l] + red[0][2][l] + red[0][3][l];
-  a1 = red[1][0][l] + red[1][1][l] + red[1][2][l] + red[1][3][l];
+  a0 = 0; a1 = 0;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { a0 += red[0][q][cl]; a1 += red[1][q][cl]; }
 }
-// grid = ceil(C/64), block 256
+// grid = ceil(C/16), block 256
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, double* __restrict__ sums,
                                                         float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
   double a0, a1;
   reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
   if (part == 0 && c < C) {
@@ -93,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                  float* running_mean, float* running_var, float momentum, float eps,
                                                                  float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
   double a0, a1;
   reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
   if (part != 0 || c >= C) return;
@@ -245,11 +256,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ---- launchers -----------------------------------------------------------
-// rows per block such that ~768 blocks cover the tensor (>= 4 rows per thread)
+// rows per block: every block streams >= 128 KiB (so that the partial rows stay ~1 % of the tensor), at most ~768 blocks
 static inline int pick_rows_per_block(int M, int C, int vec) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
-  int want = 768 / ybl;
+  const long bytes = (long)M * C * (16 / vec);
+  long want = bytes / (128 * 1024) / ybl;
+  if (want > 768 / ybl) want = 768 / ybl;
   if (want < 1) want = 1;
   int rpb = cdiv(M, want);
   rpb = cdiv(rpb, RPB) * RPB;
@@ -279,14 +292,14 @@ int css_launch_bn_stats(const void* y, int M, int C, int ld, double* partial, in
          : dtype == CSS_F32 ? bn_stats_T<float>(y, M, C, ld, partial, st) : CSS_ERR_DTYPE;
 }
 int css_launch_bn_reduce(const double* partial, int nrb, int C, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, partial, nrb, C, sums, g1, g0, accumulate);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, C, sums, g1, g0, accumulate);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                                   hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, partial, nrb, count, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, count, gamma, beta, running_mean, running_var,
                      momentum, eps, mean, invstd, scale, shift, C);
   CSS_CHECK_LAUNCH();
   return CSS_OK;

@@ -29,3 +29,19 @@ def bf16_round(x):
 
 
 TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def robust_err(a, b, q=0.9):
+    """(q-quantile, max) of |a-b| / max|b|.  Block-level backward checks use the quantile: a ReLU whose pre-activation
+    sits within fp32 rounding of 0 can get a different mask in the two implementations (probability ~1e-7 x #elements
+    per layer), which perturbs a few per cent of the gradient elements by O(1e-2) -- a wiring bug perturbs far more."""
+    a, b = a.double().flatten(), b.double().flatten()
+    e = (a - b).abs() / (b.abs().max() + 1e-30)
+    if e.numel() > 2_000_000:
+        e = e[:: e.numel() // 2_000_000 + 1]
+    return torch.quantile(e, q).item(), e.max().item()
+
+
+def assert_close_robust(a, b, tol, what=""):
+    q, m = robust_err(a, b)
+    assert q < tol and m < 0.3, (what, q, m)

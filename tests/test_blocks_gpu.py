@@ -8,7 +8,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from gpu_util import dev, rel_err, to_nchw_cpu, to_nhwc  # noqa: E402
+from gpu_util import assert_close_robust, dev, rel_err, robust_err, to_nchw_cpu, to_nhwc  # noqa: E402
 
 TOL = 1e-4
 
@@ -23,9 +23,7 @@ def _check_grads(module, sd, prefix, names):
     worst = 0.0
     named = dict(module.named_parameters())
     for n in names:
-        e = rel_err(named[n[len(prefix):]].grad.cpu(), sd[n].grad)
-        worst = max(worst, e)
-        assert e < TOL, (n, e)
+        assert_close_robust(named[n[len(prefix):]].grad.cpu(), sd[n].grad, TOL, n)
     return worst
 
 
@@ -53,7 +51,7 @@ def test_bottleneck_block(li, bi, size):
     og = blk(xg)
     assert rel_err(to_nchw_cpu(og), o.detach()) < TOL
     (og * to_nhwc(wl, torch.float32)).sum().backward()
-    assert rel_err(to_nchw_cpu(xg.grad), xr.grad) < TOL
+    assert_close_robust(to_nchw_cpu(xg.grad), xr.grad, TOL, "dx")
     _check_grads(blk, sd, prefix, names)
 
 
@@ -86,8 +84,7 @@ def test_stem_maxpool_tv_and_deepstem():
         (og * to_nhwc(wl, torch.float32)).sum().backward()
         named = dict(m.named_parameters())
         for n in names:
-            e = rel_err(named[n.replace("resnet_", "", 1)].grad.cpu(), sd[n].grad)
-            assert e < TOL, (bb, n, e)
+            assert_close_robust(named[n.replace("resnet_", "", 1)].grad.cpu(), sd[n].grad, TOL, (bb, n))
 
 
 def test_aspp_decoder_heads():
@@ -135,10 +132,10 @@ def test_aspp_decoder_heads():
     ((pg.permute(0, 3, 1, 2) * wp.to(dev())).sum() + (rg.permute(0, 3, 1, 2) * wr.to(dev())).sum()).backward()
     # the pooled branch normalises over only B=3 samples per channel: invstd up to 1/sqrt(eps) amplifies fp32 rounding
     # in its backward (same effect as the N*H*W == 2 case of test_ops_gpu), and its input gradient is added to x4's
-    errs = {"x4": rel_err(to_nchw_cpu(x4g.grad), x4r.grad), "xl": rel_err(to_nchw_cpu(xlg.grad), xlr.grad)}
+    errs = {"x4": robust_err(to_nchw_cpu(x4g.grad), x4r.grad)[0], "xl": robust_err(to_nchw_cpu(xlg.grad), xlr.grad)[0]}
     named = dict(net.named_parameters())
     for n in names:
-        errs[n] = rel_err(named[n].grad.cpu(), sd[n].grad)
+        errs[n] = robust_err(named[n].grad.cpu(), sd[n].grad)[0]
     print("aspp/decoder grad errs: max", max(errs.values()), {k: f"{v:.1e}" for k, v in errs.items() if v > TOL})
     for n, e in errs.items():
         assert e < (2e-3 if (n == "x4" or "convs.4." in n) else TOL), (n, e)
