@@ -10,7 +10,9 @@ pytestmark = pytest.mark.gpu
 
 from gpu_util import assert_close_robust, dev, rel_err, robust_err, to_nchw_cpu, to_nhwc  # noqa: E402
 
-TOL = 1e-4
+TOL = 1e-4    # forward (max-norm)
+GTOL = 1e-3   # gradients (90th percentile): one flipped ReLU reaches every element at the ~1e-4 level through the
+              # per-channel means of the batch-norm backward; a wiring bug is O(1) on most elements
 
 
 def _load(module, sd, prefix):
@@ -23,7 +25,7 @@ def _check_grads(module, sd, prefix, names):
     worst = 0.0
     named = dict(module.named_parameters())
     for n in names:
-        assert_close_robust(named[n[len(prefix):]].grad.cpu(), sd[n].grad, TOL, n)
+        assert_close_robust(named[n[len(prefix):]].grad.cpu(), sd[n].grad, GTOL, n)
     return worst
 
 
@@ -51,7 +53,7 @@ def test_bottleneck_block(li, bi, size):
     og = blk(xg)
     assert rel_err(to_nchw_cpu(og), o.detach()) < TOL
     (og * to_nhwc(wl, torch.float32)).sum().backward()
-    assert_close_robust(to_nchw_cpu(xg.grad), xr.grad, TOL, "dx")
+    assert_close_robust(to_nchw_cpu(xg.grad), xr.grad, GTOL, "dx")
     _check_grads(blk, sd, prefix, names)
 
 
@@ -84,7 +86,7 @@ def test_stem_maxpool_tv_and_deepstem():
         (og * to_nhwc(wl, torch.float32)).sum().backward()
         named = dict(m.named_parameters())
         for n in names:
-            assert_close_robust(named[n.replace("resnet_", "", 1)].grad.cpu(), sd[n].grad, TOL, (bb, n))
+            assert_close_robust(named[n.replace("resnet_", "", 1)].grad.cpu(), sd[n].grad, GTOL, (bb, n))
 
 
 def test_aspp_decoder_heads():
