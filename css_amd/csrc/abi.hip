@@ -129,28 +129,27 @@ int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, in
 }
 
 // ---- batch norm ----
-int css_bn_nrb(int M, int C, int dtype) { return css_bn_nrb_(M, C, dtype); }
-int css_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, int device, css_stream_t stream) {
+int css_bn_nrb(int Mg, int G, int C, int dtype) { return css_bn_nrb_(Mg, G, C, dtype); }
+int css_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_stats(y, M, C, ld, partial, dtype, S(stream));
+  return css_launch_bn_stats(y, Mg, G, C, ld, partial, dtype, S(stream));
 }
-int css_bn_reduce(const double* partial, int nrb, int C, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
+int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
                   css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_reduce(partial, nrb, C, sums, dgamma, dbeta, accumulate, S(stream));
+  return css_launch_bn_reduce(partial, nrb, C, G, sums, dgamma, dbeta, accumulate, S(stream));
 }
-int css_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
+int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                            int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_reduce_finalize(partial, nrb, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C,
-                                       S(stream));
+  return css_launch_bn_reduce_finalize(partial, nrb, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                                       C, S(stream));
 }
-int css_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
-                    float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device,
-                    css_stream_t stream) {
+int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_finalize(sum, sumsq, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
+  return css_launch_bn_finalize(sums, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
 }
 int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                       float* shift, int C, int device, css_stream_t stream) {
@@ -158,20 +157,20 @@ int css_bn_eval_coeff(const float* gamma, const float* beta, const float* runnin
   return css_launch_bn_eval_coeff(gamma, beta, running_mean, running_var, eps, scale, shift, C, S(stream));
 }
 int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C, int relu,
-                 int dtype, int device, css_stream_t stream) {
+                 int Mg, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, dtype, S(stream));
+  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, dtype, S(stream));
 }
-int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int M, int C,
-                      int relu, double* partial, int dtype, int device, css_stream_t stream) {
+int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int Mg,
+                      int G, int C, int relu, double* partial, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, partial, dtype, S(stream));
+  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, dtype, S(stream));
 }
 int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                     const float* mean, const float* invstd, const float* gamma, const double* sum_dz, const double* sum_dzx, double count, int M,
-                     int C, int relu, int dtype, int device, css_stream_t stream) {
+                     const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C, int relu, int Mg,
+                     int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sum_dz, sum_dzx, count, M, C, relu, dtype,
+  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, dtype,
                                  S(stream));
 }
 

@@ -15,7 +15,8 @@
 // stores: 1000 blocks doing fp64 atomics onto the same 2C addresses ran at ~390 GB/s, the contended-atomic regime).
 // Stage 2 (bn_reduce*_kernel below) sums the partial rows in fp64.
 template <typename T, typename F>
-__device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_block, double* partial) {
+__device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per_block, double* partial) {
+  // blockIdx.z = statistics group (one group per forward pass batched into the tensor); gridDim.x = row blocks per group
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256;
@@ -27,8 +28,9 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
   float s0[VEC], s1[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.f;
-  const int row0 = blockIdx.x * rows_per_block;
-  const int row1 = min(M, row0 + rows_per_block);
+  const int gbase = blockIdx.z * Mg;
+  const int row0 = gbase + blockIdx.x * rows_per_block;
+  const int row1 = min(gbase + Mg, row0 + rows_per_block);
   if (active) {
     int r = row0 + rg;
     for (; r + RPB < row1; r += 2 * RPB) {   // two independent rows in flight
@@ -45,7 +47,7 @@ __device__ __forceinline__ void channel_reduce2(F f, int M, int C, int rows_per_
   }
   __syncthreads();
   if (rg == 0 && cv < CV) {
-    double* p0 = partial + (size_t)blockIdx.x * 2 * C + cv * VEC;
+    double* p0 = partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * C + cv * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       double a0 = 0, a1 = 0;
@@ -86,28 +88,28 @@ __device__ __forceinline__ void reduce_partials_pair(const double* __restrict__ 
 #pragma unroll
   for (int q = 0; q < 16; ++q) { a0 += red[0][q][cl]; a1 += red[1][q][cl]; }
 }
-// grid = ceil(C/16), block 256
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, double* __restrict__ sums,
+// grid = ceil(C/16), block 256.  partial is [G][nrb][2][C]; sums is [G][2][C].
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, int G, double* __restrict__ sums,
                                                         float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
   const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-  double a0, a1;
-  reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
-  if (part == 0 && c < C) {
-    if (sums) { sums[c] = a0; sums[C + c] = a1; }
-    if (g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat)
-      if (accumulate) { g0[c] += (float)a0; g1[c] += (float)a1; }
-      else { g0[c] = (float)a0; g1[c] = (float)a1; }
-    }
+  double t0 = 0, t1 = 0;
+  for (int g = 0; g < G; ++g) {
+    double a0, a1;
+    reduce_partials_pair(partial + (size_t)g * nrb * 2 * C, nrb, C, c, part, a0, a1);
+    __syncthreads();
+    if (part == 0 && c < C && sums) { sums[(size_t)g * 2 * C + c] = a0; sums[(size_t)g * 2 * C + C + c] = a1; }
+    t0 += a0; t1 += a1;
+  }
+  if (part == 0 && c < C && g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat), summed over the groups
+    if (accumulate) { g0[c] += (float)t0; g1[c] += (float)t1; }
+    else { g0[c] = (float)t0; g1[c] = (float)t1; }
   }
 }
-__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nrb, double count,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float* running_mean, float* running_var, float momentum, float eps,
-                                                                 float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-  double a0, a1;
-  reduce_partials_pair(partial, nrb, C, c, part, a0, a1);
-  if (part != 0 || c >= C) return;
+// train-mode finalize for G groups: per-group mean/invstd/scale/shift ([G][C]); the running statistics take the G
+// momentum updates one after the other, exactly like G separate forward passes (mix_label.py:166 -> ddp_model.py:102-103,140-143)
+__device__ __forceinline__ void bn_finalize_one(double a0, double a1, double count, float gam, float bet, float* running_mean, float* running_var,
+                                                float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                                                int c) {
   double mean = a0 / count;
   double var = a1 / count - mean * mean;
   if (var < 0) var = 0;
@@ -115,18 +117,32 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
   const float invstd = 1.0f / sqrtf(fvar + eps);
   mean_out[c] = fmean;
   invstd_out[c] = invstd;
-  const float sc = gamma[c] * invstd;
+  const float sc = gam * invstd;
   scale_out[c] = sc;
-  shift_out[c] = beta[c] - fmean * sc;
+  shift_out[c] = bet - fmean * sc;
   if (running_mean) {
     const double unbiased = count > 1 ? var * count / (count - 1) : var;
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nrb, int G, double count,
+                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                 float* running_mean, float* running_var, float momentum, float eps,
+                                                                 float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
+  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+  for (int g = 0; g < G; ++g) {
+    double a0, a1;
+    reduce_partials_pair(partial + (size_t)g * nrb * 2 * C, nrb, C, c, part, a0, a1);
+    __syncthreads();
+    if (part == 0 && c < C)
+      bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+                      scale_out + g * C, shift_out + g * C, c);
+  }
+}
 
 template <typename T>
-__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int M, int C, int ld,
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int Mg, int C, int ld,
                                                        int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
   auto f = [&](int r, int c, float* s0, float* s1) {
@@ -139,30 +155,18 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
       s1[e] += x * x;
     }
   };
-  channel_reduce2<T>(f, M, C, rows_per_block, partial);
+  channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sumsq, double count,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, double count,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double mean = sum[c] / count;
-  double var = sumsq[c] / count - mean * mean;
-  if (var < 0) var = 0;
-  float fmean = (float)mean, fvar = (float)var;
-  float invstd = 1.0f / sqrtf(fvar + eps);
-  mean_out[c] = fmean;
-  invstd_out[c] = invstd;
-  float sc = gamma[c] * invstd;
-  scale_out[c] = sc;
-  shift_out[c] = beta[c] - fmean * sc;
-  if (running_mean) {
-    double unbiased = count > 1 ? var * count / (count - 1) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * fmean;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
+  for (int g = 0; g < G; ++g)
+    bn_finalize_one(sums[(size_t)g * 2 * C + c], sums[(size_t)g * 2 * C + C + c], count, gamma[c], beta[c], running_mean, running_var, momentum, eps,
+                    mean_out + g * C, invstd_out + g * C, scale_out + g * C, shift_out + g * C, c);
 }
 
 // eval mode: scale/shift from running statistics
@@ -180,18 +184,19 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
                                                        T* __restrict__ out, int ldo, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int M, int C, int relu) {
+                                                       const float* __restrict__ shift, int M, int C, int relu, int Mg) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const size_t total = (size_t)M * CV;
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
+    const int go = (r >= Mg ? (r / Mg) : 0) * C;     // statistics group of this row
     Vec16<T> v, o, rr;
     v.load(y + (size_t)r * ldy + c);
     if (res) rr.load(res + (size_t)r * ldr + c);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float x = v.f(e) * scale[c + e] + shift[c + e];
+      float x = v.f(e) * scale[go + c + e] + shift[go + c + e];
       if (res) x += rr.f(e);
       if (relu) x = fmaxf(x, 0.f);
       o.set(e, x);
@@ -204,8 +209,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a,
                                                             int lda, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                            int M, int C, int relu, int rows_per_block, double* partial) {
+                                                            int Mg, int C, int relu, int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
+  mean += blockIdx.z * C;
+  invstd += blockIdx.z * C;
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> g, av, yv;
     g.load(da + (size_t)r * ldda + c);
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s1[e] += dz * xh;
     }
   };
-  channel_reduce2<T>(f, M, C, rows_per_block, partial);
+  channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
 }
 
 template <typename T>
@@ -229,13 +236,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dres, int lddr, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx,
-                                                           double count, int M, int C, int relu) {
+                                                           double count, int M, int C, int relu, int Mg) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const size_t total = (size_t)M * CV;
   const float inv_n = (float)(1.0 / count);
   for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
     const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
+    const int gi = r >= Mg ? (r / Mg) : 0;
+    const float* mean_g = mean + gi * C;
+    const float* invstd_g = invstd + gi * C;
+    const double* sum_dz_g = sum_dz + (size_t)gi * 2 * C;      // sums are [G][2][C]
+    const double* sum_dzx_g = sum_dz_g + C;
     Vec16<T> g, av, yv, o, dr;
     g.load(da + (size_t)r * ldda + c);
     yv.load(y + (size_t)r * ldy + c);
@@ -244,9 +256,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     for (int e = 0; e < VEC; ++e) {
       float dz = g.f(e);
       if (relu && !(av.f(e) > 0.f)) dz = 0.f;
-      const float is = invstd[c + e];
-      const float xh = (yv.f(e) - mean[c + e]) * is;
-      const float m1 = (float)sum_dz[c + e] * inv_n, m2 = (float)sum_dzx[c + e] * inv_n;
+      const float is = invstd_g[c + e];
+      const float xh = (yv.f(e) - mean_g[c + e]) * is;
+      const float m1 = (float)sum_dz_g[c + e] * inv_n, m2 = (float)sum_dzx_g[c + e] * inv_n;
       o.set(e, gamma[c + e] * is * (dz - m1 - xh * m2));
       dr.set(e, dz);
     }
@@ -256,60 +268,61 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ---- launchers -----------------------------------------------------------
+// Tensors are [M = G*Mg][C]: G statistics groups of Mg rows each (G forward passes batched into one tensor).
 // rows per block: every block streams >= 128 KiB (so that the partial rows stay ~1 % of the tensor), at most ~768 blocks
-static inline int pick_rows_per_block(int M, int C, int vec) {
+static inline int pick_rows_per_block(int Mg, int G, int C, int vec) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
-  const long bytes = (long)M * C * (16 / vec);
+  const long bytes = (long)Mg * C * (16 / vec);
   long want = bytes / (128 * 1024) / ybl;
-  if (want > 768 / ybl) want = 768 / ybl;
+  const long cap = 768 / ((long)ybl * G) > 0 ? 768 / ((long)ybl * G) : 1;
+  if (want > cap) want = cap;
   if (want < 1) want = 1;
-  int rpb = cdiv(M, want);
+  int rpb = cdiv(Mg, want);
   rpb = cdiv(rpb, RPB) * RPB;
   if (rpb < 4 * RPB) rpb = 4 * RPB;
   return rpb;
 }
-int css_bn_nrb_(int M, int C, int dtype) {
+int css_bn_nrb_(int Mg, int G, int C, int dtype) {
   const int vec = dtype == CSS_BF16 ? 8 : 4;
-  if (M <= 0) return 1;
-  return cdiv(M, pick_rows_per_block(M, C, vec));
+  if (Mg <= 0) return 1;
+  return cdiv(Mg, pick_rows_per_block(Mg, G, C, vec));
 }
 
 template <typename T>
-static int bn_stats_T(const void* y, int M, int C, int ld, double* partial, hipStream_t st) {
+static int bn_stats_T(const void* y, int Mg, int G, int C, int ld, double* partial, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ld % VEC) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
-  const int rpb = pick_rows_per_block(M, C, VEC);
-  dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
-  hipLaunchKernelGGL(bn_stats_kernel<T>, g, dim3(256), 0, st, (const T*)y, M, C, ld, rpb, partial);
+  const int rpb = pick_rows_per_block(Mg, G, C, VEC);
+  dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
+  hipLaunchKernelGGL(bn_stats_kernel<T>, g, dim3(256), 0, st, (const T*)y, Mg, C, ld, rpb, partial);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, hipStream_t st) {
-  if (M <= 0) return CSS_ERR_ARG;
-  return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, M, C, ld, partial, st)
-         : dtype == CSS_F32 ? bn_stats_T<float>(y, M, C, ld, partial, st) : CSS_ERR_DTYPE;
+int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st) {
+  if (Mg <= 0 || G <= 0) return CSS_ERR_ARG;
+  return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, Mg, G, C, ld, partial, st)
+         : dtype == CSS_F32 ? bn_stats_T<float>(y, Mg, G, C, ld, partial, st) : CSS_ERR_DTYPE;
 }
-int css_launch_bn_reduce(const double* partial, int nrb, int C, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, C, sums, g1, g0, accumulate);
+int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, C, G, sums, g1, g0, accumulate);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
-                                  float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
-                                  hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, count, gamma, beta, running_mean, running_var,
-                     momentum, eps, mean, invstd, scale, shift, C);
-  CSS_CHECK_LAUNCH();
-  return CSS_OK;
-}
-
-int css_launch_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta,
-                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                           float* scale, float* shift, int C, hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sum, sumsq, count, gamma, beta, running_mean,
+int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                  float* shift, int C, hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, G, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift, C);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
+                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sums, G, count, gamma, beta, running_mean, running_var,
+                     momentum, eps, mean, invstd, scale, shift, C);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
@@ -327,61 +340,63 @@ static inline int ew_grid(size_t total) {
 
 template <typename T>
 static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
-                      const float* shift, int M, int C, int relu, hipStream_t st) {
+                      const float* shift, int M, int C, int relu, int Mg, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
   hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)y, ldy,
-                     (const T*)res, ldr, (T*)out, ldo, scale, shift, M, C, relu);
+                     (const T*)res, ldr, (T*)out, ldo, scale, shift, M, C, relu, Mg);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
-                        const float* shift, int M, int C, int relu, int dtype, hipStream_t st) {
+                        const float* shift, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
-  return dtype == CSS_BF16 ? bn_apply_T<bf16_t>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, st)
-         : dtype == CSS_F32 ? bn_apply_T<float>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, st) : CSS_ERR_DTYPE;
+  if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
+  return dtype == CSS_BF16 ? bn_apply_T<bf16_t>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, st)
+         : dtype == CSS_F32 ? bn_apply_T<float>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, st) : CSS_ERR_DTYPE;
 }
 
 template <typename T>
 static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                           const float* invstd, int M, int C, int relu, double* partial, hipStream_t st) {
+                           const float* invstd, int Mg, int G, int C, int relu, double* partial, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldda % VEC || ldy % VEC || (relu && lda % VEC)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
-  const int rpb = pick_rows_per_block(M, C, VEC);
-  dim3 g(cdiv(M, rpb), cdiv(CV, TPC));
+  const int rpb = pick_rows_per_block(Mg, G, C, VEC);
+  dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean,
-                     invstd, M, C, relu, rpb, partial);
+                     invstd, Mg, C, relu, rpb, partial);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                             const float* invstd, int M, int C, int relu, double* partial, int dtype, hipStream_t st) {
-  if (M <= 0) return CSS_ERR_ARG;
-  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, partial, st)
-         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, M, C, relu, partial, st)
+                             const float* invstd, int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st) {
+  if (Mg <= 0 || G <= 0) return CSS_ERR_ARG;
+  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, st)
+         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, st)
                             : CSS_ERR_DTYPE;
 }
 
 template <typename T>
 static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
-                          void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* s0,
-                          const double* s1, double count, int M, int C, int relu, hipStream_t st) {
+                          void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                          double count, int M, int C, int relu, int Mg, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && lda % VEC) || (dres && lddr % VEC)) return CSS_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)da, ldda,
-                     (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, (T*)dres, lddr, mean, invstd, gamma, s0, s1, count, M, C,
-                     relu);
+                     (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, (T*)dres, lddr, mean, invstd, gamma, sums, sums, count, M, C,
+                     relu, Mg);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
-                            void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* s0,
-                            const double* s1, double count, int M, int C, int relu, int dtype, hipStream_t st) {
+                            void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
+                            double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
+  if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
   return dtype == CSS_BF16
-             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, s0, s1, count, M, C, relu, st)
+             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, st)
          : dtype == CSS_F32
-             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, s0, s1, count, M, C, relu, st)
+             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, st)
              : CSS_ERR_DTYPE;
 }

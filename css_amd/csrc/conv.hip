@@ -41,6 +41,16 @@ template <> struct Mma<float> {
   }
 };
 
+// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros in hardware, so the im2col zero padding,
+// the M / Cout / K tails and the "ghost" prefetches past the last K tile need no branches, and the compiler can keep
+// exact vmcnt counts for a prefetch distance of two tiles.
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   using MT = Mma<T>;
@@ -63,9 +73,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-  const T* __restrict__ src = reinterpret_cast<const T*>(a.src);
-  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give each XCD a contiguous run of
+  // logical tiles, n-tile fastest: tiles that share an activation panel run on one XCD's L2 at the same time.
+  const int nt_n = (a.Cd + BN - 1) / BN;
+  const int ntiles = gridDim.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
+  const int m0 = (logical / nt_n) * BM, n0 = (logical % nt_n) * BN;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (int)a.wt_bytes, 0x00020000);
 
   const int kv = tid % KV;
   const int prow = tid / KV;
@@ -95,6 +112,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       a_w[i] = -0x40000000;
     }
   }
+  unsigned b_off[B_IT];   // byte offset of this thread's weight rows (OOB for rows >= Cout)
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + prow + i * RPP;
+    b_off[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * (unsigned)sizeof(T) : OOB;
+  }
   // ---- running (tap, channel) position of this thread's vector column ---
   int kc = kv * VEC, tr = 0, ts = 0;
   while (kc >= a.Cs) {
@@ -103,8 +126,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   }
   int kglob = kv * VEC;  // global k of this thread's vector (for the weight tile)
 
-  uint4 ra[A_IT], rb[B_IT];
-  auto load_tiles = [&]() {
+  // issue the loads of the NEXT K tile into (ra, rb) and advance the K position; never branches
+  auto issue = [&](uint4 (&ra)[A_IT], uint4 (&rb)[B_IT]) {
     const bool tap_ok = tr < a.R;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -114,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         hs = a_h[i] + tr * a.dil;
         ws = a_w[i] + ts * a.dil;
       } else {
-        int th = a_h[i] - tr * a.dil, tw = a_w[i] - ts * a.dil;
+        const int th = a_h[i] - tr * a.dil, tw = a_w[i] - ts * a.dil;
         ok = ok && th >= 0 && tw >= 0;
         if (a.stride == 2) {
           ok = ok && !((th | tw) & 1);
@@ -126,24 +149,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
         }
       }
       ok = ok && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
-      if (ok) {
-        size_t off = (size_t)(a_base[i] + hs * a.Ws + ws) * a.lds + kc;
-        ra[i] = *reinterpret_cast<const uint4*>(src + off);
-      } else {
-        ra[i] = make_uint4(0, 0, 0, 0);
-      }
+      const unsigned off = (unsigned)((a_base[i] + hs * a.Ws + ws) * a.lds + kc) * (unsigned)sizeof(T);
+#ifdef CSS_ABLATE_NOLOAD
+      ra[i] = make_uint4(off, ok, 0, 0);
+#else
+      ra[i] = bload16(rs_a, ok ? off : OOB);
+#endif
     }
+    const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * (unsigned)sizeof(T) : OOB;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-      int n = n0 + prow + i * RPP;
-      if (n < a.Cd && kglob < a.Ktot) {
-        rb[i] = *reinterpret_cast<const uint4*>(wt + (size_t)n * a.Ktot + kglob);
-      } else {
-        rb[i] = make_uint4(0, 0, 0, 0);
-      }
-    }
-  };
-  auto advance_k = [&]() {
+    for (int i = 0; i < B_IT; ++i)
+#ifdef CSS_ABLATE_NOLOAD
+      rb[i] = make_uint4(b_off[i], kb, 0, 0);
+#else
+      rb[i] = bload16(rs_b, (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
+#endif
     kglob += BK;
     kc += BK;
     while (kc >= a.Cs) {
@@ -151,15 +171,22 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
       if (++ts == a.S) { ts = 0; ++tr; }
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const uint4 (&ra)[A_IT], const uint4 (&rb)[B_IT], int buf) {
     T* Ab = As + buf * BM * STR;
     T* Bb = Bs + buf * BN * STR;
+#ifdef CSS_ABLATE_NOSTORE
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) asm volatile("" ::"v"(ra[i].x), "v"(ra[i].y), "v"(ra[i].z), "v"(ra[i].w));
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) asm volatile("" ::"v"(rb[i].x), "v"(rb[i].y), "v"(rb[i].z), "v"(rb[i].w));
+#else
 #pragma unroll
     for (int i = 0; i < A_IT; ++i)
       *reinterpret_cast<uint4*>(Ab + (prow + i * RPP) * STR + kv * VEC) = ra[i];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i)
       *reinterpret_cast<uint4*>(Bb + (prow + i * RPP) * STR + kv * VEC) = rb[i];
+#endif
   };
 
   f32x16 acc[TN][TM];
@@ -170,17 +197,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nk = (a.Ktot + BK - 1) / BK;
-  load_tiles();
-  store_tiles(0);
-  __syncthreads();
   const int l31 = lane & 31, lh = lane >> 5;
-  for (int kt = 0; kt < nk; ++kt) {
-    const int cur = kt & 1;
-    if (kt + 1 < nk) {
-      advance_k();
-      load_tiles();
-    }
+  auto compute = [&](int cur) {
     const T* Ab = As + cur * BM * STR + (wm * WTM + l31) * STR;
     const T* Bb = Bs + cur * BN * STR + (wn * WTN + l31) * STR;
 #pragma unroll
@@ -195,8 +213,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = MT::mma(fw[i], fa[j], acc[i][j]);
     }
-    if (kt + 1 < nk) store_tiles(cur ^ 1);
+  };
+
+  // ---- main loop: register-staged, two K tiles in flight (tiles past the last one are all-OOB loads = zeros) ----
+  const int nk = (a.Ktot + BK - 1) / BK;
+  uint4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];
+  issue(ra0, rb0);
+  issue(ra1, rb1);
+  store_tiles(ra0, rb0, 0);
+  __syncthreads();
+  for (int kt = 0;;) {
+    issue(ra0, rb0);              // tile kt+2
+    compute(0);                   // tile kt
+    store_tiles(ra1, rb1, 1);     // tile kt+1
     __syncthreads();
+    if (++kt >= nk) break;
+    issue(ra1, rb1);              // tile kt+2
+    compute(1);
+    store_tiles(ra0, rb0, 0);
+    __syncthreads();
+    if (++kt >= nk) break;
   }
 
   // ---- epilogue: accumulators -> LDS (wave-private) -> 16-byte row stores
@@ -412,22 +448,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
-int css_launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+int css_launch_conv(const ConvArgs& a_in, int dtype, hipStream_t st) {
+  ConvArgs a = a_in;
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
+  {
+    const size_t esz = dtype == CSS_BF16 ? 2 : 4;
+    const size_t sb = (size_t)a.N * a.Hs * a.Ws * a.lds * esz, wb = (size_t)a.Cd * a.Ktot * esz;
+    if (sb >= 0x7FFFFFF0ull || wb >= 0x7FFFFFF0ull) return CSS_ERR_ARG;   // 32-bit buffer offsets
+    a.src_bytes = (unsigned)sb;
+    a.wt_bytes = (unsigned)wb;
+  }
   if (dtype == CSS_BF16) {
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     if (a.Cd > 64) {
-      dim3 g(cdiv(a.M, 128), cdiv(a.Cd, 128));
+      dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 128));
       hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, a);
     } else {
-      dim3 g(cdiv(a.M, 128), cdiv(a.Cd, 64));
+      dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 64));
       hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, a);
     }
   } else if (dtype == CSS_F32) {
     if (a.Cs % 4 || a.lds % 4 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
-    dim3 g(cdiv(a.M, 64), cdiv(a.Cd, 64));
+    dim3 g(cdiv(a.M, 64) * cdiv(a.Cd, 64));
     hipLaunchKernelGGL((conv_igemm_kernel<float, 64, 64, 16, 2, 2>), g, dim3(256), 0, st, a);
   } else {
     return CSS_ERR_DTYPE;

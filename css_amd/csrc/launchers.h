@@ -13,6 +13,7 @@ struct ConvArgs {
   int mode;  // 0: forward gather  hs = hd*stride - pad + r*dil
              // 1: dgrad gather    hs = (hd + pad - r*dil) / stride   (must divide)
   int M, Ktot;
+  unsigned src_bytes, wt_bytes;   // filled by the launcher (buffer descriptors)
 };
 
 struct WgradArgs {
@@ -30,24 +31,24 @@ struct WgradArgs {
 int css_launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st);
 
-int css_bn_nrb_(int M, int C, int dtype);
-int css_launch_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, hipStream_t st);
-int css_launch_bn_reduce(const double* partial, int nrb, int C, double* sums, float* g1, float* g0, int accumulate, hipStream_t st);
-int css_launch_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
-                                  float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
-                                  hipStream_t st);
-int css_launch_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+int css_bn_nrb_(int Mg, int G, int C, int dtype);
+int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st);
+int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, hipStream_t st);
+int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                  float* shift, int C, hipStream_t st);
+int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                            hipStream_t st);
 int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int C,
                              hipStream_t st);
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
-                        int relu, int dtype, hipStream_t st);
-int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int M,
-                             int C, int relu, double* partial, int dtype, hipStream_t st);
+                        int relu, int Mg, int dtype, hipStream_t st);
+int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
+                             int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st);
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                            const float* mean, const float* invstd, const float* gamma, const double* s0, const double* s1, double count, int M,
-                            int C, int relu, int dtype, hipStream_t st);
+                            const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C, int relu,
+                            int Mg, int dtype, hipStream_t st);
 
 int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
                            int dtype, hipStream_t st);

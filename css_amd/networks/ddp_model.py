@@ -89,13 +89,25 @@ class _StudentTeacher(nn.Module):
         self.step += 1
 
     # ---- shared pieces of the three forwards ------------------------------------------------------------------
+    # The reference calls each network twice per step (labeled batch, unlabeled batch: ddp_model.py:102-103,140-143).  Here
+    # both batches go through the network in ONE pass, concatenated along dim 0, with two batch-norm statistics groups
+    # (css_amd.ops.bn_groups): identical arithmetic, half the kernel launches, twice the rows per launch.
+    def _teacher_pair(self, xl, xu):
+        with ops.bn_groups(2):
+            pred, rep = self.ema_model.forward_nhwc(ops.stage_inputs([xl, xu], self.ema_model.compute_dtype))
+        b = xl.shape[0]
+        return pred[b:], rep[b:]            # the labeled half only moves the teacher's BN running statistics (ddp_model.py:102)
+
     def _teacher(self, x):
         return self.ema_model.forward_nhwc(ops.stage_input(x, self.ema_model.compute_dtype))
 
-    def _student(self, x, out_hw):
-        pred, rep = self.model.forward_nhwc(ops.stage_input(x, self.model.compute_dtype))
+    def _student_pair(self, xl, xu, out_hw):
+        """-> pred [2B,h,w,K], rep_all [2B,h,w,C] (labeled first), pred_l_large, pred_u_large (logical NCHW, fp32)."""
+        with ops.bn_groups(2):
+            pred, rep = self.model.forward_nhwc(ops.stage_inputs([xl, xu], self.model.compute_dtype))
         large = ops.bilinear(pred, out_hw[0], out_hw[1], torch.float32)     # align_corners=True, ddp_model.py:141,144
-        return pred, rep, large.permute(0, 3, 1, 2)
+        ll, lu = ops.split2(large, xl.shape[0])
+        return pred, rep, ll.permute(0, 3, 1, 2), lu.permute(0, 3, 1, 2)
 
 
 class Model_mix(_StudentTeacher):
@@ -107,8 +119,7 @@ class Model_mix(_StudentTeacher):
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True):
         hw = train_u_image.shape[2:]
         with torch.no_grad():
-            self._teacher(train_l_image)          # outputs unused; keeps the teacher's BN running statistics moving (ddp_model.py:102)
-            pred_u, rep_u = self._teacher(train_u_image)
+            pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, pseudo = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
             cfg = self.config["Dataset"]
@@ -117,9 +128,7 @@ class Model_mix(_StudentTeacher):
             u_img, u_lab, u_lc, u_lr = generate_cut_gather_2(u_img, u_lab, u_lc, u_lr, mode=cfg["mix_mode"])
             u_img, u_lab, u_lc, u_lr = batch_transform_2(u_img, u_lab, u_lc, u_lr, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                          augmentation=True)
-        _, rep_l, pred_l_large = self._student(train_l_image, train_l_image.shape[2:])
-        _, rep_u2, pred_u_large = self._student(u_img, train_l_image.shape[2:])
-        rep_all = torch.cat((rep_l, rep_u2))                               # NHWC rows, [2B,h,w,C]
+        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
         prob_all = None
         if _want_prob:                                                     # the trainer derives the hard flags directly instead
             with torch.no_grad():
@@ -137,8 +146,7 @@ class Model_cross(_StudentTeacher):
     def forward(self, train_l_image, train_u_image, prototypes):
         hw = train_u_image.shape[2:]
         with torch.no_grad():
-            self._teacher(train_l_image)
-            pred_u, rep_u = self._teacher(train_u_image)
+            pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, _ = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
             cfg = self.config["Dataset"]
@@ -147,9 +155,7 @@ class Model_cross(_StudentTeacher):
             a = generate_cut_gather_3(*a, mode=cfg["mix_mode"])
             u_img, u_lab_c, u_lab_r, u_lc, u_lr = batch_transform_3(*a, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                                     augmentation=True)
-        _, rep_l, pred_l_large = self._student(train_l_image, train_l_image.shape[2:])
-        _, rep_u2, pred_u_large = self._student(u_img, train_l_image.shape[2:])
-        rep_all = torch.cat((rep_l, rep_u2))
+        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
         with torch.no_grad():
             _, prob_all, _ = Fn.similarity(rep_all, prototypes, self.temp, want_prob=True)
         return (pred_l_large, pred_u_large, u_lab_c, u_lab_r, u_lc, u_lr, rep_all.permute(0, 3, 1, 2),
@@ -166,7 +172,7 @@ class Model_ori_pseudo(_StudentTeacher):
         with torch.no_grad():
             pred_u, _ = self._teacher(train_u_image)
             raw = ops.bilinear(pred_u, hw[0], hw[1], torch.float32)
-            # softmax + max in class space only: reuse the pseudo-label kernel with the logits as both inputs
+            # softmax + max in class space only: the pseudo-label kernel with a constant similarity map
             zero_sim = torch.zeros((*pred_u.shape[:3], self.num_classes), dtype=torch.float32, device=pred_u.device)
             _, _, logits, labels, _ = Fn.pseudo_labels(zero_sim, pred_u, 1.0, hw)
             cfg = self.config["Dataset"]
@@ -174,10 +180,7 @@ class Model_ori_pseudo(_StudentTeacher):
                                                  augmentation=False)
             u_img, u_lab, u_lg = generate_cut_gather(u_img, u_lab, u_lg, mode=cfg["mix_mode"])
             u_img, u_lab, u_lg = batch_transform(u_img, u_lab, u_lg, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0), augmentation=True)
-        pred_l, rep_l, pred_l_large = self._student(train_l_image, train_l_image.shape[2:])
-        pred_u2, rep_u2, pred_u_large = self._student(u_img, train_l_image.shape[2:])
-        rep_all = torch.cat((rep_l, rep_u2))
-        pred_all = torch.cat((pred_l, pred_u2))
+        pred_all, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
         return (pred_l_large, pred_u_large, u_lab, u_lg, rep_all.permute(0, 3, 1, 2), pred_all.permute(0, 3, 1, 2),
                 raw.permute(0, 3, 1, 2))
 

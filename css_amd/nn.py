@@ -79,7 +79,7 @@ class HipBatchNorm2d(nn.Module):
 
     def forward(self, x, res=None, relu=False):
         if self.training:
-            self.num_batches_tracked += 1
+            self.num_batches_tracked += ops._bn_groups
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, self.training,
                           self.momentum, self.eps, self.sync)
 

@@ -145,8 +145,11 @@ def _world():
 
 
 class _BNAct(torch.autograd.Function):
+    """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
+    of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
+
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -154,64 +157,88 @@ class _BNAct(torch.autograd.Function):
         dc = dtype_code(dt)
         assert y.is_contiguous() and (res is None or res.is_contiguous())
         f32 = dict(dtype=torch.float32, device=y.device)
-        scale, shift = torch.empty(c, **f32), torch.empty(c, **f32)
+        g = groups if training else 1
+        assert m % g == 0, (m, g)
+        mg = m // g
+        scale, shift = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
         mean = invstd = None
-        count = float(m)
+        count = float(mg)
         if training:
-            nrb = _lib.query("css_bn_nrb", m, c, dc)
-            partial = torch.empty((nrb, 2 * c), dtype=torch.float64, device=y.device)
-            call("css_bn_stats", y, m, c, c, partial, dc, dev, st)
-            mean, invstd = torch.empty(c, **f32), torch.empty(c, **f32)
+            nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
+            partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
+            call("css_bn_stats", y, mg, g, c, c, partial, dc, dev, st)
+            mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
             if sync and _world() > 1:
-                stats = torch.empty(2 * c, dtype=torch.float64, device=y.device)
-                call("css_bn_reduce", partial, nrb, c, stats, None, None, 0, dev, st)
+                stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
+                call("css_bn_reduce", partial, nrb, c, g, stats, None, None, 0, dev, st)
                 dist.all_reduce(stats)          # SyncBN: (sum, sum of squares) of every rank; equal pixel counts per rank
-                count = float(m) * _world()
-                call("css_bn_finalize", stats, stats[c:], count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                count = float(mg) * _world()
+                call("css_bn_finalize", stats, g, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
-                call("css_bn_reduce_finalize", partial, nrb, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
-                     mean, invstd, scale, shift, c, dev, st)
+                call("css_bn_reduce_finalize", partial, nrb, g, count, gamma, beta, running_mean, running_var, float(momentum),
+                     float(eps), mean, invstd, scale, shift, c, dev, st)
         else:
             call("css_bn_eval_coeff", gamma, beta, running_mean, running_var, float(eps), scale, shift, c, dev, st)
         out = torch.empty_like(y)
-        call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), dc, dev, st)
+        call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
         if training:
             ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
-        ctx.cfg = (relu, training, count, sync, res is not None)
+        ctx.cfg = (relu, training, count, sync, res is not None, g)
         return out
 
     @staticmethod
     def backward(ctx, da):
-        relu, training, count, sync, has_res = ctx.cfg
+        relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
             raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
         y, a, mean, invstd, gamma = ctx.saved_tensors
         c = y.shape[-1]
         m = y.numel() // c
+        mg = m // g
         dt = y.dtype
         da = da.contiguous()
         dev, st = dev_stream(da)
         dc = dtype_code(dt)
-        nrb = _lib.query("css_bn_nrb", m, c, dc)
-        partial = torch.empty((nrb, 2 * c), dtype=torch.float64, device=y.device)
-        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, m, c, int(relu), partial, dc, dev, st)
-        sums = torch.empty(2 * c, dtype=torch.float64, device=y.device)
+        nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
+        partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
+        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, mg, g, c, int(relu), partial, dc, dev, st)
+        sums = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
         dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
         dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
-        # parameter gradients are LOCAL sums (DDP / the trainer all-reduce them with the rest)
-        call("css_bn_reduce", partial, nrb, c, sums, dgamma, dbeta, 0, dev, st)
+        # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
+        call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, dev, st)
         if sync and _world() > 1:
-            dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat)
+            dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, sums[c:], count, m, c, int(relu),
+        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, m, c, int(relu), mg,
              dc, dev, st)
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
-def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True):
-    return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync)
+_bn_groups = 1
+
+
+class bn_groups:
+    """Context manager: the activations inside hold ``g`` forward passes batched along dim 0 (equal sizes)."""
+
+    def __init__(self, g):
+        self.g = g
+
+    def __enter__(self):
+        global _bn_groups
+        self.prev, _bn_groups = _bn_groups, self.g
+
+    def __exit__(self, *a):
+        global _bn_groups
+        _bn_groups = self.prev
+
+
+def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
+           groups=None):
+    return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
+                        _bn_groups if groups is None else groups)
 
 
 # --------------------------------------------------------------------------
@@ -368,6 +395,45 @@ class _CatChannels(torch.autograd.Function):
 
 def cat_channels(*xs):
     return _CatChannels.apply(*xs)
+
+
+class _Split2(torch.autograd.Function):
+    """(x[:b], x[b:]) along dim 0 with a single-copy backward (autograd's own slicing would zero-fill two full tensors)."""
+
+    @staticmethod
+    def forward(ctx, x, b):
+        ctx.b, ctx.shape, ctx.dt = b, x.shape, x.dtype
+        return x.narrow(0, 0, b), x.narrow(0, b, x.shape[0] - b)
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        out = torch.empty(ctx.shape, dtype=ctx.dt, device=(g0 if g0 is not None else g1).device)
+        for g, sl in ((g0, out.narrow(0, 0, ctx.b)), (g1, out.narrow(0, ctx.b, ctx.shape[0] - ctx.b))):
+            if g is None:
+                sl.zero_()
+            else:
+                sl.copy_(g)
+        return out, None
+
+
+def split2(x, b):
+    return _Split2.apply(x, b)
+
+
+def stage_inputs(xs, dtype: torch.dtype) -> torch.Tensor:
+    """Several [Bi,C,H,W] fp32 NCHW images -> ONE [sum Bi,H,W,Cpad] ``dtype`` tensor (each written into its slice)."""
+    xs = [x.detach() if (x.dtype == torch.float32 and x.is_contiguous()) else x.detach().float().contiguous() for x in xs]
+    _, c, h, w = xs[0].shape
+    cp = pad_to(c, vec_of(dtype))
+    bt = sum(x.shape[0] for x in xs)
+    out = torch.empty((bt, h, w, cp), dtype=dtype, device=xs[0].device)
+    dev, st = dev_stream(out)
+    off = 0
+    for x in xs:
+        b = x.shape[0]
+        call("css_nchw_to_nhwc", x, out.data_ptr() + off * h * w * cp * out.element_size(), b, c, h * w, cp, dtype_code(dtype), dev, st)
+        off += b
+    return out
 
 
 def stage_input(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -50,29 +50,34 @@ CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, in
 CSS_API int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device,
                               css_stream_t stream);
 
-/* ---- batch norm: nn.BatchNorm2d / nn.SyncBatchNorm (mix_label.py:76) in train and eval mode -------- */
-/* two-stage per-channel reduction: css_bn_stats / css_bn_bwd_reduce store one fp64 partial row [2][C] per row-block
- * (nrb = css_bn_nrb(M, C, dtype) rows; plain stores, no atomics); css_bn_reduce sums them in fp64 (and can emit the BN
- * parameter gradients), css_bn_reduce_finalize fuses that sum with the train-mode finalize for the single-rank case. */
-CSS_API int css_bn_nrb(int M, int C, int dtype);
-CSS_API int css_bn_stats(const void* y, int M, int C, int ld, double* partial, int dtype, int device, css_stream_t stream);
-CSS_API int css_bn_reduce(const double* partial, int nrb, int C, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
+/* ---- batch norm: nn.BatchNorm2d / nn.SyncBatchNorm (mix_label.py:76) in train and eval mode --------
+ * Tensors are [M = G*Mg][C]: G statistics groups of Mg rows each -- G forward passes of the reference batched into one tensor
+ * (teacher on labeled+unlabeled, ddp_model.py:102-103; student on labeled+augmented, :140-143), every group normalised with
+ * its own batch statistics and the running statistics updated once per group in order, i.e. exactly G separate calls.
+ * Two-stage per-channel reduction: css_bn_stats / css_bn_bwd_reduce store one fp64 partial row [2][C] per row-block and group
+ * (partial is [G][nrb][2][C], nrb = css_bn_nrb(Mg, G, C, dtype); plain stores, no atomics); css_bn_reduce sums them
+ * (sums is [G][2][C]; can also emit the BN parameter gradients, summed over groups); css_bn_reduce_finalize fuses the sum
+ * with the train-mode finalize for the single-rank case; css_bn_finalize starts from (all-reduced) sums.
+ * mean / invstd / scale / shift are [G][C]. */
+CSS_API int css_bn_nrb(int Mg, int G, int C, int dtype);
+CSS_API int css_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
                           css_stream_t stream);
-CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, double count, const float* gamma, const float* beta, float* running_mean,
-                                   float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                                   int C, int device, css_stream_t stream);
-CSS_API int css_bn_finalize(const double* sum, const double* sumsq, double count, const float* gamma, const float* beta, float* running_mean,
+CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
+                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                   float* shift, int C, int device, css_stream_t stream);
+CSS_API int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                             int device, css_stream_t stream);
 CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                               float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
-                         int relu, int dtype, int device, css_stream_t stream);
+                         int relu, int Mg, int dtype, int device, css_stream_t stream);
 CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
-                              int M, int C, int relu, double* partial, int dtype, int device, css_stream_t stream);
+                              int Mg, int G, int C, int relu, double* partial, int dtype, int device, css_stream_t stream);
 CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                             const float* mean, const float* invstd, const float* gamma, const double* sum_dz, const double* sum_dzx,
-                             double count, int M, int C, int relu, int dtype, int device, css_stream_t stream);
+                             const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C,
+                             int relu, int Mg, int dtype, int device, css_stream_t stream);
 
 /* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
 CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,

@@ -1,0 +1,58 @@
+// Standalone timing harness for the conv kernels (ablations via -DCSS_ABLATE_*): hipcc -O3 --offload-arch=gfx950
+#include "../css_amd/csrc/conv.hip"
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+struct Shape { const char* name; int N, H, W, Cin, Cout, R, stride, pad, dil; };
+int main() {
+  std::vector<Shape> shapes = {
+      {"l3 3x3 d2 256->256", 16, 65, 65, 256, 256, 3, 1, 2, 2},
+      {"l3 1x1 1024->256", 16, 65, 65, 1024, 256, 1, 1, 0, 1},
+      {"l3 1x1 256->1024", 16, 65, 65, 256, 1024, 1, 1, 0, 1},
+      {"l4 3x3 d4 512->512", 16, 65, 65, 512, 512, 3, 1, 4, 4},
+      {"l4 1x1 512->2048", 16, 65, 65, 512, 2048, 1, 1, 0, 1},
+      {"aspp 3x3 d12 2048->256", 16, 65, 65, 2048, 256, 3, 1, 12, 12},
+      {"head 3x3 304->256", 16, 129, 129, 304, 256, 3, 1, 1, 1},
+      {"l1 1x1 64->256", 16, 129, 129, 64, 256, 1, 1, 0, 1},
+  };
+  for (auto& s : shapes) {
+    const int Ho = (s.H + 2 * s.pad - s.dil * (s.R - 1) - 1) / s.stride + 1, Wo = Ho;
+    size_t nx = (size_t)s.N * s.H * s.W * s.Cin, nw = (size_t)s.Cout * s.R * s.R * s.Cin, ny = (size_t)s.N * Ho * Wo * s.Cout;
+    std::vector<unsigned short> hx(nx), hw(nw);
+    for (auto& v : hx) v = 0x3C00 + (rand() & 0x3FF) - ((rand() & 1) << 15);   // random bf16-ish bit patterns around +-1
+    for (auto& v : hw) v = 0x3800 + (rand() & 0x3FF) - ((rand() & 1) << 15);
+    void *dx, *dw, *dy;
+    float* dwg;
+    hipMalloc(&dx, nx * 2); hipMalloc(&dw, nw * 2); hipMalloc(&dy, ny * 2); hipMalloc(&dwg, nw * 4);
+    hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice);
+    hipMemset(dwg, 0, nw * 4);
+    ConvArgs a{};
+    a.src = dx; a.wt = dw; a.dst = dy; a.bias = nullptr;
+    a.N = s.N; a.Hs = s.H; a.Ws = s.W; a.Cs = s.Cin; a.lds = s.Cin;
+    a.Hd = Ho; a.Wd = Wo; a.Cd = s.Cout; a.ldd = s.Cout;
+    a.R = s.R; a.S = s.R; a.stride = s.stride; a.pad = s.pad; a.dil = s.dil; a.mode = 0;
+    a.M = s.N * Ho * Wo; a.Ktot = s.R * s.R * s.Cin;
+    WgradArgs g{};
+    g.x = dx; g.dy = dy; g.dw = dwg; g.N = s.N; g.Hs = s.H; g.Ws = s.W; g.Cs = s.Cin; g.ldx = s.Cin; g.Hd = Ho; g.Wd = Wo; g.Cd = s.Cout;
+    g.ldy = s.Cout; g.R = s.R; g.S = s.R; g.stride = s.stride; g.pad = s.pad; g.dil = s.dil; g.M = a.M; g.Ktot = a.Ktot; g.m_per_split = a.M;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flops = 2.0 * a.M * s.Cout * a.Ktot;
+    for (int which = 0; which < 2; ++which) {
+      for (int i = 0; i < 3; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 0);
+      hipDeviceSynchronize();
+      const int reps = 20;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < reps; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 0);
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      printf("%-24s %s  M=%d K=%d N=%d  %8.1f us  %7.1f TFLOP/s\n", s.name, which ? "wgrad" : "fwd  ", a.M, a.Ktot, s.Cout, ms / reps * 1e3,
+             flops / (ms / reps * 1e-3) / 1e12);
+    }
+    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(dwg);
+  }
+  return 0;
+}

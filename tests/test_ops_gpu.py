@@ -202,3 +202,37 @@ def test_stage_input():
         ref = x.permute(0, 2, 3, 1)
         assert rel_err(o[..., :3].float().cpu(), ref if dt == torch.float32 else bf16_round(ref)) == 0
         assert o[..., 3:].abs().max() == 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_groups_equal_separate_passes(dtype):
+    """G forward passes batched along dim 0 with per-group statistics == G separate calls (values, running stats, grads)."""
+    from css_amd import ops
+    g = torch.Generator().manual_seed(9)
+    c = 64
+    xs = [torch.randn(2, c, 9, 7, generator=g) * (1 + i) + i for i in range(2)]
+    rs = [torch.randn(2, c, 9, 7, generator=g) for _ in range(2)]
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    gos = [torch.randn(2, c, 9, 7, generator=g) for _ in range(2)]
+    if dtype == torch.bfloat16:
+        xs, rs, gos = [bf16_round(t) for t in xs], [bf16_round(t) for t in rs], [bf16_round(t) for t in gos]
+    # reference: two sequential F.batch_norm calls sharing parameters and running stats
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm_r, rv_r = rm.clone(), rv.clone()
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    outs = []
+    for i in range(2):
+        outs.append(F.relu(F.batch_norm(xr[i], rm_r, rv_r, gr, br, True, 0.1, 1e-5) + rs[i]))
+    (sum((o * go).sum() for o, go in zip(outs, gos))).backward()
+    xg = to_nhwc(torch.cat(xs), dtype).requires_grad_(True)
+    rg = to_nhwc(torch.cat(rs), dtype)
+    gg, bg = gamma.to(dev()).requires_grad_(True), beta.to(dev()).requires_grad_(True)
+    rmg, rvg = rm.to(dev()), rv.to(dev())
+    og = ops.bn_act(xg, gg, bg, rmg, rvg, rg, True, True, 0.1, 1e-5, False, groups=2)
+    tol = TOL[dtype]
+    assert rel_err(to_nchw_cpu(og), torch.cat(outs).detach()) < tol
+    assert rel_err(rmg.cpu(), rm_r) < 1e-5 and rel_err(rvg.cpu(), rv_r) < 1e-5
+    og.backward(to_nhwc(torch.cat(gos), dtype))
+    assert rel_err(to_nchw_cpu(xg.grad), torch.cat([t.grad for t in xr])) < tol * 5
+    assert rel_err(gg.grad.cpu(), gr.grad) < tol * 5 and rel_err(bg.grad.cpu(), br.grad) < tol * 5
