@@ -356,34 +356,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   const int ncol = n0 + yv * VEC;
   const bool n_ok = ncol < a.Cd;
 
-  uint4 rx[X_IT], ry[Y_IT];
-  auto load_tiles = [&](int mb) {
+  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+  // branch-free loads of the pixel block starting at mb (rows >= m_end, padding taps and tail columns read as zeros)
+  auto issue = [&](uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT], int mb) {
 #pragma unroll
     for (int i = 0; i < X_IT; ++i) {
       const int m = mb + xrow + i * X_RPP;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (k_ok && m < m_end) {
-        const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
-        const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
-        const uint32_t hd = fdiv(rem, a.fd_w);
-        const uint32_t wd = rem - hd * a.fd_w.d;
-        const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
-        if ((unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws) {
-          size_t off = (size_t)((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc;
-          v = *reinterpret_cast<const uint4*>(x + off);
-        }
-      }
-      rx[i] = v;
+      const uint32_t mm = (uint32_t)min(m, a.M - 1);
+      const uint32_t n_img = fdiv(mm, a.fd_hw);
+      const uint32_t rem = mm - n_img * a.fd_hw.d;
+      const uint32_t hd = fdiv(rem, a.fd_w);
+      const uint32_t wd = rem - hd * a.fd_w.d;
+      const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
+      const bool ok = k_ok && m < m_end && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
+      const unsigned off = (unsigned)(((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc) * (unsigned)sizeof(T);
+      rx[i] = bload16(rs_x, ok ? off : OOB);
     }
 #pragma unroll
     for (int i = 0; i < Y_IT; ++i) {
       const int m = mb + yrow + i * Y_RPP;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (n_ok && m < m_end) v = *reinterpret_cast<const uint4*>(dy + (size_t)m * a.ldy + ncol);
-      ry[i] = v;
+      const unsigned off = (unsigned)(m * a.ldy + ncol) * (unsigned)sizeof(T);
+      ry[i] = bload16(rs_y, (n_ok && m < m_end) ? off : OOB);
     }
   };
-  auto store_tiles = [&](int buf) {
+  auto store_tiles = [&](const uint4 (&rx)[X_IT], const uint4 (&ry)[Y_IT], int buf) {
     T* Yb = Ysm + buf * BP * YS;
     T* Xb = Xsm + buf * BP * XS;
 #pragma unroll
@@ -402,15 +399,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit > 0) {
-    load_tiles(m_begin);
-    store_tiles(0);
-  }
-  __syncthreads();
-  for (int it = 0; it < nit; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < nit) load_tiles(m_begin + (it + 1) * BP);
+  auto compute = [&](int cur) {
     const T* Yb = Ysm + cur * BP * YS;
     const T* Xb = Xsm + cur * BP * XS;
 #pragma unroll
@@ -425,10 +414,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TK; ++j) acc[i][j] = WF::mma(fy[i], fx[j], acc[i][j]);
     }
-    if (it + 1 < nit) store_tiles(cur ^ 1);
+  };
+
+  const int nit = (m_end - m_begin + BP - 1) / BP;
+  if (nit <= 0) return;
+  // two pixel blocks in flight (blocks past m_end are all-OOB loads = zeros)
+  uint4 rx0[X_IT], ry0[Y_IT], rx1[X_IT], ry1[Y_IT];
+  int mb = m_begin;
+  issue(rx0, ry0, mb); mb += BP;
+  issue(rx1, ry1, mb); mb += BP;
+  store_tiles(rx0, ry0, 0);
+  __syncthreads();
+  for (int it = 0;;) {
+    issue(rx0, ry0, mb); mb += BP;
+    compute(0);
+    store_tiles(rx1, ry1, 1);
     __syncthreads();
+    if (++it >= nit) break;
+    issue(rx1, ry1, mb); mb += BP;
+    compute(1);
+    store_tiles(rx0, ry0, 0);
+    __syncthreads();
+    if (++it >= nit) break;
   }
-  if (nit == 0) return;
   // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
   const int l31 = lane & 31, lh = lane >> 5;
 #pragma unroll
@@ -495,6 +503,13 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
     return CSS_ERR_DTYPE;
   }
   if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.dy) & 15)) return CSS_ERR_ARG;
+  {
+    const size_t esz = dtype == CSS_BF16 ? 2 : 4;
+    const size_t xb = (size_t)a.N * a.Hs * a.Ws * a.ldx * esz, yb = (size_t)a.M * a.ldy * esz;
+    if (xb >= 0x7FFFFFF0ull || yb >= 0x7FFFFFF0ull) return CSS_ERR_ARG;   // 32-bit buffer offsets
+    a.x_bytes = (unsigned)xb;
+    a.dy_bytes = (unsigned)yb;
+  }
   const int tiles = cdiv(a.Ktot, bkc) * cdiv(a.Cd, bn);
   // enough splits over the pixel dimension to fill the chip ~4x, but >= 8 iterations each
   int splits = (4 * n_cu + tiles - 1) / tiles;

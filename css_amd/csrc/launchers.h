@@ -25,6 +25,7 @@ struct WgradArgs {
   int R, S, stride, pad, dil;
   int M, Ktot, m_per_split;
   FastDiv fd_hw, fd_w;
+  unsigned x_bytes, dy_bytes;   // filled by the launcher (buffer descriptors)
 };
 
 
