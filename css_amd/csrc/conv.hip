@@ -338,8 +338,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  const int k0 = blockIdx.x * BKC, n0 = blockIdx.y * BN_;
-  const int m_begin = blockIdx.z * a.m_per_split;
+  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; all (k-column, cout) tiles of one pixel slice
+  // are given to ONE XCD so that the slice of dY / X is fetched into a single L2 (measured before: 3.7x over-fetch).
+  const int per_z = a.tiles_k * a.tiles_n;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
+  if (zz >= a.splits) return;
+  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
+  const int m_begin = zz * a.m_per_split;
   const int m_end = min(a.M, m_begin + a.m_per_split);
   const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
@@ -510,17 +516,28 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
     a.x_bytes = (unsigned)xb;
     a.dy_bytes = (unsigned)yb;
   }
+  // Pixel splits: a multiple of 8 (one slice per XCD at a time, see the kernel) chosen so that the tiles an XCD owns
+  // (tiles per slice x slices per XCD) fill its 32 CUs x 2 resident workgroups in whole rounds, with >= 4 iterations each.
   const int tiles = cdiv(a.Ktot, bkc) * cdiv(a.Cd, bn);
-  // enough splits over the pixel dimension to fill the chip ~4x, but >= 8 iterations each
-  int splits = (4 * n_cu + tiles - 1) / tiles;
-  int max_splits = cdiv(a.M, 8 * bp);
-  if (splits > max_splits) splits = max_splits;
-  if (splits < 1) splits = 1;
-  int mps = cdiv(a.M, splits);
-  mps = cdiv(mps, bp) * bp;
+  const int slots = (n_cu / 8) * 2;
+  int best_k = 1;
+  double best_eff = 0;
+  for (int k = 1; k <= 64; ++k) {
+    const int mps_k = cdiv(cdiv(a.M, 8 * k), bp) * bp;
+    if (k > 1 && mps_k < 4 * bp) break;
+    const int txcd = tiles * k;
+    const double eff = (double)txcd / ((double)cdiv(txcd, slots) * slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = k; }
+    if (eff >= 0.93) break;
+  }
+  int splits = 8 * best_k;
+  int mps = cdiv(cdiv(a.M, splits), bp) * bp;
   splits = cdiv(a.M, mps);
   a.m_per_split = mps;
-  dim3 g(cdiv(a.Ktot, bkc), cdiv(a.Cd, bn), splits);
+  a.splits = splits;
+  a.tiles_k = cdiv(a.Ktot, bkc);
+  a.tiles_n = cdiv(a.Cd, bn);
+  dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
   if (dtype == CSS_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
   else

