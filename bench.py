@@ -63,6 +63,24 @@ def cpu_baseline(threads=None):
             "sample": f"1 step of mix_label.train semantics at BASELINE configs[0] (321x321, B=2+2, fp32, tv-R101, Q=256, N=512), {dt:.1f} s"}
 
 
+def pmc_traffic():
+    """HBM bytes per conv_igemm launch from the committed rocprofv3 PMC passes (profiles/*pmc_hbm_traffic.csv: separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction of the guide)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))
+    if not files:
+        return None
+    rd = wr = n = 0.0
+    for r in csv.DictReader(open(files[-1])):
+        if "conv_igemm_kernel" in r["kernel"]:
+            k = float(r["launches"])
+            rd += float(r["read_MB_per_launch_corrected_x2"]) * k
+            wr += float(r["write_MB_per_launch"]) * k
+            n += k
+    return round((rd + wr) / n * 1e6) if n else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +170,7 @@ def main():
                                    f"K=21, Q=256, N=512, mix_mode={a.mix}", "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + dgrad launches)", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12
                          if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": round(ach * 1e12 / (PEAK_BF16 if a.dtype == "bf16" else 157.3e12), 4),
-                         "traffic": None, "launches_per_step": ig_n / a.steps, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
+                         "traffic": pmc_traffic(), "launches_per_step": ig_n / a.steps, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "alg_flops_per_launch": ig_fl / max(ig_n, 1)},
             "kernels": {k: {"ms_per_step": round(v[0] / a.steps, 3), "launches_per_step": v[1] / a.steps,
                             "alg_tflops_or_GBs": round(v[2] / max(v[0] * 1e-3, 1e-12) / (1e12 if k.startswith("conv") else 1e9), 2)}
