@@ -74,6 +74,38 @@ def prepared_weight(weight: torch.Tensor, dtype: torch.dtype, cin_pad: int, dgra
     return out
 
 
+# --------------------------------------------------------------------------
+# direct gradient accumulation (trainer mode)
+# --------------------------------------------------------------------------
+_direct_grads = False
+
+
+class direct_param_grads:
+    """Inside this context the conv / batch-norm backward kernels ADD parameter gradients straight into the existing
+    ``param.grad`` buffers (the trainer's flat gradient buffer) and report ``None`` to autograd: no per-layer zero-fill,
+    no AccumulateGrad add.  Only for callers that own ``param.grad`` (``MixTrainer``); DDP needs the ordinary path."""
+
+    def __enter__(self):
+        global _direct_grads
+        self.prev, _direct_grads = _direct_grads, True
+
+    def __exit__(self, *a):
+        global _direct_grads
+        _direct_grads = self.prev
+
+
+def _grad_sink(param, phys_shape):
+    """param.grad as a contiguous fp32 buffer in the kernel's physical layout, or None if it cannot be used in place."""
+    g = getattr(param, "grad", None)
+    if not _direct_grads or g is None or g.dtype != torch.float32:
+        return None
+    if g.dim() == 4:
+        g = g.permute(0, 2, 3, 1)
+    if not g.is_contiguous() or tuple(g.shape) != tuple(phys_shape):
+        return None
+    return g
+
+
 def conv_out_size(h, k, stride, pad, dil):
     return (h + 2 * pad - dil * (k - 1) - 1) // stride + 1
 
@@ -96,6 +128,7 @@ class _Conv2d(torch.autograd.Function):
         call("css_conv2d_forward", x, wf, bias, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
              dtype_code(dt), dev, st)
         ctx.save_for_backward(x, weight)
+        ctx.bias_ref = bias
         ctx.cfg = (stride, pad, dil, bias is not None, flops)
         return y
 
@@ -123,13 +156,23 @@ class _Conv2d(torch.autograd.Function):
             call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
                  dc, dev, st)
         if ctx.needs_input_grad[1]:
-            dwp = torch.zeros((cout_pad, r, s, cp), dtype=torch.float32, device=dy.device)
-            call("css_conv2d_wgrad", x, dyp, dwp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
-                 dc, dev, st)
-            dw = dwp[:cout, :, :, :cin].permute(0, 3, 1, 2)
+            sink = _grad_sink(weight, (cout, r, s, cin)) if (cout_pad == cout and cp == cin) else None
+            if sink is not None:      # the wgrad kernel accumulates atomically: add straight into param.grad
+                call("css_conv2d_wgrad", x, dyp, sink, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
+                     dc, dev, st)
+            else:
+                dwp = torch.zeros((cout_pad, r, s, cp), dtype=torch.float32, device=dy.device)
+                call("css_conv2d_wgrad", x, dyp, dwp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil,
+                     flops, dc, dev, st)
+                dw = dwp[:cout, :, :, :cin].permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
-            db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
-            call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
+            bias_p = ctx.bias_ref
+            sink = _grad_sink(bias_p, (cout,)) if bias_p is not None else None
+            if sink is not None:
+                call("css_colsum", dy, cout, n * ho * wo, cout, sink, dc, dev, st)
+            else:
+                db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
+                call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
         return dx, dw, db, None, None, None
 
 
@@ -184,6 +227,7 @@ class _BNAct(torch.autograd.Function):
         call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
         if training:
             ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
+        ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         return out
 
@@ -204,10 +248,15 @@ class _BNAct(torch.autograd.Function):
         partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
         call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, mg, g, c, int(relu), partial, dc, dev, st)
         sums = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
-        dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
-        dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
         # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
-        call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, dev, st)
+        sg, sb = _grad_sink(gamma, (c,)), _grad_sink(ctx.beta_ref, (c,))
+        if sg is not None and sb is not None:
+            call("css_bn_reduce", partial, nrb, c, g, sums, sg, sb, 1, dev, st)
+            dgamma = dbeta = None
+        else:
+            dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
+            dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
+            call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, dev, st)
         if sync and _world() > 1:
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)

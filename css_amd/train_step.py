@@ -70,7 +70,8 @@ class MixTrainer:
                                        strong_threshold=self.crit_contrast.strong_threshold)
         con = self.crit_contrast.forward_fused(rep_rows, cls, hard, self.prototypes, self.K, _injected)
         total = sup + unsup + con * ramp
-        total.backward()
+        with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
+            total.backward()
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
         if world > 1:
             dist.all_reduce(self.flat_g)                                     # DDP gradient all-reduce (mean), one bucket
