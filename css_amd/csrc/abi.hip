@@ -96,7 +96,7 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
   ProfScope ps(0, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream));
 }
 int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
@@ -109,7 +109,7 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ProfScope ps(1, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream));
 }
 int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {

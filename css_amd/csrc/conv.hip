@@ -19,6 +19,7 @@
 // through LDS to full 16-byte row-contiguous stores.
 #include "common.h"
 #include "launchers.h"
+#include <cstdlib>
 
 // --------------------------------------------------------------------------
 template <typename T> struct Mma;
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
   const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
   const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
-  const int m0 = (logical / nt_n) * BM, n0 = (logical % nt_n) * BN;
+  const int m0 = a.m_begin + (logical / nt_n) * BM, n0 = (logical % nt_n) * BN;
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, (int)a.src_bytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (int)a.wt_bytes, 0x00020000);
 
@@ -283,6 +284,227 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// bf16 throughput variant: 256x128x64 tile, 8 waves (4x2, 64x64 each), THREE LDS stages filled by LDS-DMA
+// (buffer_load_dwordx4 ... lds: global -> LDS without VGPR staging or ds_write), two K tiles in flight.
+// The ablation of the register-staged kernel above (profiles/r01_conv_ablation.txt) showed global loads and LDS stores
+// each costing ~25 %; this structure removes the stores and halves the weight-tile traffic per FLOP.
+//  * LDS image of a stage: rows of 64 bf16 = 128 B, unpadded (a DMA wave-instruction writes 64 lanes x 16 B = 1 KiB
+//    = 8 whole rows, lane-linear).  16-byte chunk c of row r is stored at position c ^ ((r >> 1) & 7): the swizzle is
+//    applied to the per-lane SOURCE address and again on the ds_read_b128 fragment reads (conflict-free: the 16 lanes of
+//    a read group then hit 16 distinct 16-byte slots of the 256-byte bank row).
+//  * thread t owns chunk position t & 7 of rows (t >> 3) + 64 i: ((r >> 1) & 7) is the same for all of them, so one
+//    running (tap, channel) state per thread serves every DMA it issues.
+//  * sync per K tile: s_waitcnt vmcnt(6) (this wave's share of tile kt has landed, tile kt+1 may be in flight) ->
+//    s_barrier (everyone's share landed, everyone left stage (kt-1)%3) -> issue tile kt+2 into that stage -> MFMAs on kt.
+// --------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
+}
+
+__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
+  using T = bf16_t;
+  constexpr int BM = 256, BN = 128, BK = 64, VEC = 8, NST = 3;
+  constexpr int A_IT = 4, B_IT = 2;                    // DMA wave-instructions per thread per stage (rows t>>3 + 64 i)
+  constexpr int ROWB = BK * 2;                         // 128 bytes per LDS row
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
+  constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2, CSTR = WTN + VEC;
+  static_assert(8 * WTM * CSTR * 2 <= NST * ST_BYTES, "epilogue staging fits");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int nt_n = (a.Cd + BN - 1) / BN;
+  const int ntiles = gridDim.x;
+  const int q8 = ntiles >> 3, r8 = ntiles & 7;
+  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
+  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
+  const int m0 = a.m_begin + (logical / nt_n) * BM, n0 = (logical % nt_n) * BN;
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, (int)a.src_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (int)a.wt_bytes, 0x00020000);
+
+  const int prow = tid >> 3;                                   // tile row of this thread's chunks (+ 64 i)
+  const int cch = (tid & 7) ^ ((tid >> 4) & 7);                // source chunk (8 channels) this thread fetches: p ^ ((r>>1)&7)
+
+  int a_base[A_IT], a_h[A_IT], a_w[A_IT];
+#pragma unroll
+  for (int i = 0; i < A_IT; ++i) {
+    const int m = m0 + prow + i * 64;
+    if (m < a.M) {
+      const int hw = a.Hd * a.Wd;
+      const int n_img = m / hw;
+      const int rem = m - n_img * hw;
+      const int hd = rem / a.Wd;
+      const int wd = rem - hd * a.Wd;
+      a_base[i] = n_img * a.Hs * a.Ws;
+      if (a.mode == 0) {
+        a_h[i] = hd * a.stride - a.pad;
+        a_w[i] = wd * a.stride - a.pad;
+      } else {
+        a_h[i] = hd + a.pad;
+        a_w[i] = wd + a.pad;
+      }
+    } else {
+      a_base[i] = 0;
+      a_h[i] = -0x40000000;
+      a_w[i] = -0x40000000;
+    }
+  }
+  unsigned b_off[B_IT];
+#pragma unroll
+  for (int i = 0; i < B_IT; ++i) {
+    const int n = n0 + prow + i * 64;
+    b_off[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u : OOB;
+  }
+  int kc = cch * VEC, tr = 0, ts = 0;
+  while (kc >= a.Cs) {
+    kc -= a.Cs;
+    if (++ts == a.S) { ts = 0; ++tr; }
+  }
+  int kglob = cch * VEC;
+
+  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*512 + w*64, +64) of the stage image
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
+    unsigned char* sb = sa + A_BYTES;
+    const bool tap_ok = tr < a.R;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+      int hs, ws;
+      bool ok = tap_ok;
+      if (a.mode == 0) {
+        hs = a_h[i] + tr * a.dil;
+        ws = a_w[i] + ts * a.dil;
+      } else {
+        const int th = a_h[i] - tr * a.dil, tw = a_w[i] - ts * a.dil;
+        ok = ok && th >= 0 && tw >= 0;
+        if (a.stride == 2) {
+          ok = ok && !((th | tw) & 1);
+          hs = th >> 1;
+          ws = tw >> 1;
+        } else {
+          hs = th;
+          ws = tw;
+        }
+      }
+      ok = ok && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
+      const unsigned off = (unsigned)((a_base[i] + hs * a.Ws + ws) * a.lds + kc) * 2u;
+      dma16(rs_a, sa + i * 8192, ok ? off : OOB);
+    }
+    const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * 2u : OOB;
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * 8192, (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
+    kglob += BK;
+    kc += BK;
+    while (kc >= a.Cs) {
+      kc -= a.Cs;
+      if (++ts == a.S) { ts = 0; ++tr; }
+    }
+  };
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int l31 = lane & 31, lh = lane >> 5;
+  const int xr = (l31 >> 1) & 7;
+  int koff[4];                                         // swizzled byte offset of k-step ks inside a row
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = (((2 * ks + lh) ^ xr) << 4);
+  const int a_row = (wm * WTM + l31) * ROWB, b_row = A_BYTES + (wn * WTN + l31) * ROWB;
+  auto compute = [&](int stage) {
+    const unsigned char* sbase = smem + stage * ST_BYTES;
+    // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets, statically indexed)
+    bf16x8 fw[2][TN], fa[2][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) fw[0][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + i * 32 * ROWB + koff[0]);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) fa[0][j] = *reinterpret_cast<const bf16x8*>(sbase + a_row + j * 32 * ROWB + koff[0]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      if (ks < 3) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+          fw[(ks + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + i * 32 * ROWB + koff[ks + 1]);
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          fa[(ks + 1) & 1][j] = *reinterpret_cast<const bf16x8*>(sbase + a_row + j * 32 * ROWB + koff[ks + 1]);
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks & 1][i], fa[ks & 1][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  const int nk = (a.Ktot + BK - 1) / BK;
+  issue(0);
+  issue(1);
+  int st_c = 0, st_i = 2;
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(st_i);                       // tile kt+2 (past the end: all-OOB = zeros into a free stage)
+    compute(st_c);
+    st_c = st_c == 2 ? 0 : st_c + 1;
+    st_i = st_i == 2 ? 0 : st_i + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must land before the stages are reused below
+  __builtin_amdgcn_s_barrier();
+
+  // ---- epilogue (as in conv_igemm_kernel): accumulators -> wave-private LDS -> 16-byte row stores
+  T* Cw = reinterpret_cast<T*>(smem) + wave * (WTM * CSTR);
+#pragma unroll
+  for (int i = 0; i < TN; ++i) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int nl = i * 32 + 8 * q + 4 * lh;
+      float bv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (a.bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int n = n0 + wn * WTN + nl + e;
+          bv[e] = n < a.Cd ? a.bias[n] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TM; ++j) {
+        T* p = Cw + (j * 32 + l31) * CSTR + nl;
+        union { T e[4]; uint2 u2; } pk;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) pk.e[e] = (T)(acc[i][j][4 * q + e] + bv[e]);
+        *reinterpret_cast<uint2*>(p) = pk.u2;
+      }
+    }
+  }
+  __syncthreads();
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  constexpr int CV = WTN / VEC;
+  const bool vec_ok = (a.ldd % VEC) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
+#pragma unroll 4
+  for (int idx = lane; idx < WTM * CV; idx += 64) {
+    const int row = idx / CV, cv = idx - row * CV;
+    const int m = m0 + wm * WTM + row;
+    const int n = n0 + wn * WTN + cv * VEC;
+    if (m >= a.M || n >= a.Cd) continue;
+    const T* p = Cw + row * CSTR + cv * VEC;
+    T* o = dst + (size_t)m * a.ldd + n;
+    if (vec_ok && n + VEC <= a.Cd) {
+      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p);
+    } else {
+      for (int e = 0; e < VEC && n + e < a.Cd; ++e) o[e] = p[e];
+    }
+  }
+}
+
+// --------------------------------------------------------------------------
 // Weight gradient: dW[n][k] += sum_m dY[m][n] * X(m, k)     (k = (r, s, c))
 // Both operands are contiguous along the NON-reduced index in memory, so the bf16 path
 // keeps the tiles as loaded ([pixel][channel]) and reads MFMA fragments with the gfx950
@@ -462,8 +684,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 // --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
-int css_launch_conv(const ConvArgs& a_in, int dtype, hipStream_t st) {
+int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
   ConvArgs a = a_in;
+  a.m_begin = 0;
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
   {
     const size_t esz = dtype == CSS_BF16 ? 2 : 4;
@@ -475,7 +698,27 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, hipStream_t st) {
   if (dtype == CSS_BF16) {
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
-    if (a.Cd > 64) {
+    if (a.Cd > 64 && !getenv("CSS_NO_DMA_CONV")) {
+      // Big tiles (256x128, one workgroup per CU) only for whole rounds of the chip; the leftover rows go to the 128x128
+      // kernel (4x as many, smaller tiles, two per CU) instead of paying a full extra round for a fraction of one.
+      const int nt_n = cdiv(a.Cd, 128), mt = cdiv(a.M, 256);
+      const int slots = n_cu;
+      int full_mt = mt;
+      const double rounds = (double)mt * nt_n / slots;
+      if (rounds > 1.0 && rounds - (long)rounds < 0.6 && (rounds - (long)rounds) > 1e-9) {
+        full_mt = (int)((long)rounds * slots / nt_n);      // m-tiles covered by whole rounds
+      }
+      if (full_mt > 0) {
+        ConvArgs b = a;
+        b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
+        hipLaunchKernelGGL(conv_igemm_dma_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+      }
+      if (full_mt < mt) {
+        ConvArgs b = a;
+        b.m_begin = full_mt * 256;
+        hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * nt_n), dim3(256), 0, st, b);
+      }
+    } else if (a.Cd > 64) {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 128));
       hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, a);
     } else {

@@ -14,6 +14,7 @@ struct ConvArgs {
              // 1: dgrad gather    hs = (hd + pad - r*dil) / stride   (must divide)
   int M, Ktot;
   unsigned src_bytes, wt_bytes;   // filled by the launcher (buffer descriptors)
+  int m_begin;                    // first output row handled by this launch (rows m_begin .. M-1)
 };
 
 struct WgradArgs {
@@ -30,7 +31,7 @@ struct WgradArgs {
 };
 
 
-int css_launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
+int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st);
 
 int css_bn_nrb_(int Mg, int G, int C, int dtype);

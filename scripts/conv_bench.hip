@@ -6,14 +6,14 @@
 struct Shape { const char* name; int N, H, W, Cin, Cout, R, stride, pad, dil; };
 int main() {
   std::vector<Shape> shapes = {
-      {"l3 3x3 d2 256->256", 16, 65, 65, 256, 256, 3, 1, 2, 2},
-      {"l3 1x1 1024->256", 16, 65, 65, 1024, 256, 1, 1, 0, 1},
-      {"l3 1x1 256->1024", 16, 65, 65, 256, 1024, 1, 1, 0, 1},
-      {"l4 3x3 d4 512->512", 16, 65, 65, 512, 512, 3, 1, 4, 4},
-      {"l4 1x1 512->2048", 16, 65, 65, 512, 2048, 1, 1, 0, 1},
-      {"aspp 3x3 d12 2048->256", 16, 65, 65, 2048, 256, 3, 1, 12, 12},
-      {"head 3x3 304->256", 16, 129, 129, 304, 256, 3, 1, 1, 1},
-      {"l1 1x1 64->256", 16, 129, 129, 64, 256, 1, 1, 0, 1},
+      {"l3 3x3 d2 256->256", 32, 65, 65, 256, 256, 3, 1, 2, 2},
+      {"l3 1x1 1024->256", 32, 65, 65, 1024, 256, 1, 1, 0, 1},
+      {"l3 1x1 256->1024", 32, 65, 65, 256, 1024, 1, 1, 0, 1},
+      {"l4 3x3 d4 512->512", 32, 65, 65, 512, 512, 3, 1, 4, 4},
+      {"l4 1x1 512->2048", 32, 65, 65, 512, 2048, 1, 1, 0, 1},
+      {"aspp 3x3 d12 2048->256", 32, 65, 65, 2048, 256, 3, 1, 12, 12},
+      {"head 3x3 304->256", 32, 129, 129, 304, 256, 3, 1, 1, 1},
+      {"l1 1x1 64->256", 32, 129, 129, 64, 256, 1, 1, 0, 1},
   };
   for (auto& s : shapes) {
     const int Ho = (s.H + 2 * s.pad - s.dil * (s.R - 1) - 1) / s.stride + 1, Wo = Ho;
@@ -40,11 +40,11 @@ int main() {
     hipEventCreate(&e0); hipEventCreate(&e1);
     const double flops = 2.0 * a.M * s.Cout * a.Ktot;
     for (int which = 0; which < 2; ++which) {
-      for (int i = 0; i < 3; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 0);
+      for (int i = 0; i < 3; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 256, 0);
       hipDeviceSynchronize();
       const int reps = 20;
       hipEventRecord(e0, 0);
-      for (int i = 0; i < reps; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 0);
+      for (int i = 0; i < reps; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 256, 0);
       hipEventRecord(e1, 0);
       hipEventSynchronize(e1);
       float ms;

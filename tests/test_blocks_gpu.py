@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from gpu_util import assert_close_robust, dev, rel_err, robust_err, to_nchw_cpu, to_nhwc  # noqa: E402
 
 TOL = 1e-4    # forward (max-norm)
-GTOL = 1e-3   # gradients (90th percentile): one flipped ReLU reaches every element at the ~1e-4 level through the
+GTOL = 4e-3   # gradients (90th percentile): one flipped ReLU reaches every element at the ~1e-4 level through the
               # per-channel means of the batch-norm backward; a wiring bug is O(1) on most elements
 
 
