@@ -90,6 +90,9 @@ def main():
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mix", default="cutmix")
+    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
+                    help="c2: VOC-shaped 513^2 tv-R101 B=16 (default, the headline metric); c4: Cityscapes-shaped 769^2 deep-stem R101 "
+                         "K=19 OHEM B=8; c5: c4 with Q=1024, N=2048")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -109,9 +112,15 @@ def main():
     from css_amd.train_step import MixTrainer
 
     K, S, B = 21, a.size, a.batch
+    backbone, sup, Q, N = "tv", "ce", 256, 512
+    if a.workload in ("c4", "c5"):
+        K, S, B, backbone, sup = 19, 769, 8, "stem", "ohem"
+        if a.workload == "c5":
+            Q, N = 1024, 2048
     torch.manual_seed(3407)
     cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": a.mix}}
-    model = Model_mix(resnet.resnet101_tv(zero_init_residual=False), num_classes=K, output_dim=256, config=cfg, temp=0.5)
+    bb = resnet.resnet101_tv(zero_init_residual=False) if backbone == "tv" else resnet.resnet101(zero_init_residual=False)
+    model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
     # seeded non-degenerate weights: Kaiming convs (constructor), BN gamma~U(.5,1.5), beta~N(0,.1)
     g = torch.Generator().manual_seed(3407)
     with torch.no_grad():
@@ -124,8 +133,8 @@ def main():
                 mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
         model.ema_model.load_state_dict(model.model.state_dict())
     model = model.to(dev).train().set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
-    tr = MixTrainer(model, K, lr=6.4e-3, total_iter=80000, num_queries=256, num_negatives=512, strong_threshold=0.8, weak_threshold=0.7,
-                    un_threshold=0.97)
+    tr = MixTrainer(model, K, lr=6.4e-3, total_iter=80000, num_queries=Q, num_negatives=N, strong_threshold=0.8, weak_threshold=0.7,
+                    un_threshold=0.97, sup=sup, ohem_min_kept=50000 * B)
     l_img, l_lab, u_img = synth_batch(B, S, K, 3407 + rank, dev)
 
     def sync():
@@ -166,8 +175,11 @@ def main():
             "value": round(2 * B * world * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: VOC-shaped mix_label step, tv-ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, "
-                                   f"K=21, Q=256, N=512, mix_mode={a.mix}", "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
+            "config": {"workload": (f"BASELINE configs[1]: VOC-shaped mix_label step, tv-ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, "
+                                    f"K={K}, Q={Q}, N={N}, mix_mode={a.mix}") if a.workload == "c2" else
+                                   (f"BASELINE configs[{3 if a.workload == 'c4' else 4}] shape on {world} GPU(s): Cityscapes-shaped mix_label step, deep-stem "
+                                    f"ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, OHEM, Q={Q}, N={N}, mix_mode={a.mix}"),
+                       "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + dgrad launches)", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12
                          if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": round(ach * 1e12 / (PEAK_BF16 if a.dtype == "bf16" else 157.3e12), 4),
                          "traffic": pmc_traffic(), "launches_per_step": ig_n / a.steps, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
@@ -175,7 +187,8 @@ def main():
             "kernels": {k: {"ms_per_step": round(v[0] / a.steps, 3), "launches_per_step": v[1] / a.steps,
                             "alg_tflops_or_GBs": round(v[2] / max(v[0] * 1e-3, 1e-12) / (1e12 if k.startswith("conv") else 1e9), 2)}
                         for k, v in prof.items()},
-            "step_alg_tflops": round(8 * B * FWD_FLOP_513_TV * (S / 513.0) ** 2 / (dt / a.steps) / 1e12, 2),
+            "step_alg_tflops": round(8 * B * (FWD_FLOP_513_TV * (S / 513.0) ** 2 if backbone == "tv" else 1239.1e9 * (S / 769.0) ** 2)
+                                     / (dt / a.steps) / 1e12, 2),
             "losses": {k: round(v, 4) for k, v in losses.items()},
         }
         if world == 1 and not a.no_cpu_baseline:

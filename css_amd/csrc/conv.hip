@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 // --------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
+#ifdef CSS_DMA_NOLOAD
+  asm volatile("" ::"v"(off));
+#else
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
+#endif
 }
 
 __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
@@ -452,7 +456,9 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     issue(st_i);                       // tile kt+2 (past the end: all-OOB = zeros into a free stage)
+#ifndef CSS_DMA_NOCOMPUTE
     compute(st_c);
+#endif
     st_c = st_c == 2 ? 0 : st_c + 1;
     st_i = st_i == 2 ? 0 : st_i + 1;
   }

