@@ -161,17 +161,18 @@ int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, in
   set_dev(device);
   return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, dtype, S(stream));
 }
-int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd, int Mg,
-                      int G, int C, int relu, double* partial, int dtype, int device, css_stream_t stream) {
+int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
+                      const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, int device,
+                      css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, dtype, S(stream));
+  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, dtype, S(stream));
 }
 int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                     const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C, int relu, int Mg,
-                     int dtype, int device, css_stream_t stream) {
+                     const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
+                     double count, int M, int C, int relu, int Mg, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, dtype,
-                                 S(stream));
+  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg,
+                                 dtype, S(stream));
 }
 
 // ---- pooling / resize / concat ----

@@ -181,22 +181,32 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
   shift_out[c] = beta[c] - running_mean[c] * sc;
 }
 
+// Elementwise BN kernels: thread t owns channel vector (blockIdx.y*TPC + t % TPC) for all of its rows, so the per-channel
+// coefficients are loaded ONCE into registers (they used to be re-loaded for every element and made these kernels
+// instruction-bound).  grid = (row blocks, channel blocks, groups).
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
                                                        T* __restrict__ out, int ldo, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int M, int C, int relu, int Mg) {
+                                                       const float* __restrict__ shift, int Mg, int C, int relu, int rows_per_block) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
-  const size_t total = (size_t)M * CV;
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
-    const int go = (r >= Mg ? (r / Mg) : 0) * C;     // statistics group of this row
+  const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
+  const int cvi = threadIdx.x % TPC, rg = threadIdx.x / TPC;
+  const int cv = blockIdx.y * TPC + cvi;
+  if (rg >= RPB || cv >= CV) return;
+  const int c = cv * VEC, g = blockIdx.z;
+  float sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) { sc[e] = scale[g * C + c + e]; sh[e] = shift[g * C + c + e]; }
+  const int gbase = g * Mg;
+  const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
+  for (int r = row0 + rg; r < row1; r += RPB) {
     Vec16<T> v, o, rr;
     v.load(y + (size_t)r * ldy + c);
     if (res) rr.load(res + (size_t)r * ldr + c);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float x = v.f(e) * scale[go + c + e] + shift[go + c + e];
+      float x = v.f(e) * sc[e] + sh[e];
       if (res) x += rr.f(e);
       if (relu) x = fmaxf(x, 0.f);
       o.set(e, x);
@@ -209,20 +219,33 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a,
                                                             int lda, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int Mg, int C, int relu, int rows_per_block, double* partial) {
   constexpr int VEC = 16 / sizeof(T);
-  mean += blockIdx.z * C;
-  invstd += blockIdx.z * C;
+  const int CV = C / VEC;
+  const int TPC = CV < 256 ? CV : 256;
+  const int cv = min(blockIdx.y * TPC + (int)(threadIdx.x % TPC), CV - 1);   // this thread's channel vector (as in channel_reduce2)
+  const int g = blockIdx.z, c0 = cv * VEC;
+  float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    mu[e] = mean[g * C + c0 + e];
+    is[e] = invstd[g * C + c0 + e];
+    sc[e] = (relu && !a) ? scale[g * C + c0 + e] : 0.f;
+    sh[e] = (relu && !a) ? shift[g * C + c0 + e] : 0.f;
+  }
   auto f = [&](int r, int c, float* s0, float* s1) {
-    Vec16<T> g, av, yv;
-    g.load(da + (size_t)r * ldda + c);
+    Vec16<T> gv, av, yv;
+    gv.load(da + (size_t)r * ldda + c);
     yv.load(y + (size_t)r * ldy + c);
-    if (relu) av.load(a + (size_t)r * lda + c);
+    if (relu && a) av.load(a + (size_t)r * lda + c);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float dz = g.f(e);
-      if (relu && !(av.f(e) > 0.f)) dz = 0.f;
-      float xh = (yv.f(e) - mean[c + e]) * invstd[c + e];
+      float dz = gv.f(e);
+      // ReLU mask: from the saved activation, or (layers without a residual) recomputed exactly as the forward did
+      const float act = a ? av.f(e) : yv.f(e) * sc[e] + sh[e];
+      if (relu && !(act > 0.f)) dz = 0.f;
+      const float xh = (yv.f(e) - mu[e]) * is[e];
       s0[e] += dz;
       s1[e] += dz * xh;
     }
@@ -235,31 +258,42 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const T* __restrict__ y, int ldy, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dres, int lddr, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ sum_dz, const double* __restrict__ sum_dzx,
-                                                           double count, int M, int C, int relu, int Mg) {
+                                                           const double* __restrict__ sums, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, double count, int Mg, int C, int relu,
+                                                           int rows_per_block) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
-  const size_t total = (size_t)M * CV;
+  const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
+  const int cvi = threadIdx.x % TPC, rg = threadIdx.x / TPC;
+  const int cv = blockIdx.y * TPC + cvi;
+  if (rg >= RPB || cv >= CV) return;
+  const int c = cv * VEC, g = blockIdx.z;
   const float inv_n = (float)(1.0 / count);
-  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-    const int r = (int)(idx / CV), c = (int)(idx - (size_t)r * CV) * VEC;
-    const int gi = r >= Mg ? (r / Mg) : 0;
-    const float* mean_g = mean + gi * C;
-    const float* invstd_g = invstd + gi * C;
-    const double* sum_dz_g = sum_dz + (size_t)gi * 2 * C;      // sums are [G][2][C]
-    const double* sum_dzx_g = sum_dz_g + C;
-    Vec16<T> g, av, yv, o, dr;
-    g.load(da + (size_t)r * ldda + c);
+  float mu[VEC], is[VEC], gi[VEC], m1[VEC], m2[VEC], sc[VEC], sh[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) {
+    mu[e] = mean[g * C + c + e];
+    is[e] = invstd[g * C + c + e];
+    gi[e] = gamma[c + e] * is[e];
+    m1[e] = (float)sums[(size_t)g * 2 * C + c + e] * inv_n;          // sums are [G][2][C]
+    m2[e] = (float)sums[(size_t)g * 2 * C + C + c + e] * inv_n;
+    sc[e] = (relu && !a) ? scale[g * C + c + e] : 0.f;
+    sh[e] = (relu && !a) ? shift[g * C + c + e] : 0.f;
+  }
+  const int gbase = g * Mg;
+  const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
+  for (int r = row0 + rg; r < row1; r += RPB) {
+    Vec16<T> gv, av, yv, o, dr;
+    gv.load(da + (size_t)r * ldda + c);
     yv.load(y + (size_t)r * ldy + c);
-    if (relu) av.load(a + (size_t)r * lda + c);
+    if (relu && a) av.load(a + (size_t)r * lda + c);
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
-      float dz = g.f(e);
-      if (relu && !(av.f(e) > 0.f)) dz = 0.f;
-      const float is = invstd_g[c + e];
-      const float xh = (yv.f(e) - mean_g[c + e]) * is;
-      const float m1 = (float)sum_dz_g[c + e] * inv_n, m2 = (float)sum_dzx_g[c + e] * inv_n;
-      o.set(e, gamma[c + e] * is * (dz - m1 - xh * m2));
+      float dz = gv.f(e);
+      const float act = a ? av.f(e) : yv.f(e) * sc[e] + sh[e];
+      if (relu && !(act > 0.f)) dz = 0.f;
+      const float xh = (yv.f(e) - mu[e]) * is[e];
+      o.set(e, gi[e] * (dz - m1[e] - xh * m2[e]));
       dr.set(e, dz);
     }
     o.store(dy + (size_t)r * lddy + c);
@@ -338,13 +372,28 @@ static inline int ew_grid(size_t total) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
+// rows per block for the elementwise kernels: ~2048 blocks in total, >= 8 rows per thread
+static inline int pick_rows_ew(int Mg, int G, int C, int vec) {
+  const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
+  const int ybl = (CV + TPC - 1) / TPC;
+  long want = 2048 / ((long)ybl * G);
+  if (want < 1) want = 1;
+  int rpb = cdiv(Mg, want);
+  rpb = cdiv(rpb, RPB) * RPB;
+  if (rpb < 8 * RPB) rpb = 8 * RPB;
+  return rpb;
+}
+
 template <typename T>
 static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
                       const float* shift, int M, int C, int relu, int Mg, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
-  hipLaunchKernelGGL(bn_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)y, ldy,
-                     (const T*)res, ldr, (T*)out, ldo, scale, shift, M, C, relu, Mg);
+  const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
+  const int rpb = pick_rows_ew(Mg, G, C, VEC);
+  dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
+  hipLaunchKernelGGL(bn_apply_kernel<T>, g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, Mg, C,
+                     relu, rpb);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
@@ -358,45 +407,51 @@ int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* 
 
 template <typename T>
 static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                           const float* invstd, int Mg, int G, int C, int relu, double* partial, hipStream_t st) {
+                           const float* invstd, const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial,
+                           hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
-  if (C % VEC || ldda % VEC || ldy % VEC || (relu && lda % VEC)) return CSS_ERR_ARG;
+  if (C % VEC || ldda % VEC || ldy % VEC || (relu && a && lda % VEC) || (relu && !a && (!scale || !shift))) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
   const int rpb = pick_rows_per_block(Mg, G, C, VEC);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean,
-                     invstd, Mg, C, relu, rpb, partial);
+                     invstd, scale, shift, Mg, C, relu, rpb, partial);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
-                             const float* invstd, int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st) {
+                             const float* invstd, const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial,
+                             int dtype, hipStream_t st) {
   if (Mg <= 0 || G <= 0) return CSS_ERR_ARG;
-  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, st)
-         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, Mg, G, C, relu, partial, st)
+  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, st)
+         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, st)
                             : CSS_ERR_DTYPE;
 }
 
 template <typename T>
 static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                           void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                          double count, int M, int C, int relu, int Mg, hipStream_t st) {
+                          const float* scale, const float* shift, double count, int M, int C, int relu, int Mg, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
-  if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && lda % VEC) || (dres && lddr % VEC)) return CSS_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, dim3(ew_grid((size_t)M * (C / VEC))), dim3(256), 0, st, (const T*)da, ldda,
-                     (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, (T*)dres, lddr, mean, invstd, gamma, sums, sums, count, M, C,
-                     relu, Mg);
+  if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && a && lda % VEC) || (dres && lddr % VEC) ||
+      (relu && !a && (!scale || !shift)))
+    return CSS_ERR_ARG;
+  const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
+  const int rpb = pick_rows_ew(Mg, G, C, VEC);
+  dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy,
+                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, Mg, C, relu, rpb);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                             void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                            double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
+                            const float* scale, const float* shift, double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
   if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
   return dtype == CSS_BF16
-             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg, st)
          : dtype == CSS_F32
-             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, count, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg, st)
              : CSS_ERR_DTYPE;
 }

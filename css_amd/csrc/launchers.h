@@ -48,10 +48,10 @@ int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float*
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
                         int relu, int Mg, int dtype, hipStream_t st);
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
-                             int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st);
+                             const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st);
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                            const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C, int relu,
-                            int Mg, int dtype, hipStream_t st);
+                            const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
+                            double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st);
 
 int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
                            int dtype, hipStream_t st);

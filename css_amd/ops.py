@@ -226,7 +226,8 @@ class _BNAct(torch.autograd.Function):
         out = torch.empty_like(y)
         call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
         if training:
-            ctx.save_for_backward(y, out if relu else None, mean, invstd, gamma)
+            # ReLU mask in backward: from `out` when a residual was added, else recomputed from y*scale+shift (one read less)
+            ctx.save_for_backward(y, out if (relu and res is not None) else None, mean, invstd, gamma, scale, shift)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         return out
@@ -236,7 +237,7 @@ class _BNAct(torch.autograd.Function):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
             raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
-        y, a, mean, invstd, gamma = ctx.saved_tensors
+        y, a, mean, invstd, gamma, scale, shift = ctx.saved_tensors
         c = y.shape[-1]
         m = y.numel() // c
         mg = m // g
@@ -246,7 +247,7 @@ class _BNAct(torch.autograd.Function):
         dc = dtype_code(dt)
         nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
         partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
-        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, mg, g, c, int(relu), partial, dc, dev, st)
+        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, scale, shift, mg, g, c, int(relu), partial, dc, dev, st)
         sums = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
         # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
         sg, sb = _grad_sink(gamma, (c,)), _grad_sink(ctx.beta_ref, (c,))
@@ -261,8 +262,8 @@ class _BNAct(torch.autograd.Function):
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, m, c, int(relu), mg,
-             dc, dev, st)
+        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, m, c,
+             int(relu), mg, dc, dev, st)
         return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 

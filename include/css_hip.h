@@ -73,11 +73,14 @@ CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float
                               float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
                          int relu, int Mg, int dtype, int device, css_stream_t stream);
+/* backward: `a` (the saved activation, for the ReLU mask) may be NULL for layers without a residual: the mask is then
+ * recomputed as y*scale+shift > 0 from the forward's scale/shift ([G][C]), saving one full read of the layer tensor */
 CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
-                              int Mg, int G, int C, int relu, double* partial, int dtype, int device, css_stream_t stream);
+                              const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, int device,
+                              css_stream_t stream);
 CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
-                             const float* mean, const float* invstd, const float* gamma, const double* sums, double count, int M, int C,
-                             int relu, int Mg, int dtype, int device, css_stream_t stream);
+                             const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale,
+                             const float* shift, double count, int M, int C, int relu, int Mg, int dtype, int device, css_stream_t stream);
 
 /* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
 CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
