@@ -73,7 +73,7 @@ def pmc_traffic():
         return None
     rd = wr = n = 0.0
     for r in csv.DictReader(open(files[-1])):
-        if "conv_igemm_kernel" in r["kernel"]:
+        if "conv_igemm" in r["kernel"]:
             k = float(r["launches"])
             rd += float(r["read_MB_per_launch_corrected_x2"]) * k
             wr += float(r["write_MB_per_launch"]) * k
@@ -180,7 +180,7 @@ def main():
                                    (f"BASELINE configs[{3 if a.workload == 'c4' else 4}] shape on {world} GPU(s): Cityscapes-shaped mix_label step, deep-stem "
                                     f"ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, OHEM, Q={Q}, N={N}, mix_mode={a.mix}"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (forward + dgrad launches)", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_dma_kernel + conv_igemm_kernel (all forward + dgrad launches)", "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12
                          if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s", "frac": round(ach * 1e12 / (PEAK_BF16 if a.dtype == "bf16" else 157.3e12), 4),
                          "traffic": pmc_traffic(), "launches_per_step": ig_n / a.steps, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
                          "alg_flops_per_launch": ig_fl / max(ig_n, 1)},

@@ -367,10 +367,10 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
   }
   int kglob = cch * VEC;
 
-  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*512 + w*64, +64) of the stage image
-  auto issue = [&](int stage) {
-    unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
-    unsigned char* sb = sa + A_BYTES;
+  // Byte offsets of this thread's A rows for the CURRENT tap and channel position; within a tap they simply advance by
+  // BK*2 bytes per K tile, so the (expensive) coordinate / bounds arithmetic runs only when the tap changes.
+  unsigned offA[A_IT];
+  auto tap_offsets = [&]() {
     const bool tap_ok = tr < a.R;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -393,16 +393,30 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
       }
       ok = ok && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
       const unsigned off = (unsigned)((a_base[i] + hs * a.Ws + ws) * a.lds + kc) * 2u;
-      dma16(rs_a, sa + i * 8192, ok ? off : OOB);
+      offA[i] = ok ? off : OOB;
     }
+  };
+  tap_offsets();
+  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*512 + w*64, +64) of the stage image
+  auto issue = [&](int stage) {
+    unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
+    unsigned char* sb = sa + A_BYTES;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * 8192, offA[i]);
     const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * 2u : OOB;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * 8192, (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
     kglob += BK;
     kc += BK;
-    while (kc >= a.Cs) {
-      kc -= a.Cs;
-      if (++ts == a.S) { ts = 0; ++tr; }
+    if (kc >= a.Cs) {          // next tap (uniform across the block whenever Cs is a multiple of BK)
+      do {
+        kc -= a.Cs;
+        if (++ts == a.S) { ts = 0; ++tr; }
+      } while (kc >= a.Cs);
+      tap_offsets();
+    } else {
+#pragma unroll
+      for (int i = 0; i < A_IT; ++i) offA[i] += (offA[i] & OOB) ? 0u : (unsigned)(BK * 2);
     }
   };
 

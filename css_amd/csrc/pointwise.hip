@@ -180,16 +180,49 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const TI* __restrict_
 template <typename T>
 __global__ __launch_bounds__(256) void spatial_sum_kernel(const T* __restrict__ x, int ldx, T* __restrict__ out, int HW, int C,
                                                           float scale) {
+  // block = 8 channel-vectors (16 B each) x 32 pixel partitions; 4 independent loads in flight per thread
+  constexpr int VEC = 16 / sizeof(T);
   const int n = blockIdx.y;
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int part = threadIdx.x >> 6;  // 4 row partitions
-  float acc = 0.f;
-  if (c < C)
-    for (int p = part; p < HW; p += 4) acc += (float)x[((size_t)n * HW + p) * ldx + c];
-  __shared__ float red[4][64];
-  red[part][threadIdx.x & 63] = acc;
+  const int cv = blockIdx.x * 8 + (threadIdx.x & 7);
+  const int part = threadIdx.x >> 3;
+  const int c = cv * VEC;
+  float acc[4][VEC];
+#pragma unroll
+  for (int u = 0; u < 4; ++u)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[u][e] = 0.f;
+  if (c < C) {
+    const T* base = x + (size_t)n * HW * ldx + c;
+    int p = part;
+    for (; p + 96 < HW; p += 128) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        Vec16<T> v;
+        v.load(base + (size_t)(p + 32 * u) * ldx);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[u][e] += v.f(e);
+      }
+    }
+    for (; p < HW; p += 32) {
+      Vec16<T> v;
+      v.load(base + (size_t)p * ldx);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[0][e] += v.f(e);
+    }
+  }
+  __shared__ float red[32][8 * VEC + 1];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[part][(threadIdx.x & 7) * VEC + e] = (acc[0][e] + acc[1][e]) + (acc[2][e] + acc[3][e]);
   __syncthreads();
-  if (part == 0 && c < C) out[(size_t)n * C + c] = (T)((red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]) * scale);
+  if (threadIdx.x < 8 * VEC) {
+    const int cc = blockIdx.x * 8 * VEC + threadIdx.x;
+    if (cc < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 32; ++q) t += red[q][threadIdx.x];
+      out[(size_t)n * C + cc] = (T)(t * scale);
+    }
+  }
 }
 // out[n][hw][c] = scale * x[n][c]
 template <typename T>
@@ -395,7 +428,9 @@ int css_launch_bilinear(const void* x, int ldx, void* out, int ldo, int N, int H
 
 int css_launch_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, hipStream_t st) {
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(spatial_sum_kernel<T>, dim3(cdiv(C, 64), N), dim3(256), 0, st, (const T*)x, ldx, (T*)out, HW, C, scale);
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC || ldx % VEC) return CSS_ERR_ARG;
+    hipLaunchKernelGGL(spatial_sum_kernel<T>, dim3(cdiv(C, 8 * VEC), N), dim3(256), 0, st, (const T*)x, ldx, (T*)out, HW, C, scale);
   });
   CSS_CHECK_LAUNCH();
   return CSS_OK;
