@@ -89,7 +89,7 @@ int css_prof_read(int kind, double* total_ms, double* launches, double* alg_work
 int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
                        int ldy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  ConvArgs a;
+  ConvArgs a = {};
   a.src = x; a.wt = w; a.dst = y; a.bias = bias;
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.lds = ldx;
   a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldd = ldy;
@@ -98,15 +98,43 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   ProfScope ps(0, alg_flops, S(stream));
   return css_launch_conv(a, dtype, cu_count(device), S(stream));
 }
+int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
+                               int Cout, int ldy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device,
+                               css_stream_t stream) {
+  set_dev(device);
+  ConvArgs a = {};
+  a.src = x; a.wt = w; a.dst = y; a.bias = nullptr;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.lds = ldx;
+  a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldd = ldy;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
+  a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
+  a.stats = stats; a.stat_Mg = Mg;
+  if (!stats || Mg < 128 || a.M % Mg) return CSS_ERR_ARG;
+  ProfScope ps(0, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+}
 int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   if (stride != 1 && stride != 2) return CSS_ERR_ARG;
-  ConvArgs a;
+  ConvArgs a = {};
   a.src = dy; a.wt = w_t; a.dst = dx; a.bias = nullptr;
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.lds = lddy;
   a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1;
+  a.M = N * H * W; a.Ktot = R * Sk * Cout;
+  ProfScope ps(1, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+}
+int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
+                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  if (stride != 1 && stride != 2) return CSS_ERR_ARG;
+  ConvArgs a = {};
+  a.src = dy; a.wt = w_t; a.dst = dx; a.bias = nullptr;
+  a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.lds = lddy;
+  a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ProfScope ps(1, alg_flops, S(stream));
   return css_launch_conv(a, dtype, cu_count(device), S(stream));
@@ -128,6 +156,12 @@ int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, in
   return css_launch_weight_layout(w, out, Cout, taps, Cin, CinPad, dgrad, dtype, S(stream));
 }
 
+int css_weight_dgrad_layout_batched(const float* flat, void* out, const long* desc, int n_layers, long total_tiles, int dtype, int device,
+                                    css_stream_t stream) {
+  set_dev(device);
+  return css_launch_weight_dgrad_layout_batched(flat, out, desc, n_layers, total_tiles, dtype, S(stream));
+}
+
 // ---- batch norm ----
 int css_bn_nrb(int Mg, int G, int C, int dtype) { return css_bn_nrb_(Mg, G, C, dtype); }
 int css_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, int device, css_stream_t stream) {
@@ -145,6 +179,13 @@ int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, 
   set_dev(device);
   return css_launch_bn_reduce_finalize(partial, nrb, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                                        C, S(stream));
+}
+int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                 float* shift, double* sums_out, int C, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_reduce_slabs(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                                    sums_out, C, S(stream));
 }
 int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device, css_stream_t stream) {

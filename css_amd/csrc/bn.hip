@@ -33,11 +33,13 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
   const int row1 = min(gbase + Mg, row0 + rows_per_block);
   if (active) {
     int r = row0 + rg;
-    for (; r + RPB < row1; r += 2 * RPB) {   // two independent rows in flight
+    for (; r + 3 * RPB < row1; r += 4 * RPB) {   // four independent rows in flight (latency-bound otherwise)
       f(r, cv * VEC, s0, s1);
       f(r + RPB, cv * VEC, s0, s1);
+      f(r + 2 * RPB, cv * VEC, s0, s1);
+      f(r + 3 * RPB, cv * VEC, s0, s1);
     }
-    if (r < row1) f(r, cv * VEC, s0, s1);
+    for (; r < row1; r += RPB) f(r, cv * VEC, s0, s1);
   }
   __shared__ float red[2][256 * VEC];
 #pragma unroll
@@ -141,6 +143,67 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* _
   }
 }
 
+// Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile): partial is fp32
+// [nslab + G][2][C]: one row per 128-row slab of the [G*Mg][C] tensor plus one spill row per group (rows of a slab that
+// lie in the NEXT group than the slab's first row).  Group g = slabs ceil(g*Mg/128) .. ceil((g+1)*Mg/128)-1, plus spill
+// row nslab+g when g*Mg is not a multiple of 128.  block = 1024 threads = 16 channels x 64 row partitions, fp64 sums.
+// sums_out != null: write [G][2][C] sums only (SyncBN: all-reduced before bn_finalize); else finalize in place.
+__global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
+                                                               const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                               float* running_mean, float* running_var, float momentum, float eps,
+                                                               float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
+                                                               double* sums_out, int C) {
+  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  __shared__ double red[2][64][16];
+  for (int g = 0; g < G; ++g) {
+    const long lo = (long)g * Mg, hi = lo + Mg;
+    const int s_lo = (int)((lo + 127) >> 7);
+    int s_hi = (int)((hi + 127) >> 7);
+    if (s_hi > nslab) s_hi = nslab;
+    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
+    if (c < C) {
+      int sb = s_lo + part;
+      for (; sb + 192 < s_hi; sb += 256) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          a0[u] += (double)partial[(size_t)(sb + 64 * u) * 2 * C + c];
+          a1[u] += (double)partial[(size_t)(sb + 64 * u) * 2 * C + C + c];
+        }
+      }
+      for (; sb < s_hi; sb += 64) {
+        a0[0] += (double)partial[(size_t)sb * 2 * C + c];
+        a1[0] += (double)partial[(size_t)sb * 2 * C + C + c];
+      }
+      if (part == 0 && g > 0 && (lo & 127)) {
+        a0[1] += (double)partial[(size_t)(nslab + g) * 2 * C + c];
+        a1[1] += (double)partial[(size_t)(nslab + g) * 2 * C + C + c];
+      }
+    }
+    red[0][part][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
+    red[1][part][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
+    __syncthreads();
+    for (int st = 32; st > 0; st >>= 1) {
+      if (part < st) {
+        red[0][part][cl] += red[0][part + st][cl];
+        red[1][part][cl] += red[1][part + st][cl];
+      }
+      __syncthreads();
+    }
+    if (part == 0 && c < C) {
+      const double t0 = red[0][0][cl], t1 = red[1][0][cl];
+      if (sums_out) {
+        sums_out[(size_t)g * 2 * C + c] = t0;
+        sums_out[(size_t)g * 2 * C + C + c] = t1;
+      } else {
+        bn_finalize_one(t0, t1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+                        scale_out + g * C, shift_out + g * C, c);
+      }
+    }
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int Mg, int C, int ld,
                                                        int rows_per_block, double* partial) {
@@ -181,6 +244,7 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
   shift_out[c] = beta[c] - running_mean[c] * sc;
 }
 
+#define EW_UNROLL 4
 // Elementwise BN kernels: thread t owns channel vector (blockIdx.y*TPC + t % TPC) for all of its rows, so the per-channel
 // coefficients are loaded ONCE into registers (they used to be re-loaded for every element and made these kernels
 // instruction-bound).  grid = (row blocks, channel blocks, groups).
@@ -200,18 +264,33 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   for (int e = 0; e < VEC; ++e) { sc[e] = scale[g * C + c + e]; sh[e] = shift[g * C + c + e]; }
   const int gbase = g * Mg;
   const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
-  for (int r = row0 + rg; r < row1; r += RPB) {
-    Vec16<T> v, o, rr;
-    v.load(y + (size_t)r * ldy + c);
-    if (res) rr.load(res + (size_t)r * ldr + c);
+  // EW_UNROLL rows per trip, all loads issued before the first use: a thread's trips are a serial chain of ~2 us memory
+  // round trips, which (not bandwidth) bounded the 10-40 MB layers.
+  for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
+    Vec16<T> v[EW_UNROLL], rr[EW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float x = v.f(e) * sc[e] + sh[e];
-      if (res) x += rr.f(e);
-      if (relu) x = fmaxf(x, 0.f);
-      o.set(e, x);
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int ru = r + u * RPB;
+      if (ru < row1) {
+        v[u].load(y + (size_t)ru * ldy + c);
+        if (res) rr[u].load(res + (size_t)ru * ldr + c);
+      }
     }
-    o.store(out + (size_t)r * ldo + c);
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int ru = r + u * RPB;
+      if (ru < row1) {
+        Vec16<T> o;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float x = v[u].f(e) * sc[e] + sh[e];
+          if (res) x += rr[u].f(e);
+          if (relu) x = fmaxf(x, 0.f);
+          o.set(e, x);
+        }
+        o.store(out + (size_t)ru * ldo + c);
+      }
+    }
   }
 }
 
@@ -282,34 +361,47 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
   const int gbase = g * Mg;
   const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
-  for (int r = row0 + rg; r < row1; r += RPB) {
-    Vec16<T> gv, av, yv, o, dr;
-    gv.load(da + (size_t)r * ldda + c);
-    yv.load(y + (size_t)r * ldy + c);
-    if (relu && a) av.load(a + (size_t)r * lda + c);
+  for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
+    Vec16<T> gv[EW_UNROLL], av[EW_UNROLL], yv[EW_UNROLL];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float dz = gv.f(e);
-      const float act = a ? av.f(e) : yv.f(e) * sc[e] + sh[e];
-      if (relu && !(act > 0.f)) dz = 0.f;
-      const float xh = (yv.f(e) - mu[e]) * is[e];
-      o.set(e, gi[e] * (dz - m1[e] - xh * m2[e]));
-      dr.set(e, dz);
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int ru = r + u * RPB;
+      if (ru < row1) {
+        gv[u].load(da + (size_t)ru * ldda + c);
+        yv[u].load(y + (size_t)ru * ldy + c);
+        if (relu && a) av[u].load(a + (size_t)ru * lda + c);
+      }
     }
-    o.store(dy + (size_t)r * lddy + c);
-    if (dres) dr.store(dres + (size_t)r * lddr + c);
+#pragma unroll
+    for (int u = 0; u < EW_UNROLL; ++u) {
+      const int ru = r + u * RPB;
+      if (ru < row1) {
+        Vec16<T> o, dr;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          float dz = gv[u].f(e);
+          const float act = a ? av[u].f(e) : yv[u].f(e) * sc[e] + sh[e];
+          if (relu && !(act > 0.f)) dz = 0.f;
+          const float xh = (yv[u].f(e) - mu[e]) * is[e];
+          o.set(e, gi[e] * (dz - m1[e] - xh * m2[e]));
+          dr.set(e, dz);
+        }
+        o.store(dy + (size_t)ru * lddy + c);
+        if (dres) dr.store(dres + (size_t)ru * lddr + c);
+      }
+    }
   }
 }
 
 // ---- launchers -----------------------------------------------------------
 // Tensors are [M = G*Mg][C]: G statistics groups of Mg rows each (G forward passes batched into one tensor).
-// rows per block: every block streams >= 128 KiB (so that the partial rows stay ~1 % of the tensor), at most ~768 blocks
+// rows per block: every block streams >= 64 KiB (so that the partial rows stay a few % of the tensor), at most ~1024 blocks
 static inline int pick_rows_per_block(int Mg, int G, int C, int vec) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
   const long bytes = (long)Mg * C * (16 / vec);
-  long want = bytes / (128 * 1024) / ybl;
-  const long cap = 768 / ((long)ybl * G) > 0 ? 768 / ((long)ybl * G) : 1;
+  long want = bytes / (64 * 1024) / ybl;
+  const long cap = 1024 / ((long)ybl * G) > 0 ? 1024 / ((long)ybl * G) : 1;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   int rpb = cdiv(Mg, want);
@@ -352,6 +444,15 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
+int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                               float* shift, double* sums_out, int C, hipStream_t st) {
+  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M) return CSS_ERR_ARG;
+  hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, partial, cdiv(M, 128), Mg, G, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
 int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                            hipStream_t st) {
@@ -372,7 +473,7 @@ static inline int ew_grid(size_t total) {
   return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
 }
 
-// rows per block for the elementwise kernels: ~2048 blocks in total, >= 8 rows per thread
+// rows per block for the elementwise kernels: ~2048 blocks in total, >= EW_UNROLL rows per thread
 static inline int pick_rows_ew(int Mg, int G, int C, int vec) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
@@ -380,7 +481,7 @@ static inline int pick_rows_ew(int Mg, int G, int C, int vec) {
   if (want < 1) want = 1;
   int rpb = cdiv(Mg, want);
   rpb = cdiv(rpb, RPB) * RPB;
-  if (rpb < 8 * RPB) rpb = 8 * RPB;
+  if (rpb < EW_UNROLL * RPB) rpb = EW_UNROLL * RPB;
   return rpb;
 }
 

@@ -52,6 +52,183 @@ __device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off)
   return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+
+// Sum of v over the lanes {l : l % CV == lane % CV} of the wave, result in every lane.  row_ror DPP adds inside 16-lane
+// rows, then v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows.  The swaps are inline asm: the
+// __builtin_amdgcn_permlane{16,32}_swap builtins of this toolchain return the same register for both results.
+template <int CV>
+__device__ __forceinline__ float lanes_sum(float v) {
+  static_assert(CV == 4 || CV == 8 || CV == 16, "lane groups");
+  if constexpr (CV <= 8) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  if constexpr (CV <= 4) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  float w = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  v += w;
+  w = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v), "+v"(w));
+  return v + w;
+}
+
+// --------------------------------------------------------------------------
+// Shared tail of the epilogue: one wave moves its staged [WTM][WTN] tile from LDS to global memory in 16-byte row
+// pieces.  Fused into that pass, per launch option:
+//  * a.addend  - the tensor added element-wise before the store (dgrad: the residual branch's gradient, which autograd
+//                would otherwise add in a separate pass over both tensors; same rounding: bf16 + bf16 in fp32, rounded once)
+//  * a.stats   - batch-norm statistics of exactly the values stored (the bf16-rounded ones bn_stats would read back):
+//                per-channel (sum, sum of squares) of every 128-row SLAB of the output, written to
+//                stats[slab][2][Cd] (fp32, plain stores - one workgroup owns a slab).  Statistics groups (forward passes
+//                batched along M, stat_Mg rows each) need not be slab-aligned: the rows of a slab that lie past the end of
+//                the group its first row belongs to are summed separately and land in the spill row stats[nslab + g + 1].
+//                css_bn_reduce_finalize_slabs (bn.hip) adds slabs and spill rows per group in fp64.
+// sstat: LDS area of this wave's (slab, wave column) pair: an arrival counter (zeroed at kernel start) and one slot
+// [2 parts][2 stats][WTN] per wave row (part 1 = rows of the next group).  wml: which of the slab's two wave rows this is.
+// --------------------------------------------------------------------------
+template <typename T, int WTM, int WTN, int CSTR, int BN, bool STATS>
+__device__ __forceinline__ void store_wave_tile(const ConvArgs& a, const T* Cw, int mrow0, int n0w, int wml, int lane, float* sstat) {
+  constexpr int VEC = 16 / sizeof(T), CV = WTN / VEC, RSTEP = 64 / CV;
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const T* __restrict__ addp = reinterpret_cast<const T*>(a.addend);
+  const bool vec_ok = (a.ldd % VEC) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0) &&
+                      (!addp || ((a.ld_add % VEC) == 0 && (reinterpret_cast<uintptr_t>(a.addend) & 15) == 0));
+  const int cv = lane % CV, r0 = lane / CV;
+  const int n = n0w + cv * VEC;
+  const bool want = STATS && a.stats != nullptr;
+  float s[VEC], q[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) s[e] = q[e] = 0.f;
+  static_assert(WTM % RSTEP == 0, "static trip count");
+  constexpr int NIT = WTM / RSTEP;
+  auto accumulate = [&](const Vec16<T>& v) {
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float f = v.f(e);
+      s[e] += f;
+      q[e] += f * f;
+    }
+  };
+  if (vec_ok && n0w + WTN <= a.Cd && mrow0 + WTM <= a.M) {
+    // interior wave tile (wave-uniform test): branch-free, every LDS read / addend load issued before the first store
+    Vec16<T> v[NIT], r[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it].load(Cw + (r0 + it * RSTEP) * CSTR + cv * VEC);
+    if (addp) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) r[it].load(addp + (size_t)(mrow0 + r0 + it * RSTEP) * a.ld_add + n);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) v[it].set(e, v[it].f(e) + r[it].f(e));
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) v[it].store(dst + (size_t)(mrow0 + r0 + it * RSTEP) * a.ldd + n);
+    if (want) {
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) accumulate(v[it]);
+    }
+  } else {
+    // edge tiles: M / Cout tails, unaligned leading dimensions
+    for (int it = 0; it < NIT; ++it) {
+      const int row = r0 + it * RSTEP;
+      const int m = mrow0 + row;
+      if (m >= a.M || n >= a.Cd) continue;
+      Vec16<T> v;
+      v.load(Cw + row * CSTR + cv * VEC);
+      T* o = dst + (size_t)m * a.ldd + n;
+      if (vec_ok && n + VEC <= a.Cd) {
+        if (addp) {
+          Vec16<T> r;
+          r.load(addp + (size_t)m * a.ld_add + n);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v.set(e, v.f(e) + r.f(e));
+        }
+        v.store(o);
+      } else {
+        // statically indexed on purpose: a run-time index into the vector sends it through a stack object (which the
+        // compiler places in LDS) on EVERY path of this loop
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          if (n + e < a.Cd) {
+            if (addp) v.set(e, v.f(e) + ElemT<T>::to_f(addp[(size_t)m * a.ld_add + n + e]));
+            o[e] = v.e[e];
+          }
+        }
+      }
+      if (want) accumulate(v);
+    }
+  }
+  if constexpr (STATS) {
+    if (want) {
+      const int bnd = ((mrow0 & ~127) / a.stat_Mg + 1) * a.stat_Mg;   // rows >= bnd belong to the next statistics group
+      const bool straddle = mrow0 < bnd && mrow0 + WTM > bnd && bnd < a.M;   // wave-uniform, at most one wave row per group
+      // sum over the 64/CV lanes that own the same channel vector (lane = row*CV + cv): VALU only (DPP row rotates, then the
+      // gfx950 row-swap instructions) - a ds_bpermute butterfly plus LDS atomics cost ~4 us per tile here
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        s[e] = lanes_sum<CV>(s[e]);
+        q[e] = lanes_sum<CV>(q[e]);
+      }
+      float s1[VEC], q1[VEC];   // the share of the NEXT group
+      if (straddle) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s1[e] = q1[e] = 0.f;
+        for (int row = r0; row < WTM; row += RSTEP) {
+          const int m = mrow0 + row;
+          if (m < bnd || m >= a.M || n >= a.Cd) continue;
+          Vec16<T> v;
+          v.load(Cw + row * CSTR + cv * VEC);
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float f = v.f(e);
+            s1[e] += f;
+            q1[e] += f * f;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          s1[e] = lanes_sum<CV>(s1[e]);
+          q1[e] = lanes_sum<CV>(q1[e]);
+        }
+      } else {
+        const float all_next = mrow0 >= bnd ? 1.f : 0.f;   // the whole wave tile lies in the next group (or none of it)
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) { s1[e] = all_next * s[e]; q1[e] = all_next * q[e]; }
+      }
+      // Two wave rows make a slab.  The first of the pair to get here parks its sums in its LDS slot; the second adds them
+      // to its own and writes the slab's row(s) of a.stats: no block-wide barrier, no second pass.
+      float* mine = sstat + 4 * WTN;            // sstat = this pair's area: [counter .. pad][slot 0][slot 1]; slot = [4][WTN]
+      float* slot = mine + (wml ? 4 * WTN : 0);
+      if (r0 == 0) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          slot[0 * WTN + cv * VEC + e] = s[e] - s1[e];
+          slot[1 * WTN + cv * VEC + e] = q[e] - q1[e];
+          slot[2 * WTN + cv * VEC + e] = s1[e];
+          slot[3 * WTN + cv * VEC + e] = q1[e];
+        }
+      }
+      int second = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");       // slot stores stay ahead of the arrival count
+      if (lane == 0) second = atomicAdd(reinterpret_cast<int*>(sstat), 1);
+      second = __builtin_amdgcn_readfirstlane(second);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (second && (mrow0 & ~127) < a.M) {
+        const float* other = mine + (wml ? 0 : 4 * WTN);
+        const int row0 = mrow0 & ~127;
+        const int g0 = row0 / a.stat_Mg;
+        const bool spill = bnd < row0 + 128 && bnd < a.M;
+        for (int i = lane; i < 4 * WTN; i += 64) {
+          const int col = i % WTN, stat = (i / WTN) & 1, part = i / (2 * WTN);
+          const int nn = n0w + col;
+          if (nn >= a.Cd) continue;
+          const float v = slot[i] + other[i];
+          if (part == 0) a.stats[((size_t)(row0 >> 7) * 2 + stat) * a.Cd + nn] = v;
+          else if (spill) a.stats[((size_t)(a.stat_nslab + g0 + 1) * 2 + stat) * a.Cd + nn] = v;
+        }
+      }
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int BK, int WAVES_M, int WAVES_N>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   using MT = Mma<T>;
@@ -69,6 +246,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
   static_assert(WAVES_M * WAVES_N == 4, "4 waves");
   static_assert(BM % RPP == 0 && BN % RPP == 0, "tile/thread mapping");
   __shared__ __attribute__((aligned(16))) T smem[SM_ELEMS];
+  constexpr bool STATS = BM % 128 == 0;                    // slab statistics need whole slabs per workgroup
+  // per (slab, wave column) pair of waves: [counter + pad: 4*WTN floats][slot wave row 0: 4*WTN][slot wave row 1: 4*WTN]
+  __shared__ float sstat[STATS ? (BM / 128) * WAVES_N * 12 * (BN / WAVES_N) : 1];
+  if (STATS && a.stats && threadIdx.x < (BM / 128) * WAVES_N)
+    reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * (BN / WAVES_N)] = 0;       // ordered by the main loop's barriers
   T* As = smem;
   T* Bs = smem + 2 * BM * STR;
 
@@ -264,23 +446,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
-  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
-  constexpr int CV = WTN / VEC;  // vectors per staged row
-  const bool vec_ok = (a.ldd % VEC) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
-#pragma unroll 4
-  for (int idx = lane; idx < WTM * CV; idx += 64) {
-    const int row = idx / CV, cv = idx - row * CV;
-    const int m = m0 + wm * WTM + row;
-    const int n = n0 + wn * WTN + cv * VEC;
-    if (m >= a.M || n >= a.Cd) continue;
-    const T* p = Cw + row * CSTR + cv * VEC;
-    T* o = dst + (size_t)m * a.ldd + n;
-    if (vec_ok && n + VEC <= a.Cd) {
-      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p);
-    } else {
-      for (int e = 0; e < VEC && n + e < a.Cd; ++e) o[e] = p[e];
-    }
-  }
+  static_assert(!STATS || WTM == 64, "two wave rows per slab");
+  store_wave_tile<T, WTM, WTN, CSTR, BN, STATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane,
+                                                sstat + (STATS ? ((wm >> 1) * WAVES_N + wn) * 12 * WTN : 0));
 }
 
 // --------------------------------------------------------------------------
@@ -314,7 +482,19 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
   constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2, CSTR = WTN + VEC;
   static_assert(8 * WTM * CSTR * 2 <= NST * ST_BYTES, "epilogue staging fits");
+  // ONE LDS object on purpose: with a second __shared__ variable the LDS lowering tags every access with alias scopes and
+  // the waitcnt pass then puts s_waitcnt vmcnt(0) in front of the fragment reads (it must assume the in-flight LDS-DMA
+  // writes alias them), which serialises the two-tiles-in-flight pipeline (measured: 64 -> 90 ms per step).
+#ifdef CSS_ABL_NOSSTAT
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+  float* sstat = reinterpret_cast<float*>(smem);
+  constexpr bool DSTATS = false;
+#else
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + 4 * 12 * 64 * 4];
+  float* sstat = reinterpret_cast<float*>(smem + NST * ST_BYTES);   // 4 wave pairs x [counter + pad | slot | slot], see store_wave_tile
+  constexpr bool DSTATS = true;
+  if (a.stats && threadIdx.x < 4) reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * 64] = 0;   // ordered by the main loop's barriers
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -505,23 +685,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
-  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
-  constexpr int CV = WTN / VEC;
-  const bool vec_ok = (a.ldd % VEC) == 0 && ((reinterpret_cast<uintptr_t>(a.dst) & 15) == 0);
-#pragma unroll 4
-  for (int idx = lane; idx < WTM * CV; idx += 64) {
-    const int row = idx / CV, cv = idx - row * CV;
-    const int m = m0 + wm * WTM + row;
-    const int n = n0 + wn * WTN + cv * VEC;
-    if (m >= a.M || n >= a.Cd) continue;
-    const T* p = Cw + row * CSTR + cv * VEC;
-    T* o = dst + (size_t)m * a.ldd + n;
-    if (vec_ok && n + VEC <= a.Cd) {
-      *reinterpret_cast<uint4*>(o) = *reinterpret_cast<const uint4*>(p);
-    } else {
-      for (int e = 0; e < VEC && n + e < a.Cd; ++e) o[e] = p[e];
-    }
-  }
+  store_wave_tile<T, WTM, WTN, CSTR, BN, DSTATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane, sstat + ((wm >> 1) * 2 + wn) * 12 * WTN);
 }
 
 // --------------------------------------------------------------------------
@@ -708,6 +872,8 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
   ConvArgs a = a_in;
   a.m_begin = 0;
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
+  if (a.stats && (dtype != CSS_BF16 || a.stat_Mg < 128 || a.addend)) return CSS_ERR_ARG;   // slab statistics: bf16 forward only
+  a.stat_nslab = cdiv(a.M, 128);
   {
     const size_t esz = dtype == CSS_BF16 ? 2 : 4;
     const size_t sb = (size_t)a.N * a.Hs * a.Ws * a.lds * esz, wb = (size_t)a.Cd * a.Ktot * esz;

@@ -15,6 +15,11 @@ struct ConvArgs {
   int M, Ktot;
   unsigned src_bytes, wt_bytes;   // filled by the launcher (buffer descriptors)
   int m_begin;                    // first output row handled by this launch (rows m_begin .. M-1)
+  // fused epilogue extras (all optional):
+  float* stats;                   // batch-norm partial statistics [stat_nslab + G][2][Cd] (see conv.hip: store_wave_tile), or null
+  int stat_Mg, stat_nslab;        // rows per statistics group; ceil(total M / 128), filled by the launcher
+  const void* addend;             // [M][ld_add] tensor added to the result before it is stored (residual gradient), or null
+  int ld_add;
 };
 
 struct WgradArgs {
@@ -40,6 +45,9 @@ int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* s
 int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                   float* shift, int C, hipStream_t st);
+int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                               float* shift, double* sums_out, int C, hipStream_t st);
 int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                            hipStream_t st);
@@ -65,6 +73,8 @@ int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long 
 int css_launch_colsum(const void* x, int ld, long M, int C, float* out, int dtype, hipStream_t st);
 int css_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, hipStream_t st);
 int css_launch_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, hipStream_t st);
+int css_launch_weight_dgrad_layout_batched(const float* flat, void* out, const long* desc, int n_layers, long total_tiles, int dtype,
+                                           hipStream_t st);
 int css_launch_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, hipStream_t st);
 int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
                        float grad_scale, hipStream_t st);

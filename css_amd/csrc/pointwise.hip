@@ -321,6 +321,39 @@ __global__ __launch_bounds__(256) void weight_dgrad_layout_kernel(const float* _
   }
 }
 
+// All dgrad layouts of a flat parameter buffer in ONE launch.  desc[l] = {src_off, dst_off, Cout, taps, Cin, first_tile}
+// (element offsets into flat / out); block b handles 32x32 tile (b - first_tile) of the layer that owns it.
+template <typename T>
+__global__ __launch_bounds__(256) void weight_dgrad_layout_batched_kernel(const float* __restrict__ flat, T* __restrict__ out,
+                                                                          const long* __restrict__ desc, int n_layers) {
+  __shared__ float tile[32][33];
+  const long b = blockIdx.x;
+  int lo = 0, hi = n_layers - 1;
+  while (lo < hi) {   // last layer with first_tile <= b
+    const int mid = (lo + hi + 1) >> 1;
+    if (desc[mid * 6 + 5] <= b) lo = mid; else hi = mid - 1;
+  }
+  const long* d = desc + lo * 6;
+  const float* w = flat + d[0];
+  T* o = out + d[1];
+  const int Cout = (int)d[2], taps = (int)d[3], Cin = (int)d[4];
+  long tix = b - d[5];
+  const int tc = (Cin + 31) / 32, tk = (Cout + 31) / 32;
+  const int c0 = (int)(tix % tc) * 32; tix /= tc;
+  const int k0 = (int)(tix % tk) * 32;
+  const int t = (int)(tix / tk);
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int j = ty; j < 32; j += 8) {
+    const int k = k0 + j, c = c0 + tx;
+    tile[j][tx] = (k < Cout && c < Cin) ? w[((size_t)k * taps + t) * Cin + c] : 0.f;
+  }
+  __syncthreads();
+  for (int j = ty; j < 32; j += 8) {
+    const int c = c0 + j, k = k0 + tx;
+    if (c < Cin && k < Cout) o[((size_t)c * taps + t) * Cout + k] = (T)tile[tx][j];
+  }
+}
+
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO* __restrict__ out, size_t n) {
   GRID_STRIDE(idx, n) out[idx] = (TO)(float)x[idx];
@@ -501,6 +534,17 @@ int css_launch_weight_layout(const float* w, void* out, int Cout, int taps, int 
       hipLaunchKernelGGL(weight_dgrad_layout_kernel<T>, dim3(cdiv(Cin, 32), cdiv(Cout, 32), taps), dim3(32, 8), 0, st, w, (T*)out,
                          Cout, taps, Cin);
     }
+  });
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_weight_dgrad_layout_batched(const float* flat, void* out, const long* desc, int n_layers, long total_tiles, int dtype,
+                                           hipStream_t st) {
+  if (n_layers <= 0 || total_tiles <= 0) return CSS_OK;
+  if (total_tiles > 0x7fffffffL) return CSS_ERR_ARG;
+  DISPATCH_T(dtype, {
+    hipLaunchKernelGGL(weight_dgrad_layout_batched_kernel<T>, dim3((unsigned)total_tiles), dim3(256), 0, st, flat, (T*)out, desc, n_layers);
   });
   CSS_CHECK_LAUNCH();
   return CSS_OK;

@@ -33,7 +33,7 @@ def flatten_parameters(module: nn.Module) -> torch.Tensor:
     offs, total = [], 0
     for p in params:
         offs.append(total)
-        total += (p.numel() + 3) // 4 * 4
+        total += (p.numel() + 7) // 8 * 8      # 16-byte aligned slices in the bf16 mirror too (ops.prepare_flat_weights)
     flat = torch.zeros(total, dtype=torch.float32, device=dev)
     for p, o in zip(params, offs):
         n = p.numel()
@@ -83,10 +83,17 @@ class _StudentTeacher(nn.Module):
             s, t = self._ensure_flat()
             dev, st = dev_stream(s)
             call("css_ema", t, s, s.numel(), float(decay), dev, st)
-            ops.invalidate_weight_cache()
+            self.refresh_weights()
         else:
             raise RuntimeError("css_amd has no CPU path: move the model to the MI355X first")
         self.step += 1
+
+    def refresh_weights(self):
+        """After the parameters changed (optimizer / EMA step): rebuild every compute-dtype weight copy in bulk."""
+        ops.invalidate_weight_cache()
+        if self._flat is not None and self.model.compute_dtype != torch.float32:
+            ops.prepare_flat_weights(self.model, self.model.compute_dtype, dgrad=True)
+            ops.prepare_flat_weights(self.ema_model, self.ema_model.compute_dtype, dgrad=False)
 
     # ---- shared pieces of the three forwards ------------------------------------------------------------------
     # The reference calls each network twice per step (labeled batch, unlabeled batch: ddp_model.py:102-103,140-143).  Here

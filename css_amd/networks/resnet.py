@@ -43,9 +43,15 @@ class Bottleneck(nn.Module):
         self.stride = stride
 
     def forward(self, x):
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.bn2(self.conv2(out), relu=True)
         identity = x
+        if self.downsample is None and torch.is_grad_enabled() and x.requires_grad:
+            # x feeds conv1 AND the residual: take the identity from conv1's tap so that the backward adds the residual
+            # gradient inside conv1's dgrad store (ops.conv2d)
+            out, identity = self.conv1(x, tap=True)
+        else:
+            out = self.conv1(x)
+        out = self.bn1(out, relu=True)
+        out = self.bn2(self.conv2(out), relu=True)
         if self.downsample is not None:
             identity = self.downsample[1](self.downsample[0](x))
         return self.bn3(self.conv3(out), res=identity, relu=True)

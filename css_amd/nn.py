@@ -22,6 +22,8 @@ def _pair(v):
 
 
 class HipConv2d(nn.Module):
+    fuse_bn_stats = True     # bias-free convolutions emit batch-norm statistics from their epilogue (ops.conv2d)
+
     def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
         super().__init__()
         if groups != 1:
@@ -47,8 +49,10 @@ class HipConv2d(nn.Module):
                 c.bias.copy_(m.bias)
         return c
 
-    def forward(self, x):   # x: NHWC internal tensor
-        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0])
+    def forward(self, x, tap=False):   # x: NHWC internal tensor
+        # a bias-free convolution of this network always feeds a batch norm: let its epilogue produce the statistics
+        return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0],
+                          bn_stats=self.bias is None and self.training and self.fuse_bn_stats, tap=tap)
 
     def extra_repr(self):
         return (f"{self.in_channels}, {self.out_channels}, kernel_size={self.kernel_size}, stride={self.stride}, "
@@ -79,7 +83,7 @@ class HipBatchNorm2d(nn.Module):
 
     def forward(self, x, res=None, relu=False):
         if self.training:
-            self.num_batches_tracked += ops._bn_groups
+            ops.count_bn_batch(self.num_batches_tracked)
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, self.training,
                           self.momentum, self.eps, self.sync)
 

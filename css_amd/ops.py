@@ -74,6 +74,47 @@ def prepared_weight(weight: torch.Tensor, dtype: torch.dtype, cin_pad: int, dgra
     return out
 
 
+def prepare_flat_weights(module, dtype: torch.dtype, dgrad: bool) -> None:
+    """Refresh the compute-dtype copies of EVERY conv weight of a module whose parameters live in one flat buffer
+    (networks.ddp_model.flatten_parameters) in two launches instead of one or two per layer: a cast of the whole buffer
+    (the flat layout already is [Cout][R][S][Cin] per layer) and, with ``dgrad``, one batched transpose kernel.
+    The per-layer entries of ``prepared_weight``'s cache are re-pointed at views of the two persistent buffers."""
+    flat = getattr(module, "_css_flat", None)
+    if flat is None or dtype == torch.float32:
+        return
+    v = vec_of(dtype)
+    plan = module.__dict__.get("_css_lp_plan")
+    if plan is None or plan["src"] is not flat or plan["dtype"] != dtype:
+        lp = torch.empty(flat.numel(), dtype=dtype, device=flat.device)
+        fwd, dg, desc, tiles, doff = [], [], [], 0, 0
+        for p, o in zip(module.parameters(), module._css_flat_offsets):
+            if p.dim() != 4:
+                continue
+            co, ci, r, s_ = p.shape
+            n = p.numel()
+            if ci % v == 0:
+                fwd.append((p, lp[o:o + n].view(co, r, s_, ci), ci))
+            if co % v == 0 and ci % v == 0 and p.requires_grad:
+                desc.append([o, doff, co, r * s_, ci, tiles])
+                dg.append((p, doff, (ci, r, s_, co)))
+                tiles += -(-ci // 32) * -(-co // 32) * r * s_
+                doff += (n + 7) // 8 * 8
+        lpt = torch.empty(max(doff, 8), dtype=dtype, device=flat.device)
+        plan = dict(src=flat, dtype=dtype, lp=lp, lpt=lpt, fwd=fwd, tiles=tiles,
+                    dg=[(p, lpt[o:o + sh[0] * sh[1] * sh[2] * sh[3]].view(sh)) for p, o, sh in dg],
+                    desc=torch.tensor(desc, dtype=torch.int64, device=flat.device) if desc else None)
+        module.__dict__["_css_lp_plan"] = plan
+    dev, st = dev_stream(flat)
+    dc = dtype_code(dtype)
+    call("css_cast", flat, plan["lp"], flat.numel(), dtype_code(torch.float32), dc, dev, st)
+    for p, view, ci in plan["fwd"]:
+        p.__dict__.setdefault("_css_wcache", {})[(dtype, ci, False)] = ((p.data_ptr(), p._version, _epoch), view)
+    if dgrad and plan["desc"] is not None:
+        call("css_weight_dgrad_layout_batched", flat, plan["lpt"], plan["desc"], len(plan["dg"]), plan["tiles"], dc, dev, st)
+        for p, view in plan["dg"]:
+            p.__dict__.setdefault("_css_wcache", {})[(dtype, p.shape[1], True)] = ((p.data_ptr(), p._version, _epoch), view)
+
+
 # --------------------------------------------------------------------------
 # direct gradient accumulation (trainer mode)
 # --------------------------------------------------------------------------
@@ -115,7 +156,8 @@ def conv_out_size(h, k, stride, pad, dil):
 # --------------------------------------------------------------------------
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, dil):
+    def forward(ctx, x, weight, bias, stride, pad, dil, stat_groups, tap):
+        global _conv_stats_out
         n, h, w_, cp = x.shape
         cout, cin, r, s = weight.shape
         dt = x.dtype
@@ -125,15 +167,28 @@ class _Conv2d(torch.autograd.Function):
         y = torch.empty((n, ho, wo, cout), dtype=dt, device=x.device)
         dev, st = dev_stream(x)
         flops = 2.0 * n * ho * wo * cout * r * s * cin
-        call("css_conv2d_forward", x, wf, bias, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
-             dtype_code(dt), dev, st)
+        m = n * ho * wo
+        _conv_stats_out = None
+        if (stat_groups and bias is None and dt == torch.bfloat16 and m % stat_groups == 0 and m // stat_groups >= 128
+                and cout % 8 == 0):
+            # batch-norm statistics of the output from the convolution's own epilogue (no bn_stats pass)
+            mg = m // stat_groups
+            stats = torch.empty(((m + 127) // 128 + stat_groups, 2, cout), dtype=torch.float32, device=x.device)
+            call("css_conv2d_forward_bnstats", x, wf, y, stats, mg, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
+                 flops, dtype_code(dt), dev, st)
+            _conv_stats_out = (stats, mg, stat_groups, cout)
+        else:
+            call("css_conv2d_forward", x, wf, bias, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
+                 dtype_code(dt), dev, st)
         ctx.save_for_backward(x, weight)
         ctx.bias_ref = bias
         ctx.cfg = (stride, pad, dil, bias is not None, flops)
+        if tap:
+            return y, x      # x comes back as a second output: its gradient is folded into this op's dgrad store
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dtap=None):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias, flops = ctx.cfg
         n, h, w_, cp = x.shape
@@ -153,8 +208,15 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
-            call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
-                 dc, dev, st)
+            if dtap is not None:
+                dtap = dtap.contiguous()
+                call("css_conv2d_dgrad_add", dyp, wt, dx, dtap, cp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride,
+                     pad, dil, flops, dc, dev, st)
+            else:
+                call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
+                     dc, dev, st)
+        elif dtap is not None:
+            dx = dtap
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(weight, (cout, r, s, cin)) if (cout_pad == cout and cp == cin) else None
             if sink is not None:      # the wgrad kernel accumulates atomically: add straight into param.grad
@@ -173,11 +235,22 @@ class _Conv2d(torch.autograd.Function):
             else:
                 db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
                 call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1):
-    return _Conv2d.apply(x, weight, bias, stride, pad, dil)
+_conv_stats_out = None
+
+
+def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, bn_stats=False, tap=False):
+    """``bn_stats``: the output feeds a train-mode batch norm; its statistics are then produced by the convolution epilogue
+    and travel to ``bn_act`` as the ``_css_bnstats`` attribute of the result.  ``tap``: also return ``x`` itself as a second
+    output; using THAT for the residual connection lets the backward fold the residual gradient into the dgrad store
+    instead of a separate add over both tensors."""
+    out = _Conv2d.apply(x, weight, bias, stride, pad, dil, _bn_groups if bn_stats else 0, tap)
+    y = out[0] if tap else out
+    if _conv_stats_out is not None:
+        y._css_bnstats = _conv_stats_out
+    return out
 
 
 # --------------------------------------------------------------------------
@@ -192,7 +265,7 @@ class _BNAct(torch.autograd.Function):
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -206,7 +279,21 @@ class _BNAct(torch.autograd.Function):
         scale, shift = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
         mean = invstd = None
         count = float(mg)
-        if training:
+        if training and fused is not None and fused[1:] == (mg, g, c):
+            # statistics came out of the producing convolution's epilogue (fp32 rows per 128-row slab)
+            mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
+            if sync and _world() > 1:
+                stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
+                call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
+                     None, stats, c, dev, st)
+                dist.all_reduce(stats)
+                count = float(mg) * _world()
+                call("css_bn_finalize", stats, g, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                     mean, invstd, scale, shift, c, dev, st)
+            else:
+                call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
+                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, dev, st)
+        elif training:
             nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
             partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
             call("css_bn_stats", y, mg, g, c, c, partial, dc, dev, st)
@@ -264,10 +351,11 @@ class _BNAct(torch.autograd.Function):
         dres = torch.empty_like(y) if has_res else None
         call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, m, c,
              int(relu), mg, dc, dev, st)
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
+_nbt_sink = None
 
 
 class bn_groups:
@@ -277,18 +365,30 @@ class bn_groups:
         self.g = g
 
     def __enter__(self):
-        global _bn_groups
+        global _bn_groups, _nbt_sink
         self.prev, _bn_groups = _bn_groups, self.g
+        self.prev_sink, _nbt_sink = _nbt_sink, []
 
     def __exit__(self, *a):
-        global _bn_groups
-        _bn_groups = self.prev
+        global _bn_groups, _nbt_sink
+        # every layer's num_batches_tracked += groups in ONE multi-tensor launch (113 single-element adds per pass otherwise)
+        if _nbt_sink:
+            torch._foreach_add_(_nbt_sink, self.g)
+        _bn_groups, _nbt_sink = self.prev, self.prev_sink
+
+
+def count_bn_batch(counter):
+    """num_batches_tracked bookkeeping of a train-mode forward (torch BatchNorm semantics)."""
+    if _nbt_sink is not None:
+        _nbt_sink.append(counter)
+    else:
+        counter += _bn_groups
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
            groups=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
-                        _bn_groups if groups is None else groups)
+                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None))
 
 
 # --------------------------------------------------------------------------

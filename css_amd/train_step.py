@@ -79,7 +79,7 @@ class MixTrainer:
         dev, st = dev_stream(self.flat_p)
         call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
              float(self.wd), int(self.it == 0), float(decay), 1.0 / world, dev, st)
-        ops.invalidate_weight_cache()
+        m.refresh_weights()
         m.step += 1
         self.it += 1
         return dict(sup=sup.detach(), unsup=unsup.detach(), contrast=con.detach(), total=total.detach(), pseudo=u_lab)

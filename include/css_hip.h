@@ -40,15 +40,32 @@ CSS_API int css_prof_read(int kind, double* total_ms, double* launches, double* 
 CSS_API int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
                                int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device,
                                css_stream_t stream);
+/* css_conv2d_forward (bias-free, bf16) that also emits the batch-norm statistics of its output, saving bn_stats' pass over
+ * the tensor (every convolution of the reference's backbone/ASPP/decoder is followed by BatchNorm: resnet.py:119-137,
+ * aspp.py:21-62, deeplabv3.py:115-133).  The output holds G = M/Mg statistics groups of Mg >= 128 rows.
+ * stats: fp32 [ceil(M/128) + G][2][Cout], consumed by css_bn_reduce_finalize_slabs. */
+CSS_API int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho,
+                                       int Wo, int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
+                                       int device, css_stream_t stream);
 /* w_t: weights re-laid out as [Cin][R][S][Cout] (css_weight_layout dgrad=1); stride 1 or 2 */
 CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
+/* dx = dgrad(dy) + addend ([N*H*W][ld_add], same dtype): the sum autograd forms where a tensor feeds a convolution AND a
+ * residual connection (Bottleneck: resnet.py:119-139), fused into the store */
+CSS_API int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx,
+                                 int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
+                                 int device, css_stream_t stream);
 /* dw: fp32 [Cout][R][S][Cin], ACCUMULATED (atomic adds): zero it first unless accumulating on purpose */
 CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
 /* fp32 master [Cout][taps][Cin] -> compute dtype; dgrad=0: [Cout][taps][CinPad], dgrad=1: [Cin][taps][Cout] */
 CSS_API int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device,
                               css_stream_t stream);
+/* every dgrad layout of a flat fp32 parameter buffer in one launch (the weights all change together, at the optimizer step:
+ * mix_label.py:194).  desc: device int64 [n_layers][6] = {src_off, dst_off, Cout, taps, Cin, first_tile} in elements of flat / out;
+ * layer l owns tiles [first_tile_l, first_tile_l + ceil(Cin/32)*ceil(Cout/32)*taps);  total_tiles = their sum */
+CSS_API int css_weight_dgrad_layout_batched(const float* flat, void* out, const long* desc, int n_layers, long total_tiles, int dtype,
+                                            int device, css_stream_t stream);
 
 /* ---- batch norm: nn.BatchNorm2d / nn.SyncBatchNorm (mix_label.py:76) in train and eval mode --------
  * Tensors are [M = G*Mg][C]: G statistics groups of Mg rows each -- G forward passes of the reference batched into one tensor
@@ -66,6 +83,11 @@ CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* 
 CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                    float* shift, int C, int device, css_stream_t stream);
+/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [ceil(M/128) + G][2][C] -> per-group sums (fp64).  sums_out == NULL:
+ * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] (SyncBN all-reduces them, then css_bn_finalize) */
+CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                                         float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                         float* scale, float* shift, double* sums_out, int C, int device, css_stream_t stream);
 CSS_API int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
                             float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
                             int device, css_stream_t stream);

@@ -33,13 +33,18 @@ int main() {
     a.Hd = Ho; a.Wd = Wo; a.Cd = s.Cout; a.ldd = s.Cout;
     a.R = s.R; a.S = s.R; a.stride = s.stride; a.pad = s.pad; a.dil = s.dil; a.mode = 0;
     a.M = s.N * Ho * Wo; a.Ktot = s.R * s.R * s.Cin;
+#ifdef CB_NEW_EPILOGUE
+    float* dstat = nullptr; void* dadd = nullptr;
+    if (getenv("CB_STATS")) { hipMalloc(&dstat, ((size_t)(a.M + 127) / 128 + 2) * 2 * s.Cout * 4); a.stats = dstat; a.stat_Mg = a.M / 2; }
+    if (getenv("CB_ADD")) { hipMalloc(&dadd, ny * 2); hipMemset(dadd, 0, ny * 2); a.addend = dadd; a.ld_add = s.Cout; }
+#endif
     WgradArgs g{};
     g.x = dx; g.dy = dy; g.dw = dwg; g.N = s.N; g.Hs = s.H; g.Ws = s.W; g.Cs = s.Cin; g.ldx = s.Cin; g.Hd = Ho; g.Wd = Wo; g.Cd = s.Cout;
     g.ldy = s.Cout; g.R = s.R; g.S = s.R; g.stride = s.stride; g.pad = s.pad; g.dil = s.dil; g.M = a.M; g.Ktot = a.Ktot; g.m_per_split = a.M;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const double flops = 2.0 * a.M * s.Cout * a.Ktot;
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < (getenv("CB_NOWGRAD") ? 1 : 2); ++which) {
       for (int i = 0; i < 3; ++i) which ? css_launch_wgrad(g, CSS_BF16, 256, 0) : css_launch_conv(a, CSS_BF16, 256, 0);
       hipDeviceSynchronize();
       const int reps = 20;

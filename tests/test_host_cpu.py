@@ -151,3 +151,31 @@ def test_label_onehot_match_golden(golden):
     lab = torch.randint(-1, 21, (2, 9, 9))
     assert torch.equal(label_onehot(lab, 21), O.label_onehot(lab, 21))
     assert torch.equal(label_onehot_2(lab, 21), O.label_onehot_2(lab, 21))
+
+
+def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
+    """The LDS-DMA convolution keeps two K tiles in flight with a counted ``s_waitcnt vmcnt(6)``.  If the compiler ever
+    decides the in-flight DMA writes may alias the fragment reads (it did when the kernel had two __shared__ objects) it
+    inserts ``vmcnt(0)`` into the MFMA block and the kernel loses ~40 %: catch that at build time, from the ISA."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv.hip")
+    out = str(tmp_path / "conv.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    lines = open(out).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z21conv_igemm_dma_kernel"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(mfma) == 16, len(mfma)
+    first_label = max(i for i in range(mfma[0]) if body[i].startswith(".LBB"))
+    block = body[first_label:mfma[-1] + 1]
+    assert not any("vmcnt(0)" in l for l in block), "compiler serialised the LDS-DMA pipeline"
+    assert any("s_waitcnt vmcnt(6)" in l for l in body)
+    # no hidden stack objects promoted to LDS (a dynamically indexed register vector once cost 8 KiB and ~25 % of the kernel)
+    lds = next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:"))
+    assert lds == 3 * (256 + 128) * 128 + 4 * 12 * 64 * 4, lds

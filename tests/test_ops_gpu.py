@@ -236,3 +236,103 @@ def test_bn_groups_equal_separate_passes(dtype):
     og.backward(to_nhwc(torch.cat(gos), dtype))
     assert rel_err(to_nchw_cpu(xg.grad), torch.cat([t.grad for t in xr])) < tol * 5
     assert rel_err(gg.grad.cpu(), gr.grad) < tol * 5 and rel_err(bg.grad.cpu(), br.grad) < tol * 5
+
+
+# ---- fused epilogues --------------------------------------------------------------------------------------------------
+FUSED_STAT_CASES = [
+    # N, H, W, Cin, Cout, k, pad, dil, groups   (M/groups >= 128; group boundaries mostly NOT multiples of 128)
+    (2, 17, 17, 64, 64, 1, 0, 1, 1),       # 128x64 kernel, one group, ragged last slab
+    (2, 17, 17, 64, 64, 1, 0, 1, 2),       # boundary at row 289: slab 2 straddles
+    (4, 33, 33, 128, 256, 1, 0, 1, 2),     # 128x128 kernel only (less than one round of big tiles)
+    (32, 65, 65, 64, 256, 1, 0, 1, 2),     # 256x128 DMA kernel: whole rounds + 128x128 remainder, boundary at 67600
+    (16, 65, 65, 256, 128, 3, 2, 2, 2),    # dilated 3x3 through the DMA kernel
+    (6, 23, 19, 64, 48, 3, 1, 1, 3),       # three groups, Cout not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", FUSED_STAT_CASES)
+def test_conv_epilogue_bn_statistics(case):
+    """conv + train-mode BN with the statistics from the convolution epilogue == the same with a separate bn_stats pass
+    (both read the bf16-rounded output; only the summation order differs)."""
+    from css_amd import ops
+    n, h, w, cin, cout, k, pad, dil, groups = case
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(n, h, w, cin, generator=g) + 0.5).to(dev(), torch.bfloat16)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev()).contiguous(memory_format=torch.channels_last)
+    gamma, beta = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev())
+    outs = []
+    for fused in (True, False):
+        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
+        with ops.bn_groups(groups):
+            y = ops.conv2d(x, wt, None, 1, pad, dil, bn_stats=fused)
+            assert hasattr(y, "_css_bnstats") == fused
+            a = ops.bn_act(y, gamma, beta, rm, rv, None, True, True, 0.1, 1e-5, False)
+        outs.append((y.float().cpu(), a.float().cpu(), rm.cpu(), rv.cpu()))
+    (y1, a1, rm1, rv1), (y0, a0, rm0, rv0) = outs
+    assert torch.equal(y1, y0)
+    assert rel_err(rm1, rm0) < 1e-5 and rel_err(rv1, rv0) < 1e-5
+    assert rel_err(a1, a0) < 1e-3          # bf16 outputs: a last-bit flip here and there
+    # and against an fp64 restatement of per-group statistics
+    yy = y0.double().reshape(groups, -1, cout)
+    mean = yy.mean(1)
+    var = yy.var(1, unbiased=True)
+    rm_ref, rv_ref = torch.zeros(cout, dtype=torch.float64), torch.ones(cout, dtype=torch.float64)
+    for gi in range(groups):
+        rm_ref = 0.9 * rm_ref + 0.1 * mean[gi]
+        rv_ref = 0.9 * rv_ref + 0.1 * var[gi]
+    assert rel_err(rm1.double(), rm_ref) < 1e-5 and rel_err(rv1.double(), rv_ref) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(2, 17, 17, 64, 256, 1, 0, 1), (8, 65, 65, 128, 128, 3, 2, 2), (2, 9, 9, 256, 64, 3, 1, 1)])
+def test_conv_tap_folds_residual_gradient(shape, dtype):
+    """y, x_id = conv2d(x, tap=True): the gradient reaching x is dgrad(dy) + d(x_id), the sum done in the dgrad store."""
+    from css_amd import ops
+    n, h, w, cin, cout, k, pad, dil = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(n, h, w, cin, generator=g).to(dev(), dtype)
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev()).contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(n, h, w, cout, generator=g).to(dev(), dtype)
+    gid = torch.randn(n, h, w, cin, generator=g).to(dev(), dtype)
+    grads = []
+    for tap in (True, False):
+        xg = x.clone().requires_grad_(True)
+        wg = wt.clone().requires_grad_(True)
+        if tap:
+            y, xid = ops.conv2d(xg, wg, None, 1, pad, dil, tap=True)
+            assert xid.data_ptr() == xg.data_ptr()
+        else:
+            y, xid = ops.conv2d(xg, wg, None, 1, pad, dil), xg
+        torch.autograd.backward([y, xid], [gy, gid])
+        grads.append((xg.grad.float().cpu(), wg.grad.float().cpu()))
+    assert rel_err(grads[0][1], grads[1][1]) < 1e-6
+    # same arithmetic (sum in fp32, one rounding) as autograd's separate add
+    assert rel_err(grads[0][0], grads[1][0]) < (1e-6 if dtype == torch.float32 else 2e-3)
+
+
+def test_bulk_weight_preparation_matches_per_layer():
+    """ops.prepare_flat_weights (one cast + one batched transpose launch) == the per-layer css_weight_layout results."""
+    import torch.nn as nn
+    from css_amd import ops
+    from css_amd.networks.ddp_model import flatten_parameters
+    from css_amd.nn import HipBatchNorm2d, HipConv2d
+    torch.manual_seed(3)
+    net = nn.Sequential(HipConv2d(3, 64, 7, 2, 3, bias=False), HipBatchNorm2d(64), HipConv2d(64, 72, 3, 1, 1, bias=False),
+                        HipConv2d(72, 256, 1, bias=False), HipConv2d(256, 21, 1, bias=True), HipConv2d(256, 40, 3, 1, 2, 2, bias=False)).to(dev())
+    flatten_parameters(net)
+    convs = [m for m in net if isinstance(m, HipConv2d)]
+    ref = {}
+    for i, m in enumerate(convs):
+        cin = m.in_channels
+        if cin % 8 == 0:
+            ref[(i, False)] = ops.prepared_weight(m.weight, torch.bfloat16, cin, False).clone()
+            if m.out_channels % 8 == 0:
+                ref[(i, True)] = ops.prepared_weight(m.weight, torch.bfloat16, cin, True).clone()
+    ops.invalidate_weight_cache()
+    ops.prepare_flat_weights(net, torch.bfloat16, dgrad=True)
+    for (i, dg), want in ref.items():
+        m = convs[i]
+        stamp, got = m.weight.__dict__["_css_wcache"][(torch.bfloat16, m.in_channels, dg)]
+        assert got.data_ptr() != want.data_ptr() and got.shape == want.shape
+        assert torch.equal(got, want), (i, dg)
+        assert ops.prepared_weight(m.weight, torch.bfloat16, m.in_channels, dg).data_ptr() == got.data_ptr()   # cache hit
