@@ -9,6 +9,7 @@
 //   bn_bwd_reduce sum(dz), sum(dz*xhat) with dz = da * (a > 0)
 //   bn_bwd_apply  dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), optional residual grad
 #include "common.h"
+#include <cstdlib>
 
 // generic two-value per-channel reduction over rows ------------------------------------
 // Stage 1: every block reduces its row range and STORES one partial row  partial[blockIdx.x][2][C]  (fp64, plain
@@ -63,48 +64,62 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
   }
 }
 
-// stage 2: sums[j] = sum_rb partial[rb][j]  for j in [0, 2C)  (fp64), optional fused train-mode finalize.
-// block = 256 threads = 16 channels x 16 row partitions (a 16-channel fp64 segment is one 128-byte line); 4 loads in flight.
-__device__ __forceinline__ void reduce_partials_pair(const double* __restrict__ partial, int nrb, int C, int c, int part, double& a0, double& a1) {
-  double s0[4] = {0, 0, 0, 0}, s1[4] = {0, 0, 0, 0};
-  if (c < C) {
-    int rb = part;
-    for (; rb + 48 < nrb; rb += 64) {
+// ---- stage 2 ---------------------------------------------------------------------------------------------------------
+// sums[g][j] = sum over the partial rows of group g, j in [0, 2C), in fp64.  These kernels are pure latency (a few MB read
+// by C/8 blocks), so: 1024 threads = 8 channels x 128 row partitions, the partitions dealt over as many groups as divide
+// 128 (all groups of a launch run concurrently), 8 independent loads in flight per thread, tree reduction in LDS.
+// rows(g, lo, hi, extra): partial rows [lo, hi) plus row `extra` (or -1) belong to group g.  emit(g, t0, t1, c) is called
+// by ONE thread per channel, for g = 0..G-1 in order (the running statistics take their G momentum updates in order).
+constexpr int S2_CH = 8, S2_NP = 128;
+template <typename PT, typename Rows, typename Emit>
+__device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, int C, int G, Rows rows, Emit emit) {
+  __shared__ double red[2][S2_NP][S2_CH];
+  const int cl = threadIdx.x & (S2_CH - 1), part = threadIdx.x / S2_CH;
+  const int c = blockIdx.x * S2_CH + cl;
+  const int GP = (G <= S2_NP && S2_NP % G == 0) ? G : 1;      // groups reduced concurrently
+  const int P = S2_NP / GP;                                   // partitions per group
+  const int gslot = part / P, pl = part % P;
+  for (int g0 = 0; g0 < G; g0 += GP) {
+    const int g = g0 + gslot;
+    double a0[8], a1[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        s0[u] += partial[(size_t)(rb + 16 * u) * 2 * C + c];
-        s1[u] += partial[(size_t)(rb + 16 * u) * 2 * C + C + c];
+    for (int u = 0; u < 8; ++u) a0[u] = a1[u] = 0.0;
+    if (c < C) {
+      int lo, hi, extra;
+      rows(g, lo, hi, extra);
+      int r = lo + pl;
+      for (; r + 7 * P < hi; r += 8 * P) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a0[u] += (double)partial[(size_t)(r + u * P) * 2 * C + c];
+          a1[u] += (double)partial[(size_t)(r + u * P) * 2 * C + C + c];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        if (r + u * P < hi) {
+          a0[u] += (double)partial[(size_t)(r + u * P) * 2 * C + c];
+          a1[u] += (double)partial[(size_t)(r + u * P) * 2 * C + C + c];
+        }
+      }
+      if (pl == 0 && extra >= 0) {
+        a0[7] += (double)partial[(size_t)extra * 2 * C + c];
+        a1[7] += (double)partial[(size_t)extra * 2 * C + C + c];
       }
     }
-    for (; rb < nrb; rb += 16) {
-      s0[0] += partial[(size_t)rb * 2 * C + c];
-      s1[0] += partial[(size_t)rb * 2 * C + C + c];
-    }
-  }
-  __shared__ double red[2][16][16];
-  const int cl = threadIdx.x & 15;
-  red[0][part][cl] = (s0[0] + s0[1]) + (s0[2] + s0[3]);
-  red[1][part][cl] = (s1[0] + s1[1]) + (s1[2] + s1[3]);
-  __syncthreads();
-  a0 = 0; a1 = 0;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) { a0 += red[0][q][cl]; a1 += red[1][q][cl]; }
-}
-// grid = ceil(C/16), block 256.  partial is [G][nrb][2][C]; sums is [G][2][C].
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, int G, double* __restrict__ sums,
-                                                        float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-  double t0 = 0, t1 = 0;
-  for (int g = 0; g < G; ++g) {
-    double a0, a1;
-    reduce_partials_pair(partial + (size_t)g * nrb * 2 * C, nrb, C, c, part, a0, a1);
+    red[0][part][cl] = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
+    red[1][part][cl] = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
     __syncthreads();
-    if (part == 0 && c < C && sums) { sums[(size_t)g * 2 * C + c] = a0; sums[(size_t)g * 2 * C + C + c] = a1; }
-    t0 += a0; t1 += a1;
-  }
-  if (part == 0 && c < C && g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat), summed over the groups
-    if (accumulate) { g0[c] += (float)t0; g1[c] += (float)t1; }
-    else { g0[c] = (float)t0; g1[c] = (float)t1; }
+    for (int st = P >> 1; st > 0; st >>= 1) {
+      if (pl < st) {
+        red[0][part][cl] += red[0][part + st][cl];
+        red[1][part][cl] += red[1][part + st][cl];
+      }
+      __syncthreads();
+    }
+    if (part == 0 && c < C)
+      for (int q = 0; q < GP; ++q) emit(g0 + q, red[0][q * P][cl], red[1][q * P][cl], c);
+    __syncthreads();
   }
 }
 // train-mode finalize for G groups: per-group mean/invstd/scale/shift ([G][C]); the running statistics take the G
@@ -128,80 +143,62 @@ __device__ __forceinline__ void bn_finalize_one(double a0, double a1, double cou
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
-__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nrb, int G, double count,
-                                                                 const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                 float* running_mean, float* running_var, float momentum, float eps,
-                                                                 float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
-  const int c = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
-  for (int g = 0; g < G; ++g) {
-    double a0, a1;
-    reduce_partials_pair(partial + (size_t)g * nrb * 2 * C, nrb, C, c, part, a0, a1);
-    __syncthreads();
-    if (part == 0 && c < C)
-      bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
-                      scale_out + g * C, shift_out + g * C, c);
-  }
+// grid = ceil(C/8), block 1024.  partial is [G][nrb][2][C] (fp64); sums is [G][2][C].
+__global__ __launch_bounds__(1024) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, int G, double* __restrict__ sums,
+                                                         float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
+  double t0 = 0, t1 = 0;
+  stage2_reduce(
+      partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
+      [&](int g, double a0, double a1, int c) {
+        if (sums) { sums[(size_t)g * 2 * C + c] = a0; sums[(size_t)g * 2 * C + C + c] = a1; }
+        t0 += a0; t1 += a1;
+        if (g == G - 1 && g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat), summed over the groups
+          if (accumulate) { g0[c] += (float)t0; g1[c] += (float)t1; }
+          else { g0[c] = (float)t0; g1[c] = (float)t1; }
+        }
+      });
+}
+// train-mode finalize fused with the sum (single rank): per-group mean/invstd/scale/shift ([G][C])
+__global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* __restrict__ partial, int nrb, int G, double count,
+                                                                  const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                  float* running_mean, float* running_var, float momentum, float eps,
+                                                                  float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
+  stage2_reduce(
+      partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
+      [&](int g, double a0, double a1, int c) {
+        bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+                        scale_out + g * C, shift_out + g * C, c);
+      });
 }
 
 // Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile): partial is fp32
 // [nslab + G][2][C]: one row per 128-row slab of the [G*Mg][C] tensor plus one spill row per group (rows of a slab that
 // lie in the NEXT group than the slab's first row).  Group g = slabs ceil(g*Mg/128) .. ceil((g+1)*Mg/128)-1, plus spill
-// row nslab+g when g*Mg is not a multiple of 128.  block = 1024 threads = 16 channels x 64 row partitions, fp64 sums.
+// row nslab+g when g*Mg is not a multiple of 128.
 // sums_out != null: write [G][2][C] sums only (SyncBN: all-reduced before bn_finalize); else finalize in place.
 __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* running_mean, float* running_var, float momentum, float eps,
                                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                                                                double* sums_out, int C) {
-  const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  __shared__ double red[2][64][16];
-  for (int g = 0; g < G; ++g) {
-    const long lo = (long)g * Mg, hi = lo + Mg;
-    const int s_lo = (int)((lo + 127) >> 7);
-    int s_hi = (int)((hi + 127) >> 7);
-    if (s_hi > nslab) s_hi = nslab;
-    double a0[4] = {0, 0, 0, 0}, a1[4] = {0, 0, 0, 0};
-    if (c < C) {
-      int sb = s_lo + part;
-      for (; sb + 192 < s_hi; sb += 256) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          a0[u] += (double)partial[(size_t)(sb + 64 * u) * 2 * C + c];
-          a1[u] += (double)partial[(size_t)(sb + 64 * u) * 2 * C + C + c];
+  stage2_reduce(
+      partial, C, G,
+      [&](int g, int& lo, int& hi, int& extra) {
+        const long b = (long)g * Mg, e = b + Mg;
+        lo = (int)((b + 127) >> 7);
+        hi = (int)((e + 127) >> 7);
+        if (hi > nslab) hi = nslab;
+        extra = (g > 0 && (b & 127)) ? nslab + g : -1;
+      },
+      [&](int g, double a0, double a1, int c) {
+        if (sums_out) {
+          sums_out[(size_t)g * 2 * C + c] = a0;
+          sums_out[(size_t)g * 2 * C + C + c] = a1;
+        } else {
+          bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+                          scale_out + g * C, shift_out + g * C, c);
         }
-      }
-      for (; sb < s_hi; sb += 64) {
-        a0[0] += (double)partial[(size_t)sb * 2 * C + c];
-        a1[0] += (double)partial[(size_t)sb * 2 * C + C + c];
-      }
-      if (part == 0 && g > 0 && (lo & 127)) {
-        a0[1] += (double)partial[(size_t)(nslab + g) * 2 * C + c];
-        a1[1] += (double)partial[(size_t)(nslab + g) * 2 * C + C + c];
-      }
-    }
-    red[0][part][cl] = (a0[0] + a0[1]) + (a0[2] + a0[3]);
-    red[1][part][cl] = (a1[0] + a1[1]) + (a1[2] + a1[3]);
-    __syncthreads();
-    for (int st = 32; st > 0; st >>= 1) {
-      if (part < st) {
-        red[0][part][cl] += red[0][part + st][cl];
-        red[1][part][cl] += red[1][part + st][cl];
-      }
-      __syncthreads();
-    }
-    if (part == 0 && c < C) {
-      const double t0 = red[0][0][cl], t1 = red[1][0][cl];
-      if (sums_out) {
-        sums_out[(size_t)g * 2 * C + c] = t0;
-        sums_out[(size_t)g * 2 * C + C + c] = t1;
-      } else {
-        bn_finalize_one(t0, t1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
-                        scale_out + g * C, shift_out + g * C, c);
-      }
-    }
-    __syncthreads();
-  }
+      });
 }
 
 template <typename T>
@@ -432,14 +429,14 @@ int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* par
          : dtype == CSS_F32 ? bn_stats_T<float>(y, Mg, G, C, ld, partial, st) : CSS_ERR_DTYPE;
 }
 int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, C, G, sums, g1, g0, accumulate);
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, nrb, C, G, sums, g1, g0, accumulate);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                   float* shift, int C, hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, 16)), dim3(256), 0, st, partial, nrb, G, count, gamma, beta, running_mean,
+  hipLaunchKernelGGL(bn_reduce_finalize_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, nrb, G, count, gamma, beta, running_mean,
                      running_var, momentum, eps, mean, invstd, scale, shift, C);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
@@ -448,7 +445,7 @@ int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, doubl
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                float* shift, double* sums_out, int C, hipStream_t st) {
   if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M) return CSS_ERR_ARG;
-  hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, 16)), dim3(1024), 0, st, partial, cdiv(M, 128), Mg, G, count, gamma, beta,
+  hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, cdiv(M, 128), Mg, G, count, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
@@ -474,14 +471,14 @@ static inline int ew_grid(size_t total) {
 }
 
 // rows per block for the elementwise kernels: ~2048 blocks in total, >= EW_UNROLL rows per thread
-static inline int pick_rows_ew(int Mg, int G, int C, int vec) {
+static inline int pick_rows_ew(int Mg, int G, int C, int vec, int min_rows = EW_UNROLL) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
   long want = 2048 / ((long)ybl * G);
   if (want < 1) want = 1;
   int rpb = cdiv(Mg, want);
   rpb = cdiv(rpb, RPB) * RPB;
-  if (rpb < EW_UNROLL * RPB) rpb = EW_UNROLL * RPB;
+  if (rpb < min_rows * RPB) rpb = min_rows * RPB;
   return rpb;
 }
 
@@ -538,7 +535,7 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
       (relu && !a && (!scale || !shift)))
     return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
-  const int rpb = pick_rows_ew(Mg, G, C, VEC);
+  const int rpb = pick_rows_ew(Mg, G, C, VEC, 16);   // amortise the 7-coefficient prologue (measured: 44 -> 30 us at 135200x128)
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy,
                      (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, Mg, C, relu, rpb);
