@@ -26,6 +26,9 @@ CONV_CASES = [
     (2, 17, 17, 256, 48, 1, 1, 0, 1, False),
     (3, 13, 11, 64, 320, 3, 1, 1, 1, True),
     (1, 1, 1, 2048, 256, 1, 1, 0, 1, False),
+    (1, 65, 65, 128, 128, 3, 1, 24, 24, False),   # ASPP-like: tiles near the top / bottom skip all-padding kernel rows
+    (2, 33, 33, 64, 128, 3, 1, 36, 36, False),    # dilation larger than the map: only the centre row of the kernel survives
+    (3, 20, 12, 128, 192, 3, 1, 6, 6, False),     # tiles spanning two images
 ]
 
 
