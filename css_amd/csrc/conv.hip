@@ -1143,6 +1143,157 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 }
 
 // --------------------------------------------------------------------------
+// bf16 weight gradient for Cout >= 256: 256 (cout) x 256 (k columns) tile, 32 pixels per step, 8 waves (2 x 4, 128 x 64
+// each), FOUR 32 KiB LDS stages filled by LDS-DMA (three steps in flight) - half the global->LDS bytes per FLOP of the
+// 128x128 kernel above.  Tiles stay [pixel][channel] as loaded; MFMA fragments come from ds_read_b64_tr_b16.
+//  * LDS rows are 256 channels = 512 B, unpadded (a DMA wave-instruction writes 2 rows).  A transposing read touches 4
+//    consecutive rows x 64 B per half-wave, so the 64-byte block b of row r is stored at block b ^ (r & 3): the 4 rows
+//    then sit on 4 disjoint bank groups.  The swizzle is applied to the per-lane SOURCE column and on the fragment reads.
+//  * thread t owns 16-byte position t & 31 of rows (t >> 5) + 16 i: (r & 3) is the same for all of them, so its source
+//    column - and for the X tile its (tap, channel) - is fixed for the whole reduction.
+// --------------------------------------------------------------------------
+// LDS-DMA as inline asm (M0 = wave-uniform LDS base).  Used by the weight-gradient kernel: with the builtin the waitcnt
+// pass knows LDS is being written and puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot tell that
+// the stage being read is not the one in flight), which would serialise the three-steps-in-flight pipeline.  Ordering is
+// this kernel's own job: counted s_waitcnt vmcnt + s_barrier before a stage is read, as in the forward kernels.
+__device__ __forceinline__ void dma16_asm(u32x4 rsrc, void* lds_wave_base, unsigned off) {
+  const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)lds_wave_base);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(off), "s"(rsrc) : "memory");
+}
+__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
+  u32x4 r = {(unsigned)b, (unsigned)(b >> 32), bytes, 0x00020000u};
+  return r;
+}
+
+__device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0, int col0, int lane) {
+  const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+  const int R = kk0 + 8 * (g >> 1) + q, C = col0 + 16 * (g & 1) + 4 * p;
+  const unsigned char* ad = tile + R * 512 + ((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
+  typedef __attribute__((address_space(3))) s16x4 lds_v4;
+  union { struct { s16x4 a, b; } s; bf16x8 f; } u;
+  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad));
+  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad + 4 * 512));
+  return u.f;
+}
+
+__global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs a) {
+  constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
+  constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
+  constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave >> 2, wk = wave & 3;
+  // XCD-aware order as in conv_wgrad_kernel: all tiles of one pixel slice run on one XCD
+  const int per_z = a.tiles_k * a.tiles_n;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
+  if (zz >= a.splits) return;
+  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
+  const int m_begin = zz * a.m_per_split;
+  const int m_end = min(a.M, m_begin + a.m_per_split);
+  const int nit = (m_end - m_begin + BP - 1) / BP;
+  if (nit <= 0) return;
+
+  const int prow = tid >> 5;                                             // tile row of this thread's chunks (+ 16 i)
+  const int schunk = ((((tid & 31) >> 2) ^ (prow & 3)) << 2) | (tid & 3);  // source 16-byte column of those chunks
+  const int kcol = k0 + schunk * 8;
+  const bool k_ok = kcol < a.Ktot;
+  const int tap = k_ok ? kcol / a.Cs : 0;
+  const int xc = k_ok ? kcol - tap * a.Cs : 0;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
+  const int ncol = n0 + schunk * 8;
+  const bool n_ok = ncol < a.Cd;
+
+  const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
+  // pixel block starting at mb -> stage (rows >= m_end, padding taps and tail columns land as zeros)
+  auto issue = [&](int stage, int mb) {
+    unsigned char* sy = smem + stage * ST_BYTES + wave * 1024;
+    unsigned char* sx = sy + T_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + prow + i * 16;
+      const unsigned off = (unsigned)(m * a.ldy + ncol) * 2u;
+      dma16_asm(rs_y, sy + i * 8192, (n_ok && m < m_end) ? off : OOB);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = mb + prow + i * 16;
+      const uint32_t mm = (uint32_t)min(m, a.M - 1);
+      const uint32_t n_img = fdiv(mm, a.fd_hw);
+      const uint32_t rem = mm - n_img * a.fd_hw.d;
+      const uint32_t hd = fdiv(rem, a.fd_w);
+      const uint32_t wd = rem - hd * a.fd_w.d;
+      const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
+      const bool ok = k_ok && m < m_end && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
+      const unsigned off = (unsigned)(((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc) * 2u;
+      dma16_asm(rs_x, sx + i * 8192, ok ? off : OOB);
+    }
+  };
+
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  auto compute = [&](int stage) {
+    const unsigned char* Yb = smem + stage * ST_BYTES;
+    const unsigned char* Xb = Yb + T_BYTES;
+    bf16x8 fy[2][TN], fx[2][TK];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fy[ks][i] = wg_frag_sw(Yb, ks * 16, wn * WTN + i * 32, lane);
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fx[ks][j] = wg_frag_sw(Xb, ks * 16, wk * WTK + j * 32, lane);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    }
+  };
+
+  int mb = m_begin;
+  issue(0, mb); mb += BP;
+  issue(1, mb); mb += BP;
+  issue(2, mb); mb += BP;
+  int st_c = 0, st_i = 3;
+  for (int it = 0; it < nit; ++it) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    issue(st_i, mb); mb += BP;          // step it+3 (past m_end: all-OOB = zeros into a free stage)
+    compute(st_c);
+    st_c = (st_c + 1) & 3;
+    st_i = (st_i + 1) & 3;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must have landed before the workgroup's LDS is released
+  // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
+  const int l31 = lane & 31, lh = lane >> 5;
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int k = k0 + wk * WTK + j * 32 + l31;
+      if (k >= a.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
+      }
+    }
+}
+
+// --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
@@ -1222,8 +1373,10 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
   a.fd_w = make_fastdiv((uint32_t)a.Wd);
   int bn, bkc, bp;
+  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
+  const bool big = dtype == CSS_BF16 && a.Cd >= 256 && a.Ktot >= 256 && !no_256;   // 256x256 LDS-DMA kernel, one workgroup per CU
   if (dtype == CSS_BF16) {
-    bn = 128; bkc = 128; bp = 64;
+    bn = big ? 256 : 128; bkc = big ? 256 : 128; bp = big ? 32 : 64;
     if (a.Cs % 8 || a.ldx % 8 || a.ldy % 8 || a.Cd % 8) return CSS_ERR_ARG;
   } else if (dtype == CSS_F32) {
     bn = 64; bkc = 64; bp = 16;
@@ -1242,7 +1395,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
   // Pixel splits: a multiple of 8 (one slice per XCD at a time, see the kernel) chosen so that the tiles an XCD owns
   // (tiles per slice x slices per XCD) fill its 32 CUs x 2 resident workgroups in whole rounds, with >= 4 iterations each.
   const int tiles = cdiv(a.Ktot, bkc) * cdiv(a.Cd, bn);
-  const int slots = (n_cu / 8) * 2;
+  const int slots = (n_cu / 8) * (big ? 1 : 2);
   int best_k = 1;
   double best_eff = 0;
   for (int k = 1; k <= 64; ++k) {
@@ -1261,7 +1414,9 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
   dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
-  if (dtype == CSS_BF16)
+  if (big)
+    hipLaunchKernelGGL(conv_wgrad_dma256_kernel, g, dim3(512), 0, st, a);
+  else if (dtype == CSS_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);

@@ -191,3 +191,15 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     lds = next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:"))
     assert lds == 4 * (256 + 256) * 64 + 8 * 12 * 64 * 4, lds
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
+    # weight-gradient kernel: inline-asm LDS-DMA (the only user of M0), counted vmcnt, transposing reads not serialised
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z24conv_wgrad_dma256_kernel"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(mfma) == 16, len(mfma)
+    first_label = max(i for i in range(mfma[0]) if body[i].startswith(".LBB"))
+    assert not any("vmcnt(0)" in l for l in body[first_label:mfma[-1] + 1])
+    assert any("s_waitcnt vmcnt(8)" in l for l in body)
+    n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
+    assert n_dma == 16 and sum("m0" in l.split(";")[0] for l in body) == n_dma
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
