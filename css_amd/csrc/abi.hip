@@ -5,6 +5,7 @@
 #include "launchers.h"
 
 #include <mutex>
+#include <new>
 #include <vector>
 
 namespace {
@@ -55,6 +56,17 @@ struct ProfScope {
     g_prof.push_back(r);
   }
 };
+// one ProfScope per KERNEL launch of a convolution call: the 256x256 LDS-DMA kernels get their own kinds (5/6/7)
+struct ConvProf : LaunchProf {
+  int kind_other, kind_big;
+  double flops;
+  hipStream_t st;
+  alignas(ProfScope) unsigned char buf[sizeof(ProfScope)];
+  ProfScope* cur = nullptr;
+  ConvProf(int ko, int kb, double f, hipStream_t s) : kind_other(ko), kind_big(kb), flops(f), st(s) {}
+  void begin(bool big, double share) override { cur = new (buf) ProfScope(big ? kind_big : kind_other, flops * share, st); }
+  void end() override { if (cur) { cur->~ProfScope(); cur = nullptr; } }
+};
 }  // namespace
 
 extern "C" {
@@ -95,8 +107,8 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldd = ldy;
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
-  ProfScope ps(0, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+  ConvProf cp(0, 5, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
                                int Cout, int ldy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device,
@@ -110,8 +122,8 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
   a.stats = stats; a.stat_Mg = Mg;
   if (!stats || Mg < 128 || a.M % Mg) return CSS_ERR_ARG;
-  ProfScope ps(0, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+  ConvProf cp(0, 5, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
@@ -123,8 +135,8 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
-  ProfScope ps(1, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+  ConvProf cp(1, 6, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
@@ -136,8 +148,8 @@ int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* 
   a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
-  ProfScope ps(1, alg_flops, S(stream));
-  return css_launch_conv(a, dtype, cu_count(device), S(stream));
+  ConvProf cp(1, 6, alg_flops, S(stream));
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
@@ -148,8 +160,8 @@ int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int
   a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldy = lddy;
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil;
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin; a.m_per_split = a.M;
-  ProfScope ps(2, alg_flops, S(stream));
-  return css_launch_wgrad(a, dtype, cu_count(device), S(stream));
+  ConvProf cp(2, 7, alg_flops, S(stream));
+  return css_launch_wgrad(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device, css_stream_t stream) {
   set_dev(device);

@@ -1296,7 +1296,9 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
 // --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
-int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
+int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
+  auto P0 = [&](bool big, double share) { if (prof) prof->begin(big, share); };
+  auto P1 = [&]() { if (prof) prof->end(); };
   ConvArgs a = a_in;
   a.m_begin = 0;
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
@@ -1322,12 +1324,16 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
       if (full_mt > 0) {
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
+        P0(true, (double)(b.M - b.m_begin) / a.M);
         hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+        P1();
       }
       if (full_mt < mt) {
         ConvArgs b = a;
         b.m_begin = full_mt * 256;
+        P0(false, (double)(b.M - b.m_begin) / a.M);
         hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128)), dim3(256), 0, st, b);
+        P1();
       }
     } else if (a.Cd > 64 && !no_dma) {
       // Big tiles (256x128, one workgroup per CU) only for whole rounds of the chip; the leftover rows go to the 128x128
@@ -1342,25 +1348,35 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
       if (full_mt > 0) {
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
+        P0(false, (double)(b.M - b.m_begin) / a.M);
         hipLaunchKernelGGL(conv_igemm_dma_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+        P1();
       }
       if (full_mt < mt) {
         ConvArgs b = a;
         b.m_begin = full_mt * 256;
+        P0(false, (double)(b.M - b.m_begin) / a.M);
         hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * nt_n), dim3(256), 0, st, b);
+        P1();
       }
     } else if (a.Cd > 64) {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 128));
+      P0(false, (double)(a.M - a.m_begin) / a.M);
       hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, a);
+      P1();
     } else {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 64));
+      P0(false, (double)(a.M - a.m_begin) / a.M);
       hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, a);
+      P1();
     }
   } else if (dtype == CSS_F32) {
     if (a.Cs % 4 || a.lds % 4 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     dim3 g(cdiv(a.M, 64) * cdiv(a.Cd, 64));
+    P0(false, (double)(a.M - a.m_begin) / a.M);
     hipLaunchKernelGGL((conv_igemm_kernel<float, 64, 64, 16, 2, 2>), g, dim3(256), 0, st, a);
+    P1();
   } else {
     return CSS_ERR_DTYPE;
   }
@@ -1368,7 +1384,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st) {
   return CSS_OK;
 }
 
-int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
+int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   if (a.M <= 0) return CSS_OK;
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
   a.fd_w = make_fastdiv((uint32_t)a.Wd);
@@ -1414,12 +1430,14 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st) {
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
   dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
+  if (prof) prof->begin(big, 1.0);
   if (big)
     hipLaunchKernelGGL(conv_wgrad_dma256_kernel, g, dim3(512), 0, st, a);
   else if (dtype == CSS_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);
+  if (prof) prof->end();
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

@@ -36,8 +36,14 @@ struct WgradArgs {
 };
 
 
-int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st);
-int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st);
+// Optional per-KERNEL timing hook (abi.hip brackets each kernel launch with HIP events when profiling is on):
+// begin(big, share): big = the 256x256 LDS-DMA kernel, share = fraction of the call's output rows this launch covers.
+struct LaunchProf {
+  virtual void begin(bool big, double share) = 0;
+  virtual void end() = 0;
+};
+int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
+int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 
 int css_bn_nrb_(int Mg, int G, int C, int dtype);
 int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st);

@@ -29,7 +29,10 @@ CSS_API int css_abi_version(void);
 CSS_API int css_device_cu_count(int device);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------------
- * kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad, 3 = contrast loss gather, 4 = similarity */
+ * Every kernel launch of a bracketed call gets its own event pair.  kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad
+ * (launches of every kernel but the 256x256 LDS-DMA ones), 3 = contrast loss gather, 4 = similarity,
+ * 5 / 6 / 7 = conv_igemm_dma256_kernel forward / dgrad launches and conv_wgrad_dma256_kernel launches.
+ * alg_work of a convolution launch = the call's algorithmic FLOPs x the share of output rows that launch covers. */
 CSS_API int css_prof_enable(int on);
 CSS_API int css_prof_reset(void);
 CSS_API int css_prof_read(int kind, double* total_ms, double* launches, double* alg_work);

@@ -284,6 +284,17 @@ def test_conv_epilogue_bn_statistics(case):
         rm_ref = 0.9 * rm_ref + 0.1 * mean[gi]
         rv_ref = 0.9 * rv_ref + 0.1 * var[gi]
     assert rel_err(rm1.double(), rm_ref) < 1e-5 and rel_err(rv1.double(), rv_ref) < 1e-5
+    # SyncBN form of stage 2: raw per-group (sum, sum of squares) in fp64, the numbers that get all-reduced across ranks
+    from css_amd._lib import call, dev_stream
+    with ops.bn_groups(groups):
+        y = ops.conv2d(x, wt, None, 1, pad, dil, bn_stats=True)
+    part, mg, g_, c_ = y._css_bnstats
+    sums = torch.empty(groups * 2 * cout, dtype=torch.float64, device=dev())
+    d, st = dev_stream(y)
+    call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
+         sums, cout, d, st)
+    want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1).reshape(-1)
+    assert rel_err(sums.cpu(), want) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
