@@ -262,7 +262,7 @@ def test_conv_epilogue_bn_statistics(case):
     g = torch.Generator().manual_seed(11)
     x = (torch.randn(n, h, w, cin, generator=g) + 0.5).to(dev(), torch.bfloat16)
     wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev()).contiguous(memory_format=torch.channels_last)
-    gamma, beta = torch.rand(cout, device=dev()) + 0.5, torch.randn(cout, device=dev())
+    gamma, beta = (torch.rand(cout, generator=g) + 0.5).to(dev()), torch.randn(cout, generator=g).to(dev())
     outs = []
     for fused in (True, False):
         rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
@@ -274,7 +274,10 @@ def test_conv_epilogue_bn_statistics(case):
     (y1, a1, rm1, rv1), (y0, a0, rm0, rv0) = outs
     assert torch.equal(y1, y0)
     assert rel_err(rm1, rm0) < 1e-5 and rel_err(rv1, rv0) < 1e-5
-    assert rel_err(a1, a0) < 1e-3          # bf16 outputs: a last-bit flip here and there
+    # bf16 outputs: the two paths' batch statistics differ in the last fp32 bit, which flips the rounding of the odd
+    # element; one bf16 ulp at the largest value is 2^-8 of it
+    assert rel_err(a1, a0) < 5e-3
+    assert (a1 != a0).float().mean() < 1e-3
     # and against an fp64 restatement of per-group statistics
     yy = y0.double().reshape(groups, -1, cout)
     mean = yy.mean(1)
@@ -350,3 +353,4 @@ def test_bulk_weight_preparation_matches_per_layer():
         assert got.data_ptr() != want.data_ptr() and got.shape == want.shape
         assert torch.equal(got, want), (i, dg)
         assert ops.prepared_weight(m.weight, torch.bfloat16, m.in_channels, dg).data_ptr() == got.data_ptr()   # cache hit
+
