@@ -26,6 +26,10 @@ _MAP = {
     "generalframeworks.loss.loss": "css_amd.loss.loss",
     "generalframeworks.scheduler.my_lr_scheduler": "css_amd.scheduler.my_lr_scheduler",
     "generalframeworks.scheduler.rampscheduler": "css_amd.scheduler.rampscheduler",
+    # evaluation helpers of test() (mix_label.py:199-225)
+    "generalframeworks.util.meter": "css_amd.util.meter",
+    "generalframeworks.util.miou": "css_amd.util.miou",
+    "generalframeworks.util.torch_dist_sum": "css_amd.util.torch_dist_sum",
 }
 
 

@@ -294,6 +294,15 @@ int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, 
   set_dev(device);
   return css_launch_pseudo_label(sim, pred, ldp, B, h, w, K, H, W, temp, logits_rep, labels_rep, logits_cls, labels_cls, pseudo, dtype, S(stream));
 }
+int css_eval_confusion(const void* pred, int ldp, const int64_t* label, int B, int h, int w, int K, int H, int W, int64_t* mat, uint8_t* argmax_out,
+                       int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_eval_confusion(pred, ldp, label, B, h, w, K, H, W, mat, argmax_out, dtype, S(stream));
+}
+int css_confusion_bincount(const int64_t* pred, const int64_t* label, long n, int K, int64_t* mat, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_confusion_bincount(pred, label, n, K, mat, S(stream));
+}
 int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w, int* cls,
                   int device, css_stream_t stream) {
   set_dev(device);

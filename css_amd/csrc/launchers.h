@@ -86,6 +86,9 @@ int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n,
                        float grad_scale, hipStream_t st);
 int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t st);
 
+int css_launch_eval_confusion(const void* pred, int ldp, const int64_t* label, int B, int h, int w, int K, int H, int W, int64_t* mat,
+                              uint8_t* argmax_out, int dtype, hipStream_t st);
+int css_launch_confusion_bincount(const int64_t* pred, const int64_t* label, long n, int K, int64_t* mat, hipStream_t st);
 int css_launch_proto_normalize(const float* proto, void* out, int K, int C, int dtype, hipStream_t st);
 int css_launch_similarity(const void* rep, int ld, const void* pn, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
                           float temp, float strong_thr, int dtype, int n_cu, hipStream_t st);

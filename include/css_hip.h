@@ -139,6 +139,14 @@ CSS_API int css_pseudo_label(const float* sim, const void* pred, int ldp, int B,
 CSS_API int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w,
                           int* cls, int device, css_stream_t stream);
 
+/* ---- evaluation: test() of mix_label.py:199-225.  css_eval_confusion fuses F.interpolate(bilinear,
+ * align_corners=True) of the NHWC logits [B][h][w][ldp] to the label size, argmax over K and ConfMatrix.update
+ * (util/meter.py:39-48): mat (int64 [K][K], row = target, column = prediction) is ACCUMULATED; labels outside [0,K) are
+ * ignored; argmax_out (uint8 [B][H][W]) is optional.  css_confusion_bincount is ConfMatrix.update on class indices. K <= 32. */
+CSS_API int css_eval_confusion(const void* pred, int ldp, const int64_t* label, int B, int h, int w, int K, int H, int W, int64_t* mat,
+                               uint8_t* argmax_out, int dtype, int device, css_stream_t stream);
+CSS_API int css_confusion_bincount(const int64_t* pred, const int64_t* label, long n, int K, int64_t* mat, int device, css_stream_t stream);
+
 /* ---- cross-entropy family: mix_label.py:81,169; loss/loss.py:19-46 (OHEM), :53-64 (Attention_Threshold_Loss) */
 CSS_API int css_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
                        double* stats, float* gtprob_out, int device, css_stream_t stream);

@@ -628,3 +628,25 @@ def train_step_mix(st: MixState, l_img, l_lab, u_img, *, lr, temp_model=0.5, str
         st.student[n].requires_grad_(False)
     return dict(sup=float(sup_loss), unsup=float(unsup_loss), contrast=float(c_loss), total=float(total),
                 pred_l=pred_l.detach(), rep_all=rep_all.detach(), pseudo=u_aug_label, grads=grads)
+
+
+# ---------------------------------------------------------------------------
+# evaluation path: mix_label.py:199-225, util/meter.py:39-48, util/miou.py:3-9
+# ---------------------------------------------------------------------------
+def eval_confusion(pred, label, num_classes):
+    """pred [B,K,h,w] fp32 logits, label [B,H,W] int -> (K x K int64 matrix (row = target, col = prediction), argmax [B,H,W]).
+    mix_label.py:214-216: bilinear(align_corners=True) to the label size, argmax(1); meter.py:44-47: targets outside [0,K)
+    are dropped, inds = K*target + pred, bincount."""
+    up = F.interpolate(pred.float(), size=label.shape[1:], mode="bilinear", align_corners=True)
+    am = up.argmax(1)
+    t, p = label.reshape(-1).long(), am.reshape(-1)
+    k = (t >= 0) & (t < num_classes)
+    mat = torch.bincount(num_classes * t[k] + p[k], minlength=num_classes ** 2).reshape(num_classes, num_classes)
+    return mat, am
+
+
+def mean_iou(mat):
+    """util/miou.py:3-9 (no epsilon: a class absent from both prediction and target gives NaN, like the reference)."""
+    h = mat.float()
+    iu = torch.diag(h) / (h.sum(1) + h.sum(0) - torch.diag(h))
+    return torch.mean(iu).item()

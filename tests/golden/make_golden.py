@@ -325,6 +325,32 @@ def gen_labelmask(seed=31):
     save("label_mask", **out)
 
 
+def gen_eval(seed=51):
+    """Eval path of mix_label.py:199-225: bilinear(align_corners=True) to the label size -> argmax -> ConfMatrix.update
+    (util/meter.py:39-48) over two batches -> mean_intersection_over_union (util/miou.py:3-9)."""
+    from generalframeworks.util.meter import ConfMatrix
+    from generalframeworks.util.miou import mean_intersection_over_union
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for tag, (K, h, H) in {"voc": (21, 17, 65), "city": (19, 25, 97)}.items():
+        meter = ConfMatrix(num_classes=K, fmt=":6.4f", name="test_miou")
+        for bi in range(2):
+            pred = torch.randn(2, K, h, h, generator=g)
+            # make the prediction correlate with the label so that the matrix has a real diagonal
+            lab = torch.randint(0, K, (2, H, H), generator=g)
+            lab_small = F.interpolate(lab[:, None].float(), size=(h, h), mode="nearest")[:, 0].long()
+            pred = pred + 2.0 * F.one_hot(lab_small, K).permute(0, 3, 1, 2).float() * (torch.rand(2, 1, h, h, generator=g) > 0.4)
+            lab[torch.rand(2, H, H, generator=g) < 0.07] = -1          # ignore label after the 255 -> -1 mapping
+            if bi == 1:
+                lab[0, :5] = 255                                       # and a raw 255 band: >= K is dropped as well
+            up = F.interpolate(pred, size=lab.shape[1:], mode="bilinear", align_corners=True)
+            meter.update(up.argmax(1).flatten(), lab.flatten())
+            out.update({f"{tag}::pred{bi}": pred, f"{tag}::lab{bi}": lab.to(torch.int16), f"{tag}::argmax{bi}": up.argmax(1).to(torch.uint8)})
+        out[f"{tag}::mat"] = meter.mat
+        out[f"{tag}::miou"] = np.float64(mean_intersection_over_union(meter.mat))
+    save("eval", **out)
+
+
 def gen_schedules():
     opt = torch.optim.SGD([nn.Parameter(torch.zeros(1))], lr=6.4e-3)
     sch = PolyLR(opt, 1000, min_lr=1e-4)
@@ -438,7 +464,9 @@ def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace"]
+    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval"]
+    if "eval" in which:
+        gen_eval()
     if "net" in which:
         gen_network("tv", 65, 21, 101, "net_tv_65")
         gen_network("stem", 65, 19, 102, "net_stem_65")

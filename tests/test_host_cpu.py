@@ -203,3 +203,27 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
     assert n_dma == 16 and sum("m0" in l.split(";")[0] for l in body) == n_dma
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
+
+
+def test_eval_and_checkpoint_modules_import_without_gpu_and_alias():
+    """The widened rows keep the reference's module paths and signatures; importing them needs no GPU."""
+    import inspect
+    import css_amd.compat as compat
+    compat.install()
+    from generalframeworks.util.meter import ConfMatrix, AverageMeter
+    from generalframeworks.util.miou import mean_intersection_over_union
+    from generalframeworks.util.torch_dist_sum import torch_dist_sum
+    assert list(inspect.signature(ConfMatrix.__init__).parameters)[1:] == ["num_classes", "fmt", "name"]
+    assert list(inspect.signature(ConfMatrix.update).parameters)[1:] == ["pred", "target"]
+    m = torch.tensor([[3, 1], [2, 4]])
+    assert abs(mean_intersection_over_union(m) - (3 / 6 + 4 / 7) / 2) < 1e-7
+    out = torch_dist_sum(0, m)
+    assert torch.equal(out[0], m) and out[0] is not m
+    am = AverageMeter("t", ":6.3f")
+    am.update(2.0)
+    am.update(4.0)
+    assert am.avg == 3.0
+    with pytest.raises(Exception):
+        ConfMatrix(2).update(torch.zeros(2, dtype=torch.int64), torch.zeros(2, dtype=torch.int64))     # CPU tensors: no CPU path
+    import css_amd.checkpoint as ck
+    assert callable(ck.save_checkpoint) and callable(ck.load_checkpoint)

@@ -232,3 +232,18 @@ def test_train_trace(golden, tag):
             close(probe_slice(st.student[p]), g[f"{it}::student::{p}"], 5e-3, 1e-6)
             close(probe_slice(st.teacher[p]), g[f"{it}::teacher::{p}"], 5e-3, 1e-6)
         close(st.teacher["resnet_bn1.running_mean"], g[f"{it}::teacher_rm::resnet_bn1"], lt * 4, 1e-6)
+
+
+def test_eval_confusion_matrix_and_miou(golden):
+    """Eval path (mix_label.py:199-225): oracle == the reference's ConfMatrix / mean_intersection_over_union on the fixture."""
+    g = golden("eval")
+    for tag, K in (("voc", 21), ("city", 19)):
+        mat = torch.zeros(K, K, dtype=torch.int64)
+        for bi in range(2):
+            pred = torch.from_numpy(g[f"{tag}::pred{bi}"])
+            lab = torch.from_numpy(g[f"{tag}::lab{bi}"].astype(np.int64))
+            m, am = O.eval_confusion(pred, lab, K)
+            assert torch.equal(am.to(torch.uint8), torch.from_numpy(g[f"{tag}::argmax{bi}"]))
+            mat += m
+        assert torch.equal(mat, torch.from_numpy(g[f"{tag}::mat"]))
+        assert abs(O.mean_iou(mat) - float(g[f"{tag}::miou"])) < 1e-7
