@@ -294,6 +294,16 @@ int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, 
   set_dev(device);
   return css_launch_pseudo_label(sim, pred, ldp, B, h, w, K, H, W, temp, logits_rep, labels_rep, logits_cls, labels_cls, pseudo, dtype, S(stream));
 }
+int css_aug_geom(const float* img, const float* label, const float* logits1, const float* logits2, const int* params, int* table, int maxlen, int B,
+                 int H, int W, int Hc, int Wc, uint8_t* img_q, uint8_t* lab_q, uint8_t* l1_q, uint8_t* l2_q, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_aug_geom(img, label, logits1, logits2, params, table, maxlen, B, H, W, Hc, Wc, img_q, lab_q, l1_q, l2_q, S(stream));
+}
+int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc, int Wc,
+                   float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_aug_finish(img_q, lab_q, l1_q, l2_q, flags, B, Hc, Wc, img, label, logits1, logits2, S(stream));
+}
 int css_eval_confusion(const void* pred, int ldp, const int64_t* label, int B, int h, int w, int K, int H, int W, int64_t* mat, uint8_t* argmax_out,
                        int dtype, int device, css_stream_t stream) {
   set_dev(device);

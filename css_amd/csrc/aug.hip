@@ -1,0 +1,209 @@
+// In-step augmentation of the unlabeled batch on the device: what the reference does by a
+// GPU -> CPU -> PIL -> GPU round trip per image inside Model_*.forward (dataset_helpers/VOC.py: tensor_to_pil_2 :284-291,
+// transform_2 :126-196, batch_transform_2 :339-352).  Integer / byte work on 8-bit planes, restated bit-exactly:
+//   aug_geom    : denormalise + 8-bit quantisation of the image and of the two confidence maps (to_pil_image),
+//                 PIL BILINEAR resize (two-pass, 22-bit fixed-point coefficients, antialiased when shrinking) of the image,
+//                 PIL NEAREST resize of label / confidence maps, pad (reflect / 255 / 0) at the right and bottom, crop
+//   aug_finish  : horizontal flip, to_tensor (q/255), ImageNet normalisation, label 255 -> -1 (int64)
+// Every random draw (scale, crop offset, flip ...) is made on the host and passed in: the kernels are deterministic.
+#include "common.h"
+#include "launchers.h"
+
+namespace {
+constexpr int PRECISION_BITS = 32 - 8 - 2;   // PIL Resample.c
+
+__device__ __forceinline__ unsigned char quant_image(float x, int c) {
+  // denormalise (VOC.py:309-314): normalize(x, 0, 1/std) then normalize(., -mean, 1); to_pil_image: mul(255).byte()
+  const float inv_std[3] = {(float)(1 / 0.229), (float)(1 / 0.224), (float)(1 / 0.225)};
+  const float neg_mean[3] = {-0.485f, -0.456f, -0.406f};
+  float d = __fdiv_rn(__fsub_rn(x, 0.f), inv_std[c]);
+  d = __fdiv_rn(__fsub_rn(d, neg_mean[c]), 1.f);
+  d = __fmul_rn(d, 255.f);
+  d = fminf(fmaxf(d, 0.f), 255.f);            // (.byte() of an out-of-range float is undefined in the reference)
+  return (unsigned char)d;
+}
+__device__ __forceinline__ unsigned char quant_unit(float x) {   // to_pil_image of a [0,1] map: mul(255).byte()
+  float d = __fmul_rn(x, 255.f);
+  d = fminf(fmaxf(d, 0.f), 255.f);
+  return (unsigned char)d;
+}
+__device__ __forceinline__ unsigned char quant_label(float l) {  // label.float()/255 -> mul(255).byte(); -1 wraps to 255
+  if (l < 0.f) return 255;
+  float d = __fmul_rn(__fdiv_rn(l, 255.f), 255.f);
+  d = fminf(d, 255.f);
+  return (unsigned char)d;
+}
+__device__ __forceinline__ int reflect_index(int p, int n) {     // np.pad(mode='reflect') continued periodically
+  if (n <= 1) return 0;
+  const int period = 2 * (n - 1);
+  int m = p % period;
+  return m < n ? m : period - m;
+}
+// PIL precompute_coeffs for the bilinear (triangle, support 1) filter: taps [xmin, xmin+cnt) and their 22-bit weights
+struct Taps { int xmin, cnt; int k[8]; };
+__device__ __forceinline__ Taps pil_bilinear_taps(int xx, int in_size, int out_size) {
+  Taps t;
+  const double scale = (double)in_size / (double)out_size;
+  const double filterscale = scale < 1.0 ? 1.0 : scale;
+  const double support = 1.0 * filterscale;
+  const double center = 0.0 + (xx + 0.5) * scale;
+  const double ss = 1.0 / filterscale;
+  int xmin = (int)(center - support + 0.5);
+  if (xmin < 0) xmin = 0;
+  int xmax = (int)(center + support + 0.5);
+  if (xmax > in_size) xmax = in_size;
+  xmax -= xmin;
+  if (xmax > 8) xmax = 8;                      // support <= 2 + rounding: at most 6 taps for scales >= 0.5 (launcher checks)
+  double w[8], ww = 0.0;
+  for (int x = 0; x < xmax; ++x) {
+    double a = (x + xmin - center + 0.5) * ss;
+    if (a < 0.0) a = -a;
+    w[x] = a < 1.0 ? 1.0 - a : 0.0;
+    ww += w[x];
+  }
+  for (int x = 0; x < xmax; ++x) {
+    double v = ww != 0.0 ? w[x] / ww : w[x];
+    t.k[x] = v < 0 ? (int)(-0.5 + v * (1 << PRECISION_BITS)) : (int)(0.5 + v * (1 << PRECISION_BITS));
+  }
+  t.xmin = xmin;
+  t.cnt = xmax;
+  return t;
+}
+__device__ __forceinline__ int clip8_fixed(int ss) {
+  int v = ss >> PRECISION_BITS;
+  return v < 0 ? 0 : (v > 255 ? 255 : v);
+}
+}  // namespace
+
+// PIL NEAREST resize (ImagingScaleAffine): xin = (int)(xo), xo starting at 0.5*a and ADVANCED BY REPEATED ADDITION of
+// a = in/out in double - reproduced as such (one thread per (image, axis)) so that exact .5 boundaries fall the same way.
+__global__ void aug_nearest_table_kernel(const int* __restrict__ params, int B, int H, int W, int maxlen, int* __restrict__ tab) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= 2 * B) return;
+  const int b = id >> 1, axis = id & 1;
+  const int out = params[b * 4 + axis], in = axis == 0 ? H : W;
+  int* t = tab + (size_t)id * maxlen;
+  if (out == in) {                             // PIL returns a copy without resampling
+    for (int x = 0; x < out; ++x) t[x] = x;
+    return;
+  }
+  const double a = (double)in / (double)out;
+  double xo = 0.0 + a * 0.5;
+  for (int x = 0; x < out; ++x) {
+    int xin = xo < 0.0 ? -1 : (int)xo;
+    t[x] = xin < in ? xin : in - 1;
+    xo += a;
+  }
+}
+
+// one thread per output (crop) pixel: 3 image channels + label + 2 confidence maps
+__global__ __launch_bounds__(256) void aug_geom_kernel(const float* __restrict__ img, const float* __restrict__ label, const float* __restrict__ l1,
+                                                       const float* __restrict__ l2, const int* __restrict__ params,
+                                                       const int* __restrict__ tab, int maxlen, int B, int H, int W, int Hc, int Wc,
+                                                       unsigned char* __restrict__ img_q, unsigned char* __restrict__ lab_q,
+                                                       unsigned char* __restrict__ l1_q, unsigned char* __restrict__ l2_q) {
+  const size_t total = (size_t)B * Hc * Wc;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wc);
+    size_t t = idx / Wc;
+    const int y = (int)(t % Hc), b = (int)(t / Hc);
+    const int rh = params[b * 4 + 0], rw = params[b * 4 + 1], ci = params[b * 4 + 2], cj = params[b * 4 + 3];
+    const int py = y + ci, px = x + cj;                      // position in the (padded) rescaled image
+    const bool inside = py < rh && px < rw;
+    const size_t plane = (size_t)H * W;
+    // label / confidence maps: constant padding, nearest sampling
+    unsigned char lq = 255, q1 = 0, q2 = 0;
+    if (inside) {
+      const int sy = tab[(size_t)(2 * b) * maxlen + py], sx = tab[(size_t)(2 * b + 1) * maxlen + px];
+      const size_t o = (size_t)b * plane + (size_t)sy * W + sx;
+      lq = quant_label(label[o]);
+      q1 = quant_unit(l1[o]);
+      q2 = quant_unit(l2[o]);
+    }
+    lab_q[idx] = lq;
+    l1_q[idx] = q1;
+    l2_q[idx] = q2;
+    // image: reflect padding of the RESIZED image, two-pass PIL bilinear
+    const int ry = py < rh ? py : reflect_index(py, rh), rx = px < rw ? px : reflect_index(px, rw);
+    for (int c = 0; c < 3; ++c) {
+      const float* src = img + ((size_t)b * 3 + c) * plane;
+      int out;
+      if (rh == H && rw == W) {
+        out = quant_image(src[(size_t)ry * W + rx], c);
+      } else {
+        const Taps tx = pil_bilinear_taps(rx, W, rw), ty = pil_bilinear_taps(ry, H, rh);
+        int acc = 1 << (PRECISION_BITS - 1);
+        for (int r = 0; r < ty.cnt; ++r) {
+          const float* row = src + (size_t)(ty.xmin + r) * W;
+          int h;
+          if (rw == W) {
+            h = quant_image(row[rx], c);                     // no horizontal pass when the width is unchanged
+          } else {
+            int ss = 1 << (PRECISION_BITS - 1);
+            for (int k = 0; k < tx.cnt; ++k) ss += (int)quant_image(row[tx.xmin + k], c) * tx.k[k];
+            h = clip8_fixed(ss);
+          }
+          acc += h * ty.k[r];
+        }
+        if (rh == H) {                                        // no vertical pass when the height is unchanged
+          int ss = 1 << (PRECISION_BITS - 1);
+          const float* row = src + (size_t)ry * W;
+          for (int k = 0; k < tx.cnt; ++k) ss += (int)quant_image(row[tx.xmin + k], c) * tx.k[k];
+          out = clip8_fixed(ss);
+        } else {
+          out = clip8_fixed(acc);
+        }
+      }
+      img_q[((size_t)b * 3 + c) * Hc * Wc + (size_t)y * Wc + x] = (unsigned char)out;
+    }
+  }
+}
+
+// flip + to_tensor + normalise; flags[b] bit 0 = horizontal flip
+__global__ __launch_bounds__(256) void aug_finish_kernel(const unsigned char* __restrict__ img_q, const unsigned char* __restrict__ lab_q,
+                                                         const unsigned char* __restrict__ l1_q, const unsigned char* __restrict__ l2_q,
+                                                         const int* __restrict__ flags, int B, int Hc, int Wc, float* __restrict__ img,
+                                                         int64_t* __restrict__ label, float* __restrict__ l1, float* __restrict__ l2) {
+  const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+  const size_t total = (size_t)B * Hc * Wc;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % Wc);
+    size_t t = idx / Wc;
+    const int y = (int)(t % Hc), b = (int)(t / Hc);
+    const int sx = (flags[b] & 1) ? Wc - 1 - x : x;
+    const size_t so = ((size_t)b * Hc + y) * Wc + sx;
+    const int lq = lab_q[so];
+    label[idx] = lq == 255 ? -1 : lq;
+    l1[idx] = __fdiv_rn((float)l1_q[so], 255.f);
+    l2[idx] = __fdiv_rn((float)l2_q[so], 255.f);
+    for (int c = 0; c < 3; ++c) {
+      const float v = __fdiv_rn((float)img_q[((size_t)b * 3 + c) * Hc * Wc + (size_t)y * Wc + sx], 255.f);
+      img[((size_t)b * 3 + c) * Hc * Wc + (size_t)y * Wc + x] = __fdiv_rn(__fsub_rn(v, mean[c]), stdv[c]);
+    }
+  }
+}
+
+int css_launch_aug_geom(const float* img, const float* label, const float* l1, const float* l2, const int* params, int* table, int maxlen, int B,
+                        int H, int W, int Hc, int Wc, unsigned char* img_q, unsigned char* lab_q, unsigned char* l1_q, unsigned char* l2_q,
+                        hipStream_t st) {
+  if (B <= 0 || H <= 0 || W <= 0 || Hc <= 0 || Wc <= 0 || maxlen < (H > W ? H : W)) return CSS_ERR_ARG;
+  hipLaunchKernelGGL(aug_nearest_table_kernel, dim3(cdiv(2 * B, 64)), dim3(64), 0, st, params, B, H, W, maxlen, table);
+  const size_t total = (size_t)B * Hc * Wc;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(aug_geom_kernel, dim3(grid), dim3(256), 0, st, img, label, l1, l2, params, table, maxlen, B, H, W, Hc, Wc, img_q, lab_q, l1_q,
+                     l2_q);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_aug_finish(const unsigned char* img_q, const unsigned char* lab_q, const unsigned char* l1_q, const unsigned char* l2_q,
+                          const int* flags, int B, int Hc, int Wc, float* img, int64_t* label, float* l1, float* l2, hipStream_t st) {
+  if (B <= 0) return CSS_ERR_ARG;
+  const size_t total = (size_t)B * Hc * Wc;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 8192) grid = 8192;
+  hipLaunchKernelGGL(aug_finish_kernel, dim3(grid), dim3(256), 0, st, img_q, lab_q, l1_q, l2_q, flags, B, Hc, Wc, img, label, l1, l2);
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}

@@ -139,6 +139,18 @@ CSS_API int css_pseudo_label(const float* sim, const void* pred, int ldp, int B,
 CSS_API int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w,
                           int* cls, int device, css_stream_t stream);
 
+/* ---- in-step augmentation of the unlabeled batch (dataset_helpers/VOC.py:126-196,284-291,339-352) on 8-bit planes.
+ * css_aug_geom: img fp32 [B][3][H][W] (ImageNet-normalised), label fp32 [B][H][W] (class id, 255 or -1), two confidence maps
+ * fp32 [B][H][W] in [0,1] -> the PIL images after tensor_to_pil_2 + rescale + pad + crop, as uint8 planes [B][3|1][Hc][Wc].
+ * params int32 [B][4] = {resized height, resized width, crop row, crop column} (host draws); table: int32 workspace
+ * [2B][maxlen], maxlen >= max(resized sizes).  Bit-exact to PIL (BILINEAR two-pass fixed point / NEAREST) for scales >= 0.5.
+ * css_aug_finish: flags int32 [B] (bit 0 = horizontal flip) -> img fp32 normalised, label int64 (255 -> -1), maps fp32 (q/255). */
+CSS_API int css_aug_geom(const float* img, const float* label, const float* logits1, const float* logits2, const int* params, int* table,
+                         int maxlen, int B, int H, int W, int Hc, int Wc, uint8_t* img_q, uint8_t* lab_q, uint8_t* l1_q, uint8_t* l2_q, int device,
+                         css_stream_t stream);
+CSS_API int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc,
+                           int Wc, float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream);
+
 /* ---- evaluation: test() of mix_label.py:199-225.  css_eval_confusion fuses F.interpolate(bilinear,
  * align_corners=True) of the NHWC logits [B][h][w][ldp] to the label size, argmax over K and ConfMatrix.update
  * (util/meter.py:39-48): mat (int64 [K][K], row = target, column = prediction) is ACCUMULATED; labels outside [0,K) are

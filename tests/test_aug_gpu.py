@@ -1,0 +1,86 @@
+"""Device-resident in-step augmentation against the PIL restatement of the reference's pipeline
+(oracle/aug_oracle.py) on identical random draws.  Byte work: bit-exact."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from gpu_util import dev  # noqa: E402
+
+
+def _inputs(b, h, w, seed, k=21):
+    from oracle import aug_oracle as A
+    g = torch.Generator().manual_seed(seed)
+    img = (torch.rand(b, 3, h, w, generator=g) - torch.tensor(A.MEAN).view(1, 3, 1, 1)) / torch.tensor(A.STD).view(1, 3, 1, 1)
+    lab = torch.randint(0, k, (b, h, w), generator=g).float()
+    lab[torch.rand(b, h, w, generator=g) < 0.1] = 255.0          # teacher/indicator disagreement
+    l1, l2 = torch.rand(b, h, w, generator=g), torch.rand(b, h, w, generator=g)
+    return img, lab, l1, l2
+
+
+GEOM_CASES = [
+    # H, W, crop, scales per image
+    (33, 41, (33, 41), [1.0, 0.5, 0.73, 1.5]),            # identity, strongest shrink (pad on both sides), shrink, enlarge
+    (65, 65, (65, 65), [0.8, 1.0, 1.27, 2.0]),
+    (40, 56, (32, 48), [0.9, 0.61, 1.0, 1.13]),           # crop smaller than the image
+    (37, 29, (37, 29), [0.999, 1.001, 0.5001, 1.9999]),   # sizes that differ by one pixel from the input
+]
+
+
+@pytest.mark.parametrize("case", GEOM_CASES)
+def test_rescale_pad_crop_quantise_bit_exact(case):
+    from css_amd.dataset_helpers import gpu_aug
+    from oracle import aug_oracle as A
+    h, w, crop, scales = case
+    img, lab, l1, l2 = _inputs(len(scales), h, w, seed=h * 100 + w)
+    g = torch.Generator().manual_seed(7)
+    ps_o, ps_d = [], []
+    for s in scales:
+        rh, rw = int(h * s), int(w * s)
+        ph, pw = max(rh, crop[0]), max(rw, crop[1])
+        ci = int(torch.randint(0, ph - crop[0] + 1, (1,), generator=g))
+        cj = int(torch.randint(0, pw - crop[1] + 1, (1,), generator=g))
+        ps_o.append(A.AugParams(scale=s, crop_i=ci, crop_j=cj))
+        ps_d.append(gpu_aug.AugParams(scale=s, crop_i=ci, crop_j=cj))
+    want = A.batch_transform_2(img, lab, l1, l2, ps_o, crop, augmentation=False)
+    got = gpu_aug.device_batch_transform_2(img.to(dev()), lab.to(dev()), l1.to(dev()), l2.to(dev()), crop, None, False, params=ps_d)
+    names = ("image", "label", "logits_cls", "logits_rep")
+    for n, a, b in zip(names, got, want):
+        assert a.shape == b.shape and a.dtype == b.dtype, n
+        assert torch.equal(a.cpu(), b), (n, (a.cpu() != b).float().mean().item())
+
+
+def test_flip_and_label_conventions():
+    from css_amd.dataset_helpers import gpu_aug
+    from oracle import aug_oracle as A
+    img, lab, l1, l2 = _inputs(3, 21, 34, seed=3)
+    lab[1] = -1.0                                            # second pass of the reference feeds -1 back in (wraps to 255 -> -1)
+    ps_o = [A.AugParams(flip=True), A.AugParams(flip=False), A.AugParams(scale=1.2, crop_i=2, crop_j=3, flip=True)]
+    ps_d = [gpu_aug.AugParams(**{k: getattr(p, k) for k in ("scale", "crop_i", "crop_j", "flip")}) for p in ps_o]
+    want = A.batch_transform_2(img, lab, l1, l2, ps_o, (21, 34), augmentation=True)
+    got = gpu_aug.device_batch_transform_2(img.to(dev()), lab.to(dev()), l1.to(dev()), l2.to(dev()), (21, 34), None, True, params=ps_d)
+    for a, b in zip(got, want):
+        assert torch.equal(a.cpu(), b)
+    assert int(got[1][1].max()) == -1
+
+
+def test_draw_laws():
+    """The host-side draws follow the reference's distributions (VOC.py:129,154,162-181)."""
+    from css_amd.dataset_helpers import gpu_aug
+    import random
+    rng, trng = random.Random(0), torch.Generator().manual_seed(0)
+    ps = [gpu_aug.draw_params(64, 80, (64, 80), (0.5, 1.5), True, rng, trng) for _ in range(4000)]
+    sc = torch.tensor([p.scale for p in ps])
+    assert 0.5 <= float(sc.min()) and float(sc.max()) <= 1.5 and abs(float(sc.mean()) - 1.0) < 0.02
+    assert abs(sum(p.jitter for p in ps) / 4000 - 0.8) < 0.03
+    assert abs(sum(p.blur for p in ps) / 4000 - 0.5) < 0.03 and abs(sum(p.flip for p in ps) / 4000 - 0.5) < 0.03
+    jit = [p for p in ps if p.jitter]
+    for name, lo, hi in (("brightness", 0.75, 1.25), ("contrast", 0.75, 1.25), ("saturation", 0.75, 1.25), ("hue", -0.25, 0.25)):
+        v = torch.tensor([getattr(p, name) for p in jit])
+        assert lo <= float(v.min()) and float(v.max()) <= hi and abs(float(v.mean()) - (lo + hi) / 2) < 0.02
+    assert len({p.order for p in jit}) == 24
+    sg = torch.tensor([p.sigma for p in ps if p.blur])
+    assert 0.15 <= float(sg.min()) and float(sg.max()) <= 1.15
+    for p in ps:                                            # crop offsets stay inside the padded, rescaled image
+        rh, rw = int(64 * p.scale), int(80 * p.scale)
+        assert 0 <= p.crop_i <= max(rh, 64) - 64 and 0 <= p.crop_j <= max(rw, 80) - 80
