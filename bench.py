@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--size", type=int, default=513)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--mix", default="cutmix")
+    ap.add_argument("--aug", default="identity", choices=["identity", "pil"])
     ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
                     help="c2: VOC-shaped 513^2 tv-R101 B=16 (default, the headline metric); c4: Cityscapes-shaped 769^2 deep-stem R101 "
                          "K=19 OHEM B=8; c5: c4 with Q=1024, N=2048")
@@ -118,7 +119,9 @@ def main():
         if a.workload == "c5":
             Q, N = 1024, 2048
     torch.manual_seed(3407)
-    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": a.mix}}
+    # --aug pil: the reference's in-step PIL pipeline on the device (random rescale 0.5-1.5, pad, crop, colour jitter, blur, flip,
+    # 8-bit quantisation; css_amd/csrc/aug.hip) instead of the identity stand-in
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5) if a.aug == "pil" else (1.0, 1.0), "mix_mode": a.mix, "device_aug": a.aug}}
     bb = resnet.resnet101_tv(zero_init_residual=False) if backbone == "tv" else resnet.resnet101(zero_init_residual=False)
     model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
     # seeded non-degenerate weights: Kaiming convs (constructor), BN gamma~U(.5,1.5), beta~N(0,.1)
@@ -186,7 +189,7 @@ def main():
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": (f"BASELINE configs[1]: VOC-shaped mix_label step, tv-ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, "
-                                    f"K={K}, Q={Q}, N={N}, mix_mode={a.mix}") if a.workload == "c2" else
+                                    f"K={K}, Q={Q}, N={N}, mix_mode={a.mix}" + (", device_aug=pil" if a.aug == "pil" else "")) if a.workload == "c2" else
                                    (f"BASELINE configs[{3 if a.workload == 'c4' else 4}] shape on {world} GPU(s): Cityscapes-shaped mix_label step, deep-stem "
                                     f"ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, OHEM, Q={Q}, N={N}, mix_mode={a.mix}"),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},

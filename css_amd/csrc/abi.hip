@@ -299,6 +299,11 @@ int css_aug_geom(const float* img, const float* label, const float* logits1, con
   set_dev(device);
   return css_launch_aug_geom(img, label, logits1, logits2, params, table, maxlen, B, H, W, Hc, Wc, img_q, lab_q, l1_q, l2_q, S(stream));
 }
+int css_aug_color(uint8_t* img_q, uint8_t* tmp, const int* jp, int64_t* sums, int B, int H, int W, int any_jitter, int any_blur, int device,
+                  css_stream_t stream) {
+  set_dev(device);
+  return css_launch_aug_color(img_q, tmp, jp, reinterpret_cast<unsigned long long*>(sums), B, H, W, any_jitter, any_blur, S(stream));
+}
 int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc, int Wc,
                    float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream) {
   set_dev(device);

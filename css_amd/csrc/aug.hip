@@ -183,6 +183,168 @@ __global__ __launch_bounds__(256) void aug_finish_kernel(const unsigned char* __
   }
 }
 
+// ---- colour jitter and Gaussian blur on the uint8 RGB planes ----------------------------------------------------------
+// torchvision ColorJitter on a PIL image = PIL ImageEnhance.{Brightness, Contrast, Color} (all three are Image.blend of a
+// "degenerate" image with the input, Blend.c) and a hue shift in PIL's 8-bit HSV space (Convert.c rgb2hsv / hsv2rgb),
+// applied in a random order; ImageFilter.GaussianBlur = three box-blur passes per axis with a fractional radius (BoxBlur.c),
+// for sigma <= 1.15 a 3-tap integer filter per pass.  jp int32 [B][16]:
+//   0 jitter on, 1..4 op order (0 brightness, 1 contrast, 2 saturation, 3 hue), 5..7 factors (float bits), 8 hue shift (uint8),
+//   9 blur on, 10 ww, 11 fw (box-blur centre / neighbour weights, 24-bit fixed point)
+namespace {
+__device__ __forceinline__ int pil_blend(int in1, int in2, float alpha) {            // Blend.c
+  const float temp = __fadd_rn((float)in1, __fmul_rn(alpha, (float)(in2 - in1)));
+  if (alpha >= 0.f && alpha <= 1.f) return (int)(unsigned char)temp;
+  if (temp <= 0.f) return 0;
+  if (temp >= 255.f) return 255;
+  return (int)(unsigned char)temp;
+}
+__device__ __forceinline__ int pil_luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }   // Convert.c L24
+__device__ __forceinline__ void pil_rgb2hsv(int r, int g, int b, int& uh, int& us, int& uv) {
+  const int maxc = max(r, max(g, b)), minc = min(r, min(g, b));
+  uv = maxc;
+  if (minc == maxc) { uh = 0; us = 0; return; }
+  const float cr = (float)(maxc - minc);
+  const float s = __fdiv_rn(cr, (float)maxc);
+  const float rc = __fdiv_rn((float)(maxc - r), cr), gc = __fdiv_rn((float)(maxc - g), cr), bc = __fdiv_rn((float)(maxc - b), cr);
+  float h;
+  if (r == maxc) h = __fsub_rn(bc, gc);
+  else if (g == maxc) h = (float)(2.0 + (double)rc - (double)bc);
+  else h = (float)(4.0 + (double)gc - (double)rc);
+  h = (float)fmod((double)h / 6.0 + 1.0, 1.0);
+  int ih = (int)((double)h * 255.0), is = (int)((double)s * 255.0);
+  uh = ih < 0 ? 0 : (ih > 255 ? 255 : ih);
+  us = is < 0 ? 0 : (is > 255 ? 255 : is);
+}
+__device__ __forceinline__ int clip8i(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+__device__ __forceinline__ void pil_hsv2rgb(int h, int s, int v, int& r, int& g, int& b) {
+  if (s == 0) { r = g = b = v; return; }
+  const double hh = (double)(float)h * 6.0 / 255.0;
+  const int i = (int)floor(hh);
+  const float f = (float)(hh - (double)(float)i);
+  const float fs = (float)((double)(float)s / 255.0);
+  const int p = clip8i((int)round((double)(float)v * (1.0 - (double)fs)));
+  const int q = clip8i((int)round((double)(float)v * (1.0 - (double)fs * (double)f)));
+  const int t = clip8i((int)round((double)(float)v * (1.0 - (double)fs * (1.0 - (double)f))));
+  switch (i % 6) {
+    case 0: r = v; g = t; b = p; break;
+    case 1: r = q; g = v; b = p; break;
+    case 2: r = p; g = v; b = t; break;
+    case 3: r = p; g = q; b = v; break;
+    case 4: r = t; g = p; b = v; break;
+    default: r = v; g = p; b = q; break;
+  }
+}
+// the ops of one image's jitter, op index range [first, last); `mean_l` = rounded mean luma for the contrast op
+__device__ __forceinline__ void jitter_ops(int& r, int& g, int& b, const int* __restrict__ jp, int first, int last, int mean_l) {
+  for (int k = first; k < last; ++k) {
+    const int op = jp[1 + k];
+    if (op == 0) {
+      const float f = __int_as_float(jp[5]);
+      r = pil_blend(0, r, f); g = pil_blend(0, g, f); b = pil_blend(0, b, f);
+    } else if (op == 1) {
+      const float f = __int_as_float(jp[6]);
+      r = pil_blend(mean_l, r, f); g = pil_blend(mean_l, g, f); b = pil_blend(mean_l, b, f);
+    } else if (op == 2) {
+      const float f = __int_as_float(jp[7]);
+      const int l = pil_luma(r, g, b);
+      r = pil_blend(l, r, f); g = pil_blend(l, g, f); b = pil_blend(l, b, f);
+    } else {
+      int h, s, v;
+      pil_rgb2hsv(r, g, b, h, s, v);
+      h = (h + jp[8]) & 0xff;
+      pil_hsv2rgb(h, s, v, r, g, b);
+    }
+  }
+}
+}  // namespace
+
+// sum of the luma of every image as it stands right before its contrast op (ImageStat.Stat(image.convert('L')).mean)
+__global__ __launch_bounds__(256) void aug_luma_sum_kernel(const unsigned char* __restrict__ img_q, const int* __restrict__ jp, int B, int HW,
+                                                           unsigned long long* __restrict__ sums) {
+  const int b = blockIdx.y;
+  const int* p = jp + b * 16;
+  if (!p[0]) return;
+  int cpos = 0;
+  while (cpos < 4 && p[1 + cpos] != 1) ++cpos;
+  unsigned long long acc = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    int r = img_q[((size_t)b * 3 + 0) * HW + i], g = img_q[((size_t)b * 3 + 1) * HW + i], bl = img_q[((size_t)b * 3 + 2) * HW + i];
+    jitter_ops(r, g, bl, p, 0, cpos, 0);
+    acc += (unsigned long long)pil_luma(r, g, bl);
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sums[b], acc);
+}
+__global__ __launch_bounds__(256) void aug_jitter_kernel(unsigned char* __restrict__ img_q, const int* __restrict__ jp, int B, int HW,
+                                                         const unsigned long long* __restrict__ sums) {
+  const int b = blockIdx.y;
+  const int* p = jp + b * 16;
+  if (!p[0]) return;
+  const int mean_l = (int)((double)sums[b] / (double)HW + 0.5);      // int(stat.mean[0] + 0.5)
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += gridDim.x * blockDim.x) {
+    unsigned char* pr = img_q + ((size_t)b * 3 + 0) * HW + i;
+    unsigned char* pg = img_q + ((size_t)b * 3 + 1) * HW + i;
+    unsigned char* pb = img_q + ((size_t)b * 3 + 2) * HW + i;
+    int r = *pr, g = *pg, bl = *pb;
+    jitter_ops(r, g, bl, p, 0, 4, mean_l);
+    *pr = (unsigned char)r; *pg = (unsigned char)g; *pb = (unsigned char)bl;
+  }
+}
+// three box-blur passes along one axis (BoxBlur.c ImagingLineBoxBlur8 with integer radius 0): each pass is
+// out = (c*ww + (l + r)*fw + 2^23) >> 24 with the line's edge pixels replicated; recursion on a 7-pixel neighbourhood
+__global__ __launch_bounds__(256) void aug_blur_kernel(const unsigned char* __restrict__ in, unsigned char* __restrict__ out, const int* __restrict__ jp,
+                                                       int B, int H, int W, int vertical) {
+  const size_t total = (size_t)B * 3 * H * W;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(idx % W);
+    size_t t = idx / W;
+    const int y = (int)(t % H);
+    const int bc = (int)(t / H), b = bc / 3;
+    const int* p = jp + b * 16;
+    if (!p[9]) { out[idx] = in[idx]; continue; }
+    const unsigned ww = (unsigned)p[10], fw = (unsigned)p[11];
+    const int n = vertical ? H : W, pos = vertical ? y : x;
+    const size_t stride = vertical ? (size_t)W : 1;
+    const unsigned char* line = in + (idx - (size_t)pos * stride);
+    unsigned v0[7], v1[7], v2[7];
+    for (int k = 0; k < 7; ++k) {
+      int q = pos - 3 + k;
+      q = q < 0 ? 0 : (q > n - 1 ? n - 1 : q);
+      v0[k] = line[(size_t)q * stride];
+    }
+    // a value "at position q" of pass k for q outside [0, n) never exists: clamp the INDEX at every level
+    auto at = [&](const unsigned* v, int q) {            // q relative index into the 7-window for absolute position pos-3+q
+      int a = pos - 3 + q;
+      a = a < 0 ? 0 : (a > n - 1 ? n - 1 : a);
+      return v[a - (pos - 3)];
+    };
+    for (int k = 1; k < 6; ++k) v1[k] = (at(v0, k) * ww + (at(v0, k - 1) + at(v0, k + 1)) * fw + (1u << 23)) >> 24;
+    for (int k = 2; k < 5; ++k) v2[k] = (at(v1, k) * ww + (at(v1, k - 1) + at(v1, k + 1)) * fw + (1u << 23)) >> 24;
+    out[idx] = (unsigned char)((at(v2, 3) * ww + (at(v2, 2) + at(v2, 4)) * fw + (1u << 23)) >> 24);
+  }
+}
+
+int css_launch_aug_color(unsigned char* img_q, unsigned char* tmp, const int* jp, unsigned long long* sums, int B, int H, int W, int any_jitter,
+                         int any_blur, hipStream_t st) {
+  if (B <= 0) return CSS_ERR_ARG;
+  const int HW = H * W;
+  if (any_jitter) {
+    (void)hipMemsetAsync(sums, 0, sizeof(unsigned long long) * B, st);
+    dim3 g(cdiv(HW, 256 * 4) < 1 ? 1 : cdiv(HW, 256 * 4), B);
+    hipLaunchKernelGGL(aug_luma_sum_kernel, g, dim3(256), 0, st, img_q, jp, B, HW, sums);
+    hipLaunchKernelGGL(aug_jitter_kernel, g, dim3(256), 0, st, img_q, jp, B, HW, sums);
+  }
+  if (any_blur) {
+    const size_t total = (size_t)B * 3 * HW;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    hipLaunchKernelGGL(aug_blur_kernel, dim3(grid), dim3(256), 0, st, img_q, tmp, jp, B, H, W, 0);
+    hipLaunchKernelGGL(aug_blur_kernel, dim3(grid), dim3(256), 0, st, tmp, img_q, jp, B, H, W, 1);
+  }
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
 int css_launch_aug_geom(const float* img, const float* label, const float* l1, const float* l2, const int* params, int* table, int maxlen, int B,
                         int H, int W, int Hc, int Wc, unsigned char* img_q, unsigned char* lab_q, unsigned char* l1_q, unsigned char* l2_q,
                         hipStream_t st) {

@@ -89,6 +89,8 @@ int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t 
 int css_launch_aug_geom(const float* img, const float* label, const float* l1, const float* l2, const int* params, int* table, int maxlen, int B,
                         int H, int W, int Hc, int Wc, unsigned char* img_q, unsigned char* lab_q, unsigned char* l1_q, unsigned char* l2_q,
                         hipStream_t st);
+int css_launch_aug_color(unsigned char* img_q, unsigned char* tmp, const int* jp, unsigned long long* sums, int B, int H, int W, int any_jitter,
+                         int any_blur, hipStream_t st);
 int css_launch_aug_finish(const unsigned char* img_q, const unsigned char* lab_q, const unsigned char* l1_q, const unsigned char* l2_q,
                           const int* flags, int B, int Hc, int Wc, float* img, int64_t* label, float* l1, float* l2, hipStream_t st);
 int css_launch_eval_confusion(const void* pred, int ldp, const int64_t* label, int B, int h, int w, int K, int H, int W, int64_t* mat,

@@ -1,15 +1,19 @@
-"""GPU-resident stand-in for the in-step augmentation of the reference
+"""GPU-resident in-step augmentation of the reference
 (``batch_transform_2/3`` + ``generate_cut_gather_2/3``, generalframeworks/dataset_helpers/VOC.py:325-352,393-477).
 
-The reference round-trips every unlabeled image GPU -> CPU -> PIL -> GPU in the middle of ``Model_*.forward``; that path
-is data augmentation ("next" row) and is out of scope for bit parity.  What the hot path needs from
-it is kept, on the device:
-  * geometry: identity (scale 1.0, crop = input size), i.e. what ``scale_size=(1.0,1.0)`` and ``crop_size == image size``
-    give in the reference;
-  * label convention: 255 ("disagree") -> -1, int64  (VOC.py:184-185);
-  * mixing: ``none`` | ``cutmix`` | ``cutout`` with the reference's box law (VOC.py:518-534) and partner ``(i+1) % B``
-    (VOC.py:428), boxes drawn on the host with numpy like the reference and applied by torch indexing on the device.
-Colour jitter / blur / flip / random rescale are NOT applied (statistical, not part of the parity contract).
+The reference round-trips every unlabeled image GPU -> CPU -> PIL -> GPU in the middle of ``Model_*.forward`` (SURVEY.md
+section 8f-1).  Two modes, chosen by ``config['Dataset']['device_aug']`` (``aug_mode``):
+  * ``"identity"`` (default, what the golden step traces were captured with): geometry and colours untouched; only the label
+    convention 255 ("disagree") -> -1, int64 (VOC.py:184-185);
+  * ``"pil"``: the reference's whole PIL pipeline restated on 8-bit planes by HIP kernels (csrc/aug.hip), BIT-EXACT to PIL on
+    identical random draws (tests/test_aug_gpu.py vs oracle/aug_oracle.py): tensor_to_pil_2's denormalise + 8-bit quantisation
+    of the image and both confidence maps, random rescale (PIL BILINEAR two-pass fixed point / NEAREST), pad (reflect / 255 / 0),
+    random crop, ColorJitter (PIL blends + 8-bit HSV hue shift, random order), GaussianBlur (PIL's three box passes per axis),
+    horizontal flip, to_tensor, ImageNet normalisation.  The random draws are made on the host with the reference's laws
+    (``draw_params``) - a few numbers per image.
+Mixing (both modes): ``none`` | ``cutmix`` | ``cutout`` with the reference's box law (VOC.py:518-534) and partner
+``(i+1) % B`` (VOC.py:428), boxes drawn on the host with numpy like the reference and applied by torch indexing on the device
+(classmix is not implemented on the device).
 """
 from __future__ import annotations
 
@@ -22,16 +26,51 @@ def labels_to_int(labels: torch.Tensor) -> torch.Tensor:
     return torch.where(lab == 255, torch.full_like(lab, -1), lab)
 
 
+_MODE = "identity"
+
+
+class aug_mode:
+    """``with aug_mode("pil")``: batch_transform* run the reference's PIL pipeline on the device (csrc/aug.hip, bit-exact to PIL:
+    random rescale, pad, crop, 8-bit quantisation, colour jitter, blur, flip); ``"identity"`` (default): geometry and colours
+    untouched, label convention only.  Model_* pick the mode from ``config['Dataset'].get('device_aug', 'identity')``."""
+
+    def __init__(self, mode):
+        if mode not in ("identity", "pil"):
+            raise ValueError("device_aug must be 'identity' or 'pil'")
+        self.mode = mode
+
+    def __enter__(self):
+        global _MODE
+        self.prev, _MODE = _MODE, self.mode
+
+    def __exit__(self, *a):
+        global _MODE
+        _MODE = self.prev
+
+
 def batch_transform_2(images, labels, logits_1=None, logits_2=None, crop_size=(512, 512), scale_size=(0.8, 1.0), augmentation=True):
+    if _MODE == "pil":
+        return device_batch_transform_2(images, labels, logits_1, logits_2, tuple(crop_size), scale_size, augmentation)
     return images, labels_to_int(labels), logits_1, logits_2
 
 
 def batch_transform_3(images, labels1, labels2, logits_1=None, logits_2=None, crop_size=(512, 512), scale_size=(0.8, 1.0),
                       augmentation=True):
+    if _MODE == "pil":
+        b, _, h, w = images.shape
+        cs = (h, w) if crop_size == -1 else tuple(crop_size)
+        ps = [draw_params(h, w, cs, scale_size, augmentation) for _ in range(b)]
+        img, l1, g1, g2 = device_batch_transform_2(images, labels1, logits_1, logits_2, cs, scale_size, augmentation, params=ps)
+        _, l2, _, _ = device_batch_transform_2(images, labels2, logits_1, logits_2, cs, scale_size, augmentation, params=ps)
+        return img, l1, l2, g1, g2
     return images, labels_to_int(labels1), labels_to_int(labels2), logits_1, logits_2
 
 
 def batch_transform(images, labels, logits=None, crop_size=(512, 512), scale_size=(0.8, 1.0), augmentation=True):
+    if _MODE == "pil":
+        img, lab, g, _ = device_batch_transform_2(images, labels, logits, logits, tuple(crop_size) if crop_size != -1 else -1, scale_size,
+                                                  augmentation)
+        return img, lab, g
     return images, labels_to_int(labels), logits
 
 
@@ -165,8 +204,51 @@ def device_batch_transform_2(images, labels, logits_1, logits_2, crop_size=(512,
     return out_img, out_lab, out_l1, out_l2
 
 
+def _box_blur_weights(sigma):
+    """ImageFilter.GaussianBlur(radius=sigma) -> BoxBlur.c: the fractional box radius of three passes (_gaussian_blur_radius,
+    float arithmetic as in C) and the 24-bit fixed-point weights of ImagingHorizontalBoxBlur.  Returns (ww, fw) for an integer
+    radius of 0, which is what sigma <= 1.15 gives (the reference draws sigma from [0.15, 1.15], VOC.py:170)."""
+    f32 = np.float32
+    radius = f32(sigma)
+    sigma2 = f32(f32(radius * radius) / f32(3))
+    big_l = f32(np.sqrt(12.0 * float(sigma2) + 1.0))
+    small_l = f32(np.floor((float(big_l) - 1.0) / 2.0))
+    a = f32(f32(f32(2) * small_l + f32(1)) * f32(f32(small_l * f32(small_l + f32(1))) - f32(f32(3) * sigma2)))
+    a = f32(a / f32(f32(6) * f32(sigma2 - f32(f32(small_l + f32(1)) * f32(small_l + f32(1))))))
+    fr = f32(small_l + a)
+    if int(fr) != 0:
+        raise ValueError("GaussianBlur sigma > 1.15 needs an integer box radius >= 1: outside the reference's range")
+    ww = int(f32(16777216.0) / f32(f32(fr * f32(2)) + f32(1)))
+    fw = ((1 << 24) - ww) // 2
+    return ww, fw
+
+
+def _pack_color_params(params):
+    rows = []
+    for p in params:
+        row = [0] * 16
+        if p.jitter:
+            row[0] = 1
+            row[1:5] = [int(o) for o in p.order]
+            row[5:8] = [int(np.float32(v).view(np.int32)) for v in (p.brightness, p.contrast, p.saturation)]
+            row[8] = int(p.hue * 255) & 0xFF                  # np.uint8(hue_factor * 255): truncation, wrap-around
+        if p.blur:
+            row[9] = 1
+            row[10], row[11] = _box_blur_weights(p.sigma)
+        rows.append(row)
+    return torch.tensor(rows, dtype=torch.int32)
+
+
 def _device_color_ops(img_q, params):
-    """Colour jitter and Gaussian blur on the uint8 image planes (filled in by the colour stage of csrc/aug.hip)."""
-    if any(p.jitter or p.blur for p in params):
-        raise NotImplementedError("colour jitter / blur on the device: next stage")
+    """Colour jitter and Gaussian blur on the uint8 image planes (csrc/aug.hip), in the reference's order: jitter, then blur."""
+    from .._lib import call, dev_stream
+    any_j, any_b = any(p.jitter for p in params), any(p.blur for p in params)
+    if not (any_j or any_b):
+        return img_q
+    b, _, h, w = img_q.shape
+    jp = _pack_color_params(params).to(img_q.device)
+    tmp = torch.empty_like(img_q)
+    sums = torch.empty(b, dtype=torch.int64, device=img_q.device)
+    dev, st = dev_stream(img_q)
+    call("css_aug_color", img_q, tmp, jp, sums, b, h, w, int(any_j), int(any_b), dev, st)
     return img_q

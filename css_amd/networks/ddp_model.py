@@ -18,7 +18,7 @@ import torch.nn as nn
 from .. import functional as Fn
 from .. import ops
 from .._lib import call, dev_stream
-from ..dataset_helpers.gpu_aug import (batch_transform, batch_transform_2, batch_transform_3, generate_cut_gather,
+from ..dataset_helpers.gpu_aug import (aug_mode, batch_transform, batch_transform_2, batch_transform_3, generate_cut_gather,
                                        generate_cut_gather_2, generate_cut_gather_3)
 from .deeplabv3.deeplabv3 import DeepLabv3Plus_with_rep
 
@@ -125,7 +125,7 @@ class Model_mix(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True):
         hw = train_u_image.shape[2:]
-        with torch.no_grad():
+        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, pseudo = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
@@ -152,7 +152,7 @@ class Model_cross(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image, prototypes):
         hw = train_u_image.shape[2:]
-        with torch.no_grad():
+        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, _ = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
@@ -176,7 +176,7 @@ class Model_ori_pseudo(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image):
         hw = train_u_image.shape[2:]
-        with torch.no_grad():
+        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, _ = self._teacher(train_u_image)
             raw = ops.bilinear(pred_u, hw[0], hw[1], torch.float32)
             # softmax + max in class space only: the pseudo-label kernel with a constant similarity map

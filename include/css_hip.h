@@ -148,6 +148,12 @@ CSS_API int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const floa
 CSS_API int css_aug_geom(const float* img, const float* label, const float* logits1, const float* logits2, const int* params, int* table,
                          int maxlen, int B, int H, int W, int Hc, int Wc, uint8_t* img_q, uint8_t* lab_q, uint8_t* l1_q, uint8_t* l2_q, int device,
                          css_stream_t stream);
+/* colour jitter (torchvision ColorJitter = PIL ImageEnhance blends + 8-bit HSV hue shift, random order) and
+ * ImageFilter.GaussianBlur (three 3-tap box passes per axis) in place on the uint8 planes [B][3][H][W]; tmp: same size; sums: int64 [B]
+ * workspace.  jp int32 [B][16]: 0 jitter on, 1..4 op order (0 brightness 1 contrast 2 saturation 3 hue), 5..7 the three factors
+ * (float bits), 8 hue shift (uint8), 9 blur on, 10 / 11 box-blur centre / neighbour weight (24-bit fixed point). */
+CSS_API int css_aug_color(uint8_t* img_q, uint8_t* tmp, const int* jp, int64_t* sums, int B, int H, int W, int any_jitter, int any_blur,
+                          int device, css_stream_t stream);
 CSS_API int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc,
                            int Wc, float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream);
 

@@ -84,3 +84,77 @@ def test_draw_laws():
     for p in ps:                                            # crop offsets stay inside the padded, rescaled image
         rh, rw = int(64 * p.scale), int(80 * p.scale)
         assert 0 <= p.crop_i <= max(rh, 64) - 64 and 0 <= p.crop_j <= max(rw, 80) - 80
+
+
+def _copy_params(p):
+    from css_amd.dataset_helpers import gpu_aug
+    return gpu_aug.AugParams(**{k: getattr(p, k) for k in ("scale", "crop_i", "crop_j", "jitter", "order", "brightness", "contrast",
+                                                           "saturation", "hue", "blur", "sigma", "flip")})
+
+
+def test_colour_jitter_each_op_bit_exact():
+    """Brightness / contrast / saturation (PIL blends) and the 8-bit HSV hue shift, one op at a time and all four orders mixed."""
+    from css_amd.dataset_helpers import gpu_aug
+    from oracle import aug_oracle as A
+    import itertools
+    import random
+    rng = random.Random(5)
+    orders = list(itertools.permutations(range(4)))
+    ps = []
+    for k in range(12):
+        ps.append(A.AugParams(jitter=True, order=orders[(5 * k + 1) % 24], brightness=rng.uniform(0.75, 1.25), contrast=rng.uniform(0.75, 1.25),
+                              saturation=rng.uniform(0.75, 1.25), hue=rng.uniform(-0.25, 0.25)))
+    ps.append(A.AugParams(jitter=True, brightness=1.25, contrast=0.75, saturation=1.25, hue=-0.25))      # range ends
+    ps.append(A.AugParams(jitter=True, brightness=0.75, contrast=1.25, saturation=0.75, hue=0.25))
+    img, lab, l1, l2 = _inputs(len(ps), 24, 31, seed=9)
+    img[0, :, :4] = img[0, 0:1, :4]                          # grey pixels (minc == maxc) and saturated ones
+    img[1] = (torch.randint(0, 2, (3, 24, 31)).float() - torch.tensor(A.MEAN).view(3, 1, 1)) / torch.tensor(A.STD).view(3, 1, 1)
+    want = A.batch_transform_2(img, lab, l1, l2, ps, (24, 31), augmentation=True)
+    got = gpu_aug.device_batch_transform_2(img.to(dev()), lab.to(dev()), l1.to(dev()), l2.to(dev()), (24, 31), None, True,
+                                           params=[_copy_params(p) for p in ps])
+    diff = (got[0].cpu() != want[0])
+    assert not diff.any(), (diff.float().mean().item(), diff.flatten(1).any(1).nonzero().flatten().tolist())
+
+
+def test_gaussian_blur_bit_exact_and_full_pipeline():
+    from css_amd.dataset_helpers import gpu_aug
+    from oracle import aug_oracle as A
+    import random
+    rng = random.Random(8)
+    ps = [A.AugParams(blur=True, sigma=s) for s in (0.15, 0.4, 0.77, 1.0, 1.15)]
+    # everything at once, as the second call of the reference does (scale 1, augmentation on)
+    for k in range(5):
+        ps.append(A.AugParams(jitter=True, order=tuple(rng.sample(range(4), 4)), brightness=rng.uniform(0.75, 1.25), contrast=rng.uniform(0.75, 1.25),
+                              saturation=rng.uniform(0.75, 1.25), hue=rng.uniform(-0.25, 0.25), blur=True, sigma=rng.uniform(0.15, 1.15),
+                              flip=bool(k % 2)))
+    img, lab, l1, l2 = _inputs(len(ps), 19, 27, seed=12)
+    want = A.batch_transform_2(img, lab, l1, l2, ps, (19, 27), augmentation=True)
+    got = gpu_aug.device_batch_transform_2(img.to(dev()), lab.to(dev()), l1.to(dev()), l2.to(dev()), (19, 27), None, True,
+                                           params=[_copy_params(p) for p in ps])
+    for n, a, b in zip(("image", "label", "logits_cls", "logits_rep"), got, want):
+        d = a.cpu() != b
+        assert not d.any(), (n, d.float().mean().item(), d.flatten(1).any(1).nonzero().flatten().tolist())
+
+
+def test_model_mix_with_device_augmentation():
+    """Model_mix.forward with config device_aug='pil': random rescale + crop + colour ops run on the device between teacher and
+    student; outputs keep the reference's shapes / dtypes / label convention and the step is differentiable."""
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_mix
+    K, S = 21, 65
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5), "mix_mode": "cutmix", "device_aug": "pil"}}
+    torch.manual_seed(4)
+    m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev())
+    m.model.train()
+    m.ema_model.train()
+    g = torch.Generator().manual_seed(6)
+    l, u = torch.randn(2, 3, S, S, generator=g).to(dev()), torch.randn(2, 3, S, S, generator=g).to(dev())
+    proto = torch.randn(K, 256, generator=g).to(dev())
+    pl, pu, u_lab, u_lc, u_lr, rep_all, prob_all = m(l, u, proto)
+    assert pl.shape == (2, K, S, S) and pu.shape == (2, K, S, S) and rep_all.shape[0] == 4
+    assert u_lab.dtype == torch.int64 and u_lab.shape == (2, S, S) and int(u_lab.min()) >= -1 and int(u_lab.max()) < K
+    for t in (u_lc, u_lr):                                   # confidence maps went through the 8-bit round trip
+        assert t.dtype == torch.float32 and float(t.min()) >= 0 and float(t.max()) <= 1
+        assert float(((t * 255) - (t * 255).round()).abs().max()) < 1e-4
+    (pl.mean() + pu.mean() + rep_all.pow(2).mean()).backward()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.model.parameters())

@@ -247,3 +247,32 @@ def test_eval_confusion_matrix_and_miou(golden):
             mat += m
         assert torch.equal(mat, torch.from_numpy(g[f"{tag}::mat"]))
         assert abs(O.mean_iou(mat) - float(g[f"{tag}::miou"])) < 1e-7
+
+
+def test_aug_oracle_matches_pil_primitives():
+    """The PIL restatement of transform_2 (oracle/aug_oracle.py) is the checker of the device augmentation: pin its pieces."""
+    from PIL import Image
+    from oracle import aug_oracle as A
+    g = torch.Generator().manual_seed(0)
+    img = (torch.rand(1, 3, 12, 16, generator=g) - torch.tensor(A.MEAN).view(1, 3, 1, 1)) / torch.tensor(A.STD).view(1, 3, 1, 1)
+    lab = torch.randint(0, 21, (1, 12, 16), generator=g).float()
+    lab[0, 0, :3] = 255
+    l1, l2 = torch.rand(1, 12, 16, generator=g), torch.rand(1, 12, 16, generator=g)
+    # identity draws: only the 8-bit round trip remains (image values can drop one level, VOC.py:284-316)
+    out = A.batch_transform_2(img, lab, l1, l2, [A.AugParams()], (12, 16), augmentation=False)
+    q_in = ((img[0] * torch.tensor(A.STD).view(3, 1, 1) + torch.tensor(A.MEAN).view(3, 1, 1)) * 255)
+    q_out = (out[0][0] * torch.tensor(A.STD).view(3, 1, 1) + torch.tensor(A.MEAN).view(3, 1, 1)) * 255
+    assert float((q_out.round() - q_out).abs().max()) < 1e-3 and float((q_in - q_out).max()) <= 1.001 and float((q_in - q_out).min()) > -1e-3
+    assert torch.equal(out[1][0], torch.where(lab[0] == 255, torch.full_like(lab[0], -1), lab[0]).long())
+    assert torch.equal(out[2][0], (l1[0] * 255).to(torch.uint8).float() / 255)
+    # enlargement by 2 then crop at (3, 5): equals PIL on the quantised image, label by nearest
+    p = A.AugParams(scale=2.0, crop_i=3, crop_j=5)
+    out2 = A.batch_transform_2(img, lab, l1, l2, [p], (12, 16), augmentation=False)
+    pil = A.tensors_to_pil(img[0], lab[0], l1[0], l2[0])
+    want = np.asarray(pil[0].resize((32, 24), Image.BILINEAR).crop((5, 3, 21, 15)))
+    got = ((out2[0][0] * torch.tensor(A.STD).view(3, 1, 1) + torch.tensor(A.MEAN).view(3, 1, 1)) * 255).round().permute(1, 2, 0).numpy()
+    assert np.array_equal(got.astype(np.uint8), want)
+    # padding law: shrink to half -> right / bottom halves are reflect (image), -1 (label), 0 (confidence)
+    out3 = A.batch_transform_2(img, lab, l1, l2, [A.AugParams(scale=0.5)], (12, 16), augmentation=False)
+    assert int(out3[1][0, 6:, :].max()) == -1 and int(out3[1][0, :, 8:].max()) == -1 and float(out3[2][0, 6:].abs().max()) == 0
+    assert torch.equal(out3[0][0, :, :6, 8:15], out3[0][0, :, :6, 0:7].flip(-1))
