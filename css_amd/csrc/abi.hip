@@ -339,6 +339,16 @@ int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr,
   set_dev(device);
   return css_launch_ce_bwd(logits, label, keep_thr, K, P, HW, coef, gscale, pos_only, dlogits, S(stream));
 }
+int css_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr,
+                     int K, int H, int W, double* stats, float* gtprob_out, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ce_small_fwd(small, ld, B, h, w, label, conf, conf_thr, keep_thr, K, H, W, stats, gtprob_out, dtype, S(stream));
+}
+int css_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
+                     const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_ce_small_bwd(small, ld, B, h, w, label, keep_thr, K, H, W, coef, gscale, pos_only, dsmall, dtype, S(stream));
+}
 size_t css_ohem_state_bytes(void) { return css_ohem_state_bytes_(); }
 size_t css_ohem_thr_offset(void) { return css_ohem_thr_offset_(); }
 int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,

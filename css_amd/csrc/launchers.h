@@ -86,6 +86,10 @@ int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n,
                        float grad_scale, hipStream_t st);
 int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t st);
 
+int css_launch_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
+                            const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, hipStream_t st);
+int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
+                            const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, hipStream_t st);
 int css_launch_aug_geom(const float* img, const float* label, const float* l1, const float* l2, const int* params, int* table, int maxlen, int B,
                         int H, int W, int Hc, int Wc, unsigned char* img_q, unsigned char* lab_q, unsigned char* l1_q, unsigned char* l2_q,
                         hipStream_t st);

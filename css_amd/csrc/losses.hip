@@ -164,6 +164,154 @@ __global__ void ohem_pick_kernel(OhemState* s, int shift, float thresh) {
   }
 }
 
+// ---- the same losses straight from the LOW-RESOLUTION logits --------------------------------------------------------
+// The reference up-samples the student's [B,K,h,w] logits to the label size before the loss (ddp_model.py:141,144:
+// F.interpolate(bilinear, align_corners=True)); at c2 that is 2 x 354 MB of fp32 written, read by the loss, and the same
+// again for the gradient.  These kernels interpolate on the fly: the forward stages a tile's interpolated logits in LDS
+// exactly like ce_kernel; the backward applies the adjoint of the interpolation inside the workgroup (LDS atomics on the
+// tile's footprint in the small map) and flushes the footprint with global fp32 atomics (footprints of neighbouring tiles
+// overlap by one small pixel).  Needs an up-sampling factor >= 2 (footprint of a 32x32 tile <= 18x18 small pixels).
+constexpr int CES_TW = 32, CES_TH = 32, CES_FP = 18;
+
+template <typename T>
+__device__ __forceinline__ float ces_interp(const T* __restrict__ small, int ld, int h, int w, int b, int y, int x, float sh, float sw, int k) {
+  float fy = sh * (float)y, fx = sw * (float)x;
+  int y0 = (int)fy, x0 = (int)fx;
+  if (y0 > h - 1) y0 = h - 1;
+  if (x0 > w - 1) x0 = w - 1;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  const float wy1 = fy - (float)y0, wy0 = 1.f - wy1, wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+  const size_t r0 = (size_t)(b * h + y0) * w, r1 = (size_t)(b * h + y1) * w;
+  return wy0 * (wx0 * ElemT<T>::to_f(small[(r0 + x0) * ld + k]) + wx1 * ElemT<T>::to_f(small[(r0 + x1) * ld + k])) +
+         wy1 * (wx0 * ElemT<T>::to_f(small[(r1 + x0) * ld + k]) + wx1 * ElemT<T>::to_f(small[(r1 + x1) * ld + k]));
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
+                                                           const int64_t* __restrict__ label, const float* __restrict__ conf, float conf_thr,
+                                                           const float* __restrict__ keep_thr, int K, size_t P, int H, int W,
+                                                           double* __restrict__ stats, float* __restrict__ gtprob_out) {
+  __shared__ float sacc[2][4];
+  const int tid = threadIdx.x;
+  const int HW = H * W;
+  for (size_t p0 = (size_t)blockIdx.x * 256; p0 < P; p0 += (size_t)gridDim.x * 256) {
+    __syncthreads();
+    if (tid < 8) sacc[tid >> 2][tid & 3] = 0.f;
+    __syncthreads();
+    const int b_first = (int)(p0 / HW);
+    const size_t p = p0 + tid;
+    if (p < P) {
+      const int b = (int)(p / HW);
+      const int rem = (int)(p - (size_t)b * HW), y = rem / W, x = rem - y * W;
+      const int64_t lab = label[p];
+      // two passes over the classes (interpolating twice is cheaper than K registers with a run-time K)
+      float mx = -INFINITY;
+      for (int k = 0; k < K; ++k) mx = fmaxf(mx, ces_interp(small, ld, h, w, b, y, x, sh, sw, k));
+      float se = 0.f, xg = 0.f;
+      for (int k = 0; k < K; ++k) {
+        const float v = ces_interp(small, ld, h, w, b, y, x, sh, sw, k);
+        se += __expf(v - mx);
+        if (k == lab) xg = v;
+      }
+      bool valid = lab >= 0 && lab < K;
+      float loss = 0.f, gtp = 1.f;
+      if (valid) {
+        loss = logf(se) + mx - xg;
+        gtp = __expf(xg - mx) / se;
+        if (keep_thr && !(gtp <= *keep_thr)) { valid = false; loss = 0.f; }
+      }
+      if (gtprob_out) gtprob_out[p] = (lab >= 0 && lab < K) ? gtp : 1.f;
+      if (stats) {
+        const int s = b - b_first;
+        if (valid) {
+          atomicAdd(&sacc[s][ST_S], loss);
+          atomicAdd(&sacc[s][ST_NVALID], 1.f);
+          if (loss > 0.f) atomicAdd(&sacc[s][ST_NPOS], 1.f);
+        }
+        if (conf && conf[p] >= conf_thr) atomicAdd(&sacc[s][ST_NCONF], 1.f);
+      }
+    }
+    __syncthreads();
+    if (stats && tid < 8) {
+      const int s = tid >> 2, b = b_first + s;
+      if (sacc[s][tid & 3] != 0.f) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], (double)sacc[s][tid & 3]);
+    }
+  }
+}
+
+// grid: (tiles_x, tiles_y, B); dsmall fp32 [B][h][w][K], zeroed by the caller
+template <typename T>
+__global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
+                                                           const int64_t* __restrict__ label, const float* __restrict__ keep_thr, int K, int H, int W,
+                                                           const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
+                                                           float* __restrict__ dsmall) {
+  extern __shared__ float ces_lds[];                    // 2 x CES_FP^2 x K floats (launcher): footprint logits, then their gradient
+  float* sin_ = ces_lds;
+  float* sout = ces_lds + CES_FP * CES_FP * K;
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
+  const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
+  // footprint in the small map: floor(s*first) .. floor(s*last) + 1, clamped
+  int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
+  fy0 = min(fy0, h - 1); fx0 = min(fx0, w - 1);
+  int fy1 = min((int)(sh * (float)Y1) + 1, h - 1), fx1 = min((int)(sw * (float)X1) + 1, w - 1);
+  const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;      // <= CES_FP by the launcher's factor check
+  for (int i = tid; i < fh * fw * K; i += 256) {
+    const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
+    sin_[c * K + k] = ElemT<T>::to_f(small[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * ld + k]);
+    sout[c * K + k] = 0.f;
+  }
+  __syncthreads();
+  const float cb = coef[b] * (*gscale);
+  // lane -> pixel mapping: the 64 lanes of a wave take pixels 4 apart in x and y (an 8x8 lattice), so that at up-sampling
+  // factors around 4 they scatter into 64 DIFFERENT small pixels per LDS-atomic instruction (consecutive pixels would hit
+  // the same address 4-way and serialise); the 16 lattice phases are split over the 4 waves x 4 trips
+  for (int trip = 0; trip < 4; ++trip) {
+    const int phase = (tid >> 6) * 4 + trip, lane = tid & 63;
+    const int x = X0 + (lane & 7) * 4 + (phase & 3), y = Y0 + (lane >> 3) * 4 + (phase >> 2);
+    if (x >= W || y >= H) continue;
+    const int64_t lab = label[((size_t)b * H + y) * W + x];
+    if (!(lab >= 0 && lab < K) || cb == 0.f) continue;
+    float fy = sh * (float)y, fx = sw * (float)x;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > h - 1) y0 = h - 1;
+    if (x0 > w - 1) x0 = w - 1;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1, wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    const int c00 = ((y0 - fy0) * fw + (x0 - fx0)) * K, c01 = ((y0 - fy0) * fw + (x1 - fx0)) * K;
+    const int c10 = ((y1 - fy0) * fw + (x0 - fx0)) * K, c11 = ((y1 - fy0) * fw + (x1 - fx0)) * K;
+    const float w00 = wy0 * wx0, w01 = wy0 * wx1, w10 = wy1 * wx0, w11 = wy1 * wx1;
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k)
+      mx = fmaxf(mx, wy0 * (wx0 * sin_[c00 + k] + wx1 * sin_[c01 + k]) + wy1 * (wx0 * sin_[c10 + k] + wx1 * sin_[c11 + k]));
+    float se = 0.f, xg = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float v = wy0 * (wx0 * sin_[c00 + k] + wx1 * sin_[c01 + k]) + wy1 * (wx0 * sin_[c10 + k] + wx1 * sin_[c11 + k]);
+      se += __expf(v - mx);
+      if (k == lab) xg = v;
+    }
+    const float loss = logf(se) + mx - xg;
+    if (keep_thr && !(__expf(xg - mx) / se <= *keep_thr)) continue;
+    if (pos_only && !(loss > 0.f)) continue;
+    const float inv = 1.f / se;
+    for (int k = 0; k < K; ++k) {
+      const float v = wy0 * (wx0 * sin_[c00 + k] + wx1 * sin_[c01 + k]) + wy1 * (wx0 * sin_[c10 + k] + wx1 * sin_[c11 + k]);
+      const float g = cb * (__expf(v - mx) * inv - (k == lab ? 1.f : 0.f));
+      atomicAdd(&sout[c00 + k], w00 * g);
+      if (w01 != 0.f) atomicAdd(&sout[c01 + k], w01 * g);
+      if (w10 != 0.f) atomicAdd(&sout[c10 + k], w10 * g);
+      if (w11 != 0.f) atomicAdd(&sout[c11 + k], w11 * g);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < fh * fw * K; i += 256) {
+    const float v = sout[i];
+    if (v == 0.f) continue;
+    const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
+    atomicAdd(&dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k], v);
+  }
+}
+
 // ---- launchers -----------------------------------------------------------
 static inline int ce_grid(size_t P) {
   size_t g = (P + 255) / 256;
@@ -201,6 +349,39 @@ int css_launch_ohem_threshold(const float* gtprob, long P, const double* stats, 
     hipLaunchKernelGGL(ohem_hist_kernel, dim3(ce_grid((size_t)P)), dim3(256), 0, st, gtprob, (size_t)P, s, shift);
     hipLaunchKernelGGL(ohem_pick_kernel, dim3(1), dim3(64), 0, st, s, shift, thresh);
   }
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
+int css_launch_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
+                            const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, hipStream_t st) {
+  if (K > CE_MAXK || K < 1 || B <= 0) return CSS_ERR_ARG;
+  const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  const size_t P = (size_t)B * H * W;
+  if (dtype == CSS_BF16)
+    hipLaunchKernelGGL(ce_small_fwd_kernel<bf16_t>, dim3(ce_grid(P)), dim3(256), 0, st, (const bf16_t*)small, ld, h, w, sh, sw, label, conf, conf_thr,
+                       keep_thr, K, P, H, W, stats, gtprob_out);
+  else if (dtype == CSS_F32)
+    hipLaunchKernelGGL(ce_small_fwd_kernel<float>, dim3(ce_grid(P)), dim3(256), 0, st, (const float*)small, ld, h, w, sh, sw, label, conf, conf_thr,
+                       keep_thr, K, P, H, W, stats, gtprob_out);
+  else return CSS_ERR_DTYPE;
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
+                            const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, hipStream_t st) {
+  if (K > CE_MAXK || K < 1 || B <= 0) return CSS_ERR_ARG;
+  if (2 * (h - 1) > (H - 1) || 2 * (w - 1) > (W - 1)) return CSS_ERR_ARG;      // needs an up-sampling factor >= 2 (tile footprint)
+  const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  dim3 g(cdiv(W, CES_TW), cdiv(H, CES_TH), B);
+  const size_t lds = (size_t)2 * CES_FP * CES_FP * K * sizeof(float);
+  if (dtype == CSS_BF16)
+    hipLaunchKernelGGL(ce_small_bwd_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
+                       pos_only, dsmall);
+  else if (dtype == CSS_F32)
+    hipLaunchKernelGGL(ce_small_bwd_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
+                       pos_only, dsmall);
+  else return CSS_ERR_DTYPE;
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

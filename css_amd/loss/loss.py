@@ -64,6 +64,62 @@ class _PixelCE(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2).to(in_dtype), None, None, None, None, None
 
 
+class _PixelCESmall(torch.autograd.Function):
+    """The same losses from the LOW-resolution NHWC logits ``small`` [B,h,w,K]: the bilinear(align_corners=True) up-sampling to the
+    label size (ddp_model.py:141,144) is applied on the fly in forward and backward (css_ce_small_*), so the [B,K,H,W] fp32
+    logits and their gradient (2 x 354 MB each way at c2) are never written."""
+
+    @staticmethod
+    def forward(ctx, small, label, conf, conf_thr, mode, ohem):
+        b, h, w, k = small.shape
+        x = small.detach()
+        if x.dtype not in (torch.float32, torch.bfloat16):
+            x = x.float()
+        x = x.contiguous()
+        label = label.contiguous()
+        hh, ww = label.shape[1], label.shape[2]
+        p = b * hh * ww
+        dev, st = dev_stream(x)
+        dc = dtype_code(x.dtype)
+        f64 = dict(dtype=torch.float64, device=x.device)
+        stats = torch.zeros(b * 4, **f64)
+        keep = None
+        if ohem is not None:
+            min_kept, thresh = ohem
+            gtprob = torch.empty(p, dtype=torch.float32, device=x.device)
+            call("css_ce_small_fwd", x, k, b, h, w, label, None, 0.0, None, k, hh, ww, stats, gtprob, dc, dev, st)
+            state = torch.zeros(query("css_ohem_state_bytes"), dtype=torch.uint8, device=x.device)
+            call("css_ohem_threshold", gtprob, p, stats, b, int(min_kept), float(thresh), state, dev, st)
+            keep = state[query("css_ohem_thr_offset"):]
+            stats = torch.zeros(b * 4, **f64)
+            call("css_ce_small_fwd", x, k, b, h, w, label, None, 0.0, keep, k, hh, ww, stats, None, dc, dev, st)
+        else:
+            call("css_ce_small_fwd", x, k, b, h, w, label, conf, float(conf_thr), None, k, hh, ww, stats, None, dc, dev, st)
+        loss = torch.empty(1, dtype=torch.float32, device=x.device)
+        coef = torch.empty(b, dtype=torch.float32, device=x.device)
+        call("css_ce_finalize", stats, b, int(mode), loss, coef, dev, st)
+        ctx.save_for_backward(x, label, coef, keep)
+        ctx.cfg = (mode, small.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, label, coef, keep = ctx.saved_tensors
+        mode, in_dtype = ctx.cfg
+        b, h, w, k = x.shape
+        hh, ww = label.shape[1], label.shape[2]
+        dev, st = dev_stream(x)
+        gs = g.detach().float().reshape(1).contiguous()
+        dx = torch.zeros((b, h, w, k), dtype=torch.float32, device=x.device)
+        call("css_ce_small_bwd", x, k, b, h, w, label, keep, k, hh, ww, coef, gs, int(mode == 1), dx, dtype_code(x.dtype), dev, st)
+        return dx.to(in_dtype), None, None, None, None, None
+
+
+def fused_upsample_ok(small_hw, label_hw):
+    """css_ce_small_bwd's tile footprint assumes an up-sampling factor >= 2 (513/129, 769/193 in the reference's configs)."""
+    return 2 * (small_hw[0] - 1) <= label_hw[0] - 1 and 2 * (small_hw[1] - 1) <= label_hw[1] - 1
+
+
 class CrossEntropyLoss(nn.Module):
     """nn.CrossEntropyLoss(ignore_index=-1) of mix_label.py:81 (mean over non-ignored pixels)."""
 
@@ -75,6 +131,10 @@ class CrossEntropyLoss(nn.Module):
     def forward(self, pred, target):
         return _PixelCE.apply(pred, target, None, 0.0, 0, None)
 
+    def forward_small(self, small, target):
+        """small: the network's NHWC logits [B,h,w,K] before up-sampling; == forward(F.interpolate(.., align_corners=True), target)."""
+        return _PixelCESmall.apply(small, target, None, 0.0, 0, None)
+
 
 class Attention_Threshold_Loss(nn.Module):
     def __init__(self, strong_threshold):
@@ -83,6 +143,9 @@ class Attention_Threshold_Loss(nn.Module):
 
     def forward(self, pred, pseudo_label, logits):
         return _PixelCE.apply(pred, pseudo_label, logits.detach().float().contiguous(), self.strong_threshold, 1, None)
+
+    def forward_small(self, small, pseudo_label, logits):
+        return _PixelCESmall.apply(small, pseudo_label, logits.detach().float().contiguous(), self.strong_threshold, 1, None)
 
 
 class ProbOhemCrossEntropy2d(nn.Module):
@@ -93,6 +156,9 @@ class ProbOhemCrossEntropy2d(nn.Module):
 
     def forward(self, pred, target):
         return _PixelCE.apply(pred, target, None, 0.0, 0, (self.min_kept, self.thresh))
+
+    def forward_small(self, small, target):
+        return _PixelCESmall.apply(small, target, None, 0.0, 0, (self.min_kept, self.thresh))
 
 
 # --------------------------------------------------------------------------

@@ -108,10 +108,15 @@ class _StudentTeacher(nn.Module):
     def _teacher(self, x):
         return self.ema_model.forward_nhwc(ops.stage_input(x, self.ema_model.compute_dtype))
 
-    def _student_pair(self, xl, xu, out_hw):
-        """-> pred [2B,h,w,K], rep_all [2B,h,w,C] (labeled first), pred_l_large, pred_u_large (logical NCHW, fp32)."""
+    def _student_pair(self, xl, xu, out_hw, small=False):
+        """-> pred [2B,h,w,K], rep_all [2B,h,w,C] (labeled first), pred_l_large, pred_u_large (logical NCHW, fp32).
+        ``small=True`` (fused trainer): the last two are the two halves of the LOW-resolution NHWC logits instead - the losses then
+        up-sample on the fly (loss._PixelCESmall) and the full-resolution logits are never materialised."""
         with ops.bn_groups(2):
             pred, rep = self.model.forward_nhwc(ops.stage_inputs([xl, xu], self.model.compute_dtype))
+        if small:
+            sl, su = ops.split2(pred, xl.shape[0])
+            return pred, rep, sl, su
         large = ops.bilinear(pred, out_hw[0], out_hw[1], torch.float32)     # align_corners=True, ddp_model.py:141,144
         ll, lu = ops.split2(large, xl.shape[0])
         return pred, rep, ll.permute(0, 3, 1, 2), lu.permute(0, 3, 1, 2)
@@ -123,7 +128,7 @@ class Model_mix(_StudentTeacher):
         self._init_common(base_encoder, num_classes, output_dim, ema_alpha, config)
         self.temp = temp
 
-    def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True):
+    def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
@@ -135,7 +140,7 @@ class Model_mix(_StudentTeacher):
             u_img, u_lab, u_lc, u_lr = generate_cut_gather_2(u_img, u_lab, u_lc, u_lr, mode=cfg["mix_mode"])
             u_img, u_lab, u_lc, u_lr = batch_transform_2(u_img, u_lab, u_lc, u_lr, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                          augmentation=True)
-        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
+        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
         prob_all = None
         if _want_prob:                                                     # the trainer derives the hard flags directly instead
             with torch.no_grad():

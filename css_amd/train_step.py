@@ -22,7 +22,7 @@ import torch.distributed as dist
 from . import functional as Fn
 from . import ops
 from ._lib import call, dev_stream
-from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d
+from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d, fused_upsample_ok
 from .scheduler.my_lr_scheduler import poly_lr
 
 
@@ -40,6 +40,7 @@ class MixTrainer:
         self.crit_contrast = Contrast_Loss(num_queries, num_negatives, temp=temp_loss, strong_threshold=strong_threshold, alpha=alpha_proto)
         dev = next(model.parameters()).device
         self.prototypes = torch.zeros(num_classes, output_dim, device=dev)     # mix_label.py:93
+        self.fused_loss = True     # CE / unsup / OHEM with the bilinear up-sampling folded in (no [B,K,H,W] logits)
         self.it = 0
         self.flat_p, self.flat_ema = model._ensure_flat()
         self.flat_g = torch.zeros_like(self.flat_p)
@@ -59,9 +60,16 @@ class MixTrainer:
     def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
         m = self.model
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
-        pred_l_large, pred_u_large, u_lab, u_lc, u_lr, rep_all, _ = m.forward(l_img, u_img, self.prototypes, _want_prob=False)
-        sup = (self.crit_ohem or self.crit_ce)(pred_l_large, l_lab)
-        unsup = self.crit_unsup(pred_u_large, u_lab, u_lc)
+        # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
+        # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144
+        pred_l, pred_u, u_lab, u_lc, u_lr, rep_all, _ = m.forward(l_img, u_img, self.prototypes, _want_prob=False, _small_logits=True)
+        if self.fused_loss and fused_upsample_ok(pred_l.shape[1:3], l_img.shape[2:]):
+            sup = (self.crit_ohem or self.crit_ce).forward_small(pred_l, l_lab)
+            unsup = self.crit_unsup.forward_small(pred_u, u_lab, u_lc)
+        else:
+            hh, ww = l_img.shape[2:]
+            sup = (self.crit_ohem or self.crit_ce)(ops.bilinear(pred_l, hh, ww, torch.float32).permute(0, 3, 1, 2), l_lab)
+            unsup = self.crit_unsup(ops.bilinear(pred_u, hh, ww, torch.float32).permute(0, 3, 1, 2), u_lab, u_lc)
         b2, c, h, w = rep_all.shape
         rep_rows = rep_all.permute(0, 2, 3, 1).reshape(b2 * h * w, c)         # zero-copy: rep_all is NHWC memory
         with torch.no_grad():

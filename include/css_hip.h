@@ -171,6 +171,15 @@ CSS_API int css_ce_fwd(const float* logits, const int64_t* label, const float* c
 CSS_API int css_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream);
 CSS_API int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef,
                        const float* gscale, int pos_only, float* dlogits, int device, css_stream_t stream);
+/* the same losses computed straight from the LOW-resolution logits small [B][h][w][ld] (bf16 / fp32): the bilinear
+ * (align_corners=True) up-sampling to the label size [B][H][W] of ddp_model.py:141,144 is applied on the fly, forward and
+ * adjoint, so the [B,K,H,W] logits and their gradient are never materialised.  css_ce_small_bwd ACCUMULATES into dsmall
+ * (fp32 [B][h][w][K], zero it first) and needs an up-sampling factor >= 2.  Same stats / coef / keep_thr protocol as above. */
+CSS_API int css_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
+                             const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, int device,
+                             css_stream_t stream);
+CSS_API int css_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
+                             const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, int device, css_stream_t stream);
 CSS_API size_t css_ohem_state_bytes(void);
 CSS_API size_t css_ohem_thr_offset(void);
 CSS_API int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,

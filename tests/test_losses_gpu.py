@@ -292,3 +292,49 @@ def test_contrast_sampler_distribution():
     neg2 = torch.zeros(K * Q * N, **i32)
     call("css_contrast_sample", protos_g, C, meta, 0.5, cdf, listV, listH, Q, N, 1234, 2, anchor2, neg2, dv, st)
     assert (neg2.cpu().view(K, Q, N)[0] != neg[0]).float().mean() > 0.5
+
+
+# ---- losses with the bilinear up-sampling folded in (css_ce_small_*) ----------------------------------------------------
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("kind", ["ce", "attention", "ohem"])
+@pytest.mark.parametrize("geom", [(2, 21, 17, 17, 65, 65), (3, 19, 9, 13, 33, 49), (1, 21, 33, 33, 129, 129)])
+def test_losses_from_low_resolution_logits(geom, kind, dtype):
+    """loss(small) == loss(F.interpolate(small, align_corners=True)) and so are the gradients w.r.t. the small logits: the fused
+    kernels against the materialising path (bilinear op + full-resolution loss), which is itself pinned to the reference."""
+    from css_amd import ops
+    from css_amd.loss.loss import Attention_Threshold_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d
+    b, k, h, w, hh, ww = geom
+    g = torch.Generator().manual_seed(b * 100 + k)
+    small = (torch.randn(b, h, w, k, generator=g) * 2).to(dev(), dtype)
+    lab = torch.randint(-1, k, (b, hh, ww), generator=g).to(dev())
+    conf = torch.rand(b, hh, ww, generator=g).to(dev())
+    if kind == "ce":
+        crit = CrossEntropyLoss(-1)
+        args = (lab,)
+    elif kind == "attention":
+        crit = Attention_Threshold_Loss(0.6)
+        args = (lab, conf)
+    else:
+        crit = ProbOhemCrossEntropy2d(-1, thresh=0.7, min_kept=(b * hh * ww) // 5)
+        args = (lab,)
+    s1 = small.clone().requires_grad_(True)
+    l1 = crit.forward_small(s1, *args)
+    l1.backward()
+    s0 = small.clone().requires_grad_(True)
+    l0 = crit(ops.bilinear(s0, hh, ww, torch.float32).permute(0, 3, 1, 2), *args)
+    l0.backward()
+    assert abs(float(l1) - float(l0)) < 2e-6 * max(1.0, abs(float(l0)))
+    tol = 2e-5 if dtype == torch.float32 else 1e-2          # bf16: the gradient itself is rounded to bf16 on both paths
+    assert rel_err(s1.grad.float().cpu(), s0.grad.float().cpu()) < tol
+    assert torch.isfinite(s1.grad.float()).all()
+
+
+def test_fused_loss_rejects_small_upsampling_factors():
+    from css_amd._lib import CssHipError
+    from css_amd.loss.loss import CrossEntropyLoss, fused_upsample_ok
+    assert fused_upsample_ok((129, 129), (513, 513)) and fused_upsample_ok((193, 193), (769, 769)) and not fused_upsample_ok((33, 33), (40, 40))
+    small = torch.randn(1, 33, 33, 5, device=dev(), requires_grad=True)
+    lab = torch.zeros(1, 40, 40, dtype=torch.int64, device=dev())
+    loss = CrossEntropyLoss(-1).forward_small(small, lab)          # forward works for any factor
+    with pytest.raises(CssHipError):
+        loss.backward()
