@@ -13,7 +13,7 @@ section 8f-1).  Two modes, chosen by ``config['Dataset']['device_aug']`` (``aug_
     (``draw_params``) - a few numbers per image.
 Mixing (both modes): ``none`` | ``cutmix`` | ``cutout`` with the reference's box law (VOC.py:518-534) and partner
 ``(i+1) % B`` (VOC.py:428), boxes drawn on the host with numpy like the reference and applied by torch indexing on the device
-(classmix is not implemented on the device).
+classmix (VOC.py:505-510,430-437) with torch ops on the device.
 """
 from __future__ import annotations
 
@@ -84,23 +84,37 @@ def cutout_box(h, w, ratio=2, rng=np.random):
     return int(y0), int(y0 + bh), int(x0), int(x0 + bw)
 
 
+def class_mask(pseudo_labels: torch.Tensor, generator=None) -> torch.Tensor:
+    """generate_class_mask (VOC.py:505-510): 1 where the pixel's label is one of a random half of the image's labels."""
+    labels = torch.unique(pseudo_labels)
+    perm = torch.randperm(len(labels), generator=generator).to(labels.device)
+    select = labels[perm][: len(labels) // 2]
+    return (pseudo_labels.unsqueeze(-1) == select).any(dim=-1)
+
+
 def _mix(tensors, mode, rng):
     image = tensors[0]
     b, _, h, w = image.shape
     if mode == "none":
         return tensors
+    if mode not in ("cutmix", "cutout", "classmix"):
+        raise ValueError("mode must be in none, cutout, cutmix, or classmix")
     outs = [t.clone() for t in tensors]
     for i in range(b):
-        y0, y1, x0, x1 = cutout_box(h, w, 2, rng)
         j = (i + 1) % b
-        for k, (t, o) in enumerate(zip(tensors, outs)):
+        if mode == "classmix":
+            # image i where the mask is 1, partner elsewhere (VOC.py:430-437); tensors[1] is the (first) label map
+            keep = class_mask(tensors[1][i])
+            for t, o in zip(tensors, outs):
+                o[i] = torch.where(keep if t.dim() == 3 else keep.unsqueeze(0), t[i], t[j])
+            continue
+        y0, y1, x0, x1 = cutout_box(h, w, 2, rng)
+        for t, o in zip(tensors, outs):
             if mode == "cutmix":
                 o[i, ..., y0:y1, x0:x1] = t[j, ..., y0:y1, x0:x1]
-            elif mode == "cutout":
+            else:
                 is_label = t.dtype == torch.int64
                 o[i, ..., y0:y1, x0:x1] = -1 if is_label else 0
-            else:
-                raise ValueError("mode must be none, cutout or cutmix (classmix is not implemented on the device)")
     return outs
 
 

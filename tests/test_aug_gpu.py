@@ -158,3 +158,36 @@ def test_model_mix_with_device_augmentation():
         assert float(((t * 255) - (t * 255).round()).abs().max()) < 1e-4
     (pl.mean() + pu.mean() + rep_all.pow(2).mean()).backward()
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.model.parameters())
+
+
+def test_mixing_modes_on_device():
+    """cutmix / cutout boxes follow generate_cutout_mask (half the area, VOC.py:518-534); classmix keeps a random half of the
+    image's classes and takes the partner (i+1) % B elsewhere (VOC.py:505-510,430-437)."""
+    import numpy as np
+    from css_amd.dataset_helpers import gpu_aug
+    g = torch.Generator().manual_seed(1)
+    b, h, w = 3, 20, 28
+    img = torch.randn(b, 3, h, w, generator=g).to(dev())
+    lab = torch.randint(0, 6, (b, h, w), generator=g).to(dev())
+    l1, l2 = torch.rand(b, h, w, generator=g).to(dev()), torch.rand(b, h, w, generator=g).to(dev())
+    for mode in ("cutmix", "cutout"):
+        oi, ol, o1, o2 = gpu_aug.generate_cut_gather_2(img, lab, l1, l2, mode=mode, rng=np.random.RandomState(3))
+        for i in range(b):
+            changed = (ol[i] != lab[i]) | (o1[i] != l1[i])
+            ys, xs = changed.nonzero(as_tuple=True)
+            area = (int(ys.max()) - int(ys.min()) + 1) * (int(xs.max()) - int(xs.min()) + 1)
+            assert abs(area - h * w / 2) <= w                      # the box covers half the image (up to rounding of its height)
+            if mode == "cutout":
+                assert int(ol[i][changed].max()) == -1 and float(oi[i][:, changed].abs().max()) == 0
+            else:
+                j = (i + 1) % b
+                assert torch.equal(oi[i][:, changed], img[j][:, changed]) and torch.equal(ol[i][changed], lab[j][changed])
+    torch.manual_seed(5)
+    oi, ol, o1, o2 = gpu_aug.generate_cut_gather_2(img, lab, l1, l2, mode="classmix")
+    for i in range(b):
+        j = (i + 1) % b
+        own = (ol[i] == lab[i]) & (o1[i] == l1[i])
+        kept = torch.unique(lab[i][(o1[i] == l1[i]) & (o1[i] != l1[j])])
+        assert len(kept) == len(torch.unique(lab[i])) // 2            # half of the image's classes survive
+        other = ~((o1[i] == l1[i]) & (o1[i] != l1[j]))
+        assert torch.equal(o2[i][other], l2[j][other]) and torch.equal(oi[i][:, other], img[j][:, other])
