@@ -41,4 +41,14 @@ class ASPP(nn.Module):
         self.project = ConvBNReLU(HipConv2d(5 * out_channels, out_channels, 1, bias=False), HipBatchNorm2d(out_channels))
 
     def forward(self, x):
+        import torch
+        if torch.is_grad_enabled() and x.requires_grad:
+            # x feeds five branches; chaining the four convolutions through their input taps (ops.conv2d) makes every branch's
+            # dgrad add the gradient accumulated so far in its own store pass instead of four torch adds over 554 MB tensors
+            outs, cur = [], x
+            for m in list(self.convs)[:-1]:
+                y, cur = m[0](cur, tap=True)
+                outs.append(m[1](y, relu=True))
+            outs.append(self.convs[-1](cur))
+            return self.project(ops.cat_channels(*outs))
         return self.project(ops.cat_channels(*[conv(x) for conv in self.convs]))

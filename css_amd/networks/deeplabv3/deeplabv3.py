@@ -25,7 +25,10 @@ class _Head(nn.Sequential):
         super().__init__(HipConv2d(cin, 256, 3, padding=1, bias=False), HipBatchNorm2d(256), nn.ReLU(),
                          HipConv2d(256, cout, 1))
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
+        if tap:      # also hand back the input alias whose gradient this head's first dgrad absorbs (ops.conv2d)
+            y, xa = self[0](x, tap=True)
+            return self[3](self[1](y, relu=True)), xa
         return self[3](self[1](self[0](x), relu=True))
 
 
@@ -80,13 +83,21 @@ class DeepLabv3Plus_with_rep(nn.Module):
         x = self.resnet_bn1(self.resnet_conv1(x), relu=True)
         x = self.resnet_maxpool(x)
         x_low = self.resnet_layer1(x)
+        fuse = torch.is_grad_enabled() and x_low.requires_grad    # fold fan-out gradient sums into dgrad store passes (ops.conv2d taps)
+        if fuse:
+            p, x_low = self.project[0](x_low, tap=True)
+            low = self.project[1](p, relu=True)
+        else:
+            low = self.project(x_low)
         x = self.resnet_layer2(x_low)
         x = self.resnet_layer3(x)
         x = self.resnet_layer4(x)
         feature = self.ASPP(x)
-        x_low = self.project(x_low)
-        up = ops.bilinear(feature, x_low.shape[1], x_low.shape[2])
-        dec = ops.cat_channels(x_low, up)
+        up = ops.bilinear(feature, low.shape[1], low.shape[2])
+        dec = ops.cat_channels(low, up)
+        if fuse:
+            pred, dec = self.classifier(dec, tap=True)
+            return pred, self.representation(dec)
         return self.classifier(dec), self.representation(dec)
 
     def forward(self, x):

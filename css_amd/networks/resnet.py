@@ -44,10 +44,11 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        if self.downsample is None and torch.is_grad_enabled() and x.requires_grad:
-            # x feeds conv1 AND the residual: take the identity from conv1's tap so that the backward adds the residual
-            # gradient inside conv1's dgrad store (ops.conv2d)
+        if torch.is_grad_enabled() and x.requires_grad:
+            # x feeds conv1 AND the residual branch (identity, or the downsample convolution): take that branch's input from
+            # conv1's tap so that the backward adds its gradient inside conv1's dgrad store (ops.conv2d)
             out, identity = self.conv1(x, tap=True)
+            x = identity
         else:
             out = self.conv1(x)
         out = self.bn1(out, relu=True)
