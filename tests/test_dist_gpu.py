@@ -108,3 +108,59 @@ def test_two_ranks_bf16_fused_statistics_path(tmp_path):
     assert torch.isfinite(g2).all() and torch.nn.functional.cosine_similarity(g1, g2, dim=0) > 0.8   # bf16 through 100+ layers: 0.89 measured
     rm1, rm2 = torch.tensor(r1["rm"]), torch.tensor(r2["rm"])
     assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 2e-2
+
+
+TRAINER_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from css_amd.networks import resnet
+from css_amd.networks.ddp_model import Model_mix
+from css_amd.train_step import MixTrainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+K, S = 21, 65
+torch.manual_seed(11)                                   # same initial weights on every rank (DDP broadcasts rank 0's)
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix"}}
+m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
+m.model.train(); m.ema_model.train()
+m.set_compute_dtype(torch.bfloat16)
+tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
+g = torch.Generator().manual_seed(100 + rank)           # different data per rank
+losses = []
+for it in range(2):
+    l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
+    u = torch.randn(2, 3, S, S, generator=g).to(dev)
+    out = tr.step(l, y, u)
+    losses.append([float(out["sup"]), float(out["contrast"])])
+probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
+ema = tr.flat_ema[:: tr.flat_ema.numel() // 4096][:4096].double().cpu()
+proto = tr.prototypes.double().cpu()
+rm = m.model.resnet_bn1.running_mean.double().cpu()
+json.dump(dict(losses=losses, p=probe.tolist(), ema=ema.tolist(), proto=proto.flatten().tolist(), rm=rm.tolist()), open(sys.argv[1] + str(rank), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
+    """MixTrainer.step on two ranks (bf16, different data per rank): SyncBN statistics, the prototype class sums and the flat
+    gradient are all-reduced, so after two steps both replicas hold the same parameters, EMA teacher, BN running statistics and
+    prototypes (for the classes both ranks see) - the data-parallel contract of mix_label.py:76-77."""
+    import json
+    import torch
+    out = str(tmp_path / "r")
+    code = TRAINER_WORKER % ROOT
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+        procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    a, b = json.load(open(out + "0")), json.load(open(out + "1"))
+    # (the unsupervised term is NaN-valued with zero gradient when no pseudo-label is confident, like the reference: SURVEY L2)
+    assert all(v == v and abs(v) < 1e3 for l in a["losses"] + b["losses"] for v in l), (a["losses"], b["losses"])
+    pa, pb = torch.tensor(a["p"]), torch.tensor(b["p"])
+    assert torch.equal(pa, pb), float((pa - pb).abs().max())                         # same summed gradient -> same update
+    assert torch.equal(torch.tensor(a["ema"]), torch.tensor(b["ema"]))
+    assert torch.equal(torch.tensor(a["rm"]), torch.tensor(b["rm"]))                 # SyncBN: global statistics on both ranks
