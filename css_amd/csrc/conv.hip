@@ -1332,7 +1332,15 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.m_begin = full_mt * 256;
         P0(false, (double)(b.M - b.m_begin) / a.M);
-        hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128)), dim3(256), 0, st, b);
+        {
+          // few leftover tiles: halve their width so that twice as many CUs share the (latency-bound) K loop
+          static const int rem_mode = getenv("CSS_REM_N64") ? atoi(getenv("CSS_REM_N64")) : 1;
+          const int wgs128 = cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128);
+          if ((rem_mode == 1 && wgs128 * 2 <= n_cu) || (rem_mode == 2 && wgs128 <= n_cu))
+            hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), dim3(256), 0, st, b);
+          else
+            hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(wgs128), dim3(256), 0, st, b);
+        }
         P1();
       }
     } else if (a.Cd > 64 && !no_dma) {
