@@ -57,14 +57,44 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
   if (tid < CT_MAXK) cnt[tid] = 0.f;
   __syncthreads();
   const int p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
-  constexpr int EPL = C / 64;
-  for (int p = p0 + wave; p < p1; p += 4) {
-    const int c = cls[p];
-    if (c < 0) continue;
-    const T* row = rep + (size_t)p * ld + lane * EPL;
+  constexpr int EPL = C / 64, UN = 8;
+  // UN pixel rows in flight per wave (one row at a time was a chain of 256 dependent ~1.5 us loads per wave: 0.6 ms)
+  for (int pb = p0 + wave; pb < p1; pb += 4 * UN) {
+    int c[UN];
+    T v[UN][EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; ++e) atomicAdd(&acc[c * C + lane * EPL + e], (float)row[e]);
-    if (lane == 0) atomicAdd(&cnt[c], 1.f);
+    for (int u = 0; u < UN; ++u) {
+      const int p = pb + 4 * u;
+      c[u] = p < p1 ? cls[p] : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int p = pb + 4 * u;
+      if (c[u] >= 0) {
+        const T* row = rep + (size_t)p * ld + lane * EPL;
+        if constexpr (sizeof(T) * EPL == 8) {            // one 8-byte load per lane instead of four 2-byte ones
+          union { uint2 u2; T e[EPL]; } pk;
+          pk.u2 = *reinterpret_cast<const uint2*>(row);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[u][e] = pk.e[e];
+        } else if constexpr (sizeof(T) * EPL == 16) {
+          union { uint4 u4; T e[EPL]; } pk;
+          pk.u4 = *reinterpret_cast<const uint4*>(row);
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[u][e] = pk.e[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < EPL; ++e) v[u][e] = row[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      if (c[u] < 0) continue;
+#pragma unroll
+      for (int e = 0; e < EPL; ++e) atomicAdd(&acc[c[u] * C + lane * EPL + e], (float)v[u][e]);
+      if (lane == 0) atomicAdd(&cnt[c[u]], 1.f);
+    }
   }
   __syncthreads();
   for (int i = tid; i < K * C; i += 256)
