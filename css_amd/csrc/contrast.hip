@@ -50,18 +50,22 @@ __global__ __launch_bounds__(256) void contrast_classify_kernel(const float* __r
 template <typename T, int C>
 __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __restrict__ rep, int ld, const int* __restrict__ cls, int P, int K,
                                                                   int pix_per_block, double* __restrict__ out) {
-  __shared__ float acc[CT_MAXK * C];
-  __shared__ float cnt[CT_MAXK];
+  // every wave owns a private [K][C] fp32 accumulator in LDS and a lane owns 4 channels of it: plain 16-byte
+  // read-modify-write, no atomics (LDS float atomics made this kernel 0.63 ms; a wave's LDS operations execute in order, so
+  // consecutive rows of the same class are safe)
+  extern __shared__ float cs_lds[];                       // [4 waves][K*C] then [4][CT_MAXK] counts
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < K * C; i += 256) acc[i] = 0.f;
-  if (tid < CT_MAXK) cnt[tid] = 0.f;
+  float* acc = cs_lds + (size_t)wave * K * C;
+  float* cnt = cs_lds + (size_t)4 * K * C + wave * CT_MAXK;
+  for (int i = lane; i < K * C; i += 64) acc[i] = 0.f;
+  if (lane < CT_MAXK) cnt[lane] = 0.f;
   __syncthreads();
   const int p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
   constexpr int EPL = C / 64, UN = 8;
-  // UN pixel rows in flight per wave (one row at a time was a chain of 256 dependent ~1.5 us loads per wave: 0.6 ms)
+  static_assert(EPL == 4, "a lane owns one float4 of the accumulator row");
   for (int pb = p0 + wave; pb < p1; pb += 4 * UN) {
     int c[UN];
-    T v[UN][EPL];
+    float v[UN][EPL];
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       const int p = pb + 4 * u;
@@ -72,34 +76,37 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
       const int p = pb + 4 * u;
       if (c[u] >= 0) {
         const T* row = rep + (size_t)p * ld + lane * EPL;
-        if constexpr (sizeof(T) * EPL == 8) {            // one 8-byte load per lane instead of four 2-byte ones
+        if constexpr (sizeof(T) == 2) {
           union { uint2 u2; T e[EPL]; } pk;
           pk.u2 = *reinterpret_cast<const uint2*>(row);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) v[u][e] = pk.e[e];
-        } else if constexpr (sizeof(T) * EPL == 16) {
-          union { uint4 u4; T e[EPL]; } pk;
-          pk.u4 = *reinterpret_cast<const uint4*>(row);
-#pragma unroll
-          for (int e = 0; e < EPL; ++e) v[u][e] = pk.e[e];
+          for (int e = 0; e < EPL; ++e) v[u][e] = (float)pk.e[e];
         } else {
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) v[u][e] = row[e];
+          for (int e = 0; e < EPL; ++e) v[u][e] = (float)row[e];
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (c[u] < 0) continue;
-#pragma unroll
-      for (int e = 0; e < EPL; ++e) atomicAdd(&acc[c[u] * C + lane * EPL + e], (float)v[u][e]);
-      if (lane == 0) atomicAdd(&cnt[c[u]], 1.f);
+      float4* a4 = reinterpret_cast<float4*>(acc + c[u] * C + lane * EPL);
+      float4 a = *a4;
+      a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3];
+      *a4 = a;
+      if (lane == 0) cnt[c[u]] += 1.f;
     }
   }
   __syncthreads();
-  for (int i = tid; i < K * C; i += 256)
-    if (acc[i] != 0.f) atomicAdd(&out[i], (double)acc[i]);
-  if (tid < K && cnt[tid] != 0.f) atomicAdd(&out[(size_t)K * C + tid], (double)cnt[tid]);
+  for (int i = tid; i < K * C; i += 256) {
+    const float t = (cs_lds[i] + cs_lds[(size_t)K * C + i]) + (cs_lds[(size_t)2 * K * C + i] + cs_lds[(size_t)3 * K * C + i]);
+    if (t != 0.f) atomicAdd(&out[i], (double)t);
+  }
+  if (tid < K) {
+    const float* cb = cs_lds + (size_t)4 * K * C;
+    const float t = (cb[tid] + cb[CT_MAXK + tid]) + (cb[2 * CT_MAXK + tid] + cb[3 * CT_MAXK + tid]);
+    if (t != 0.f) atomicAdd(&out[(size_t)K * C + tid], (double)t);
+  }
 }
 
 // ---- 3. stable compaction ----------------------------------------------------------------------
@@ -455,11 +462,12 @@ int css_launch_contrast_classify(const float* label, const float* mask, const fl
 }
 int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, hipStream_t st) {
   if (K > CT_MAXK || C != 256) return CSS_ERR_ARG;
-  const int ppb = 1024;
+  const int ppb = 2048;
+  const size_t lds = ((size_t)4 * K * C + 4 * CT_MAXK) * sizeof(float);     // 86 KiB at K = 21: one workgroup per CU
   if (dtype == CSS_BF16)
-    hipLaunchKernelGGL((contrast_class_sums_kernel<bf16_t, 256>), dim3(cdiv(P, ppb)), dim3(256), 0, st, (const bf16_t*)rep, ld, cls, P, K, ppb, out);
+    hipLaunchKernelGGL((contrast_class_sums_kernel<bf16_t, 256>), dim3(cdiv(P, ppb)), dim3(256), lds, st, (const bf16_t*)rep, ld, cls, P, K, ppb, out);
   else if (dtype == CSS_F32)
-    hipLaunchKernelGGL((contrast_class_sums_kernel<float, 256>), dim3(cdiv(P, ppb)), dim3(256), 0, st, (const float*)rep, ld, cls, P, K, ppb, out);
+    hipLaunchKernelGGL((contrast_class_sums_kernel<float, 256>), dim3(cdiv(P, ppb)), dim3(256), lds, st, (const float*)rep, ld, cls, P, K, ppb, out);
   else return CSS_ERR_DTYPE;
   CSS_CHECK_LAUNCH();
   return CSS_OK;
