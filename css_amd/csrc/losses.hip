@@ -244,10 +244,17 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
                                                            const int64_t* __restrict__ label, const float* __restrict__ keep_thr, int K, int H, int W,
                                                            const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
-                                                           float* __restrict__ dsmall) {
-  extern __shared__ float ces_lds[];                    // 2 x CES_FP^2 x K floats (launcher): footprint logits, then their gradient
+                                                           float* __restrict__ dsmall, int use_rmw) {
+  // LDS (launcher): the footprint's logits, then FOUR gradient copies (one per wave).  LDS float atomics are slow on this
+  // part, so a wave scatters with plain read-modify-write into its own copy; that is race-free because the lattice mapping
+  // below sends the 64 lanes of an instruction to 64 different small pixels whenever the up-sampling factor is <= 4
+  // (`rmw`); larger factors fall back to atomics on copy 0.
+  extern __shared__ float ces_lds[];
   float* sin_ = ces_lds;
-  float* sout = ces_lds + CES_FP * CES_FP * K;
+  const int FPK = CES_FP * CES_FP * K;
+  const bool rmw = use_rmw != 0;                        // launcher: factor <= 4 and five copies fit in LDS
+  const int ncopy = rmw ? 4 : 1;
+  float* sout = ces_lds + FPK + (rmw ? (threadIdx.x >> 6) * FPK : 0);
   const int tid = threadIdx.x, b = blockIdx.z;
   const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
   const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
@@ -259,8 +266,8 @@ __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__
   for (int i = tid; i < fh * fw * K; i += 256) {
     const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
     sin_[c * K + k] = ElemT<T>::to_f(small[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * ld + k]);
-    sout[c * K + k] = 0.f;
   }
+  for (int i = tid; i < ncopy * FPK; i += 256) ces_lds[FPK + i] = 0.f;
   __syncthreads();
   const float cb = coef[b] * (*gscale);
   // lane -> pixel mapping: the 64 lanes of a wave take pixels 4 apart in x and y (an 8x8 lattice), so that at up-sampling
@@ -297,15 +304,23 @@ __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__
     for (int k = 0; k < K; ++k) {
       const float v = wy0 * (wx0 * sin_[c00 + k] + wx1 * sin_[c01 + k]) + wy1 * (wx0 * sin_[c10 + k] + wx1 * sin_[c11 + k]);
       const float g = cb * (__expf(v - mx) * inv - (k == lab ? 1.f : 0.f));
-      atomicAdd(&sout[c00 + k], w00 * g);
-      if (w01 != 0.f) atomicAdd(&sout[c01 + k], w01 * g);
-      if (w10 != 0.f) atomicAdd(&sout[c10 + k], w10 * g);
-      if (w11 != 0.f) atomicAdd(&sout[c11 + k], w11 * g);
+      if (rmw) {
+        sout[c00 + k] += w00 * g;
+        if (w01 != 0.f) sout[c01 + k] += w01 * g;
+        if (w10 != 0.f) sout[c10 + k] += w10 * g;
+        if (w11 != 0.f) sout[c11 + k] += w11 * g;
+      } else {
+        atomicAdd(&sout[c00 + k], w00 * g);
+        if (w01 != 0.f) atomicAdd(&sout[c01 + k], w01 * g);
+        if (w10 != 0.f) atomicAdd(&sout[c10 + k], w10 * g);
+        if (w11 != 0.f) atomicAdd(&sout[c11 + k], w11 * g);
+      }
     }
   }
   __syncthreads();
   for (int i = tid; i < fh * fw * K; i += 256) {
-    const float v = sout[i];
+    const float* so = ces_lds + FPK;
+    const float v = rmw ? (so[i] + so[FPK + i]) + (so[2 * FPK + i] + so[3 * FPK + i]) : so[i];
     if (v == 0.f) continue;
     const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
     atomicAdd(&dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k], v);
@@ -374,13 +389,15 @@ int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, cons
   if (2 * (h - 1) > (H - 1) || 2 * (w - 1) > (W - 1)) return CSS_ERR_ARG;      // needs an up-sampling factor >= 2 (tile footprint)
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   dim3 g(cdiv(W, CES_TW), cdiv(H, CES_TH), B);
-  const size_t lds = (size_t)2 * CES_FP * CES_FP * K * sizeof(float);
+  const size_t fpk = (size_t)CES_FP * CES_FP * K * sizeof(float);
+  const int use_rmw = sh >= 0.2499f && sw >= 0.2499f && 5 * fpk <= 152 * 1024;   // logits + four per-wave gradient copies (133 KiB at K = 21)
+  const size_t lds = (use_rmw ? 5 : 2) * fpk;
   if (dtype == CSS_BF16)
     hipLaunchKernelGGL(ce_small_bwd_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
-                       pos_only, dsmall);
+                       pos_only, dsmall, use_rmw);
   else if (dtype == CSS_F32)
     hipLaunchKernelGGL(ce_small_bwd_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
-                       pos_only, dsmall);
+                       pos_only, dsmall, use_rmw);
   else return CSS_ERR_DTYPE;
   CSS_CHECK_LAUNCH();
   return CSS_OK;

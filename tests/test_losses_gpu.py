@@ -297,7 +297,9 @@ def test_contrast_sampler_distribution():
 # ---- losses with the bilinear up-sampling folded in (css_ce_small_*) ----------------------------------------------------
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("kind", ["ce", "attention", "ohem"])
-@pytest.mark.parametrize("geom", [(2, 21, 17, 17, 65, 65), (3, 19, 9, 13, 33, 49), (1, 21, 33, 33, 129, 129)])
+@pytest.mark.parametrize("geom", [(2, 21, 17, 17, 65, 65), (3, 19, 9, 13, 33, 49), (1, 21, 33, 33, 129, 129),
+                                  (1, 5, 9, 9, 65, 65),       # up-sampling factor 8: LDS-atomic fallback of the backward
+                                  (1, 30, 9, 9, 33, 33)])     # K too large for the per-wave copies: fallback as well
 def test_losses_from_low_resolution_logits(geom, kind, dtype):
     """loss(small) == loss(F.interpolate(small, align_corners=True)) and so are the gradients w.r.t. the small logits: the fused
     kernels against the materialising path (bilinear op + full-resolution loss), which is itself pinned to the reference."""
