@@ -21,11 +21,11 @@ class ASPPPooling(nn.Sequential):
         super().__init__(nn.AdaptiveAvgPool2d(1), HipConv2d(in_channels, out_channels, 1, bias=False),
                          HipBatchNorm2d(out_channels), nn.ReLU())
 
-    def forward(self, x):
+    def forward(self, x, out_into=None):
         h, w = x.shape[1], x.shape[2]
         p = ops.global_avg_pool(x)
         p = self[2](self[1](p), relu=True)
-        return ops.broadcast_hw(p, h, w)   # bilinear(align_corners=False) from a 1x1 map == broadcast
+        return ops.broadcast_hw(p, h, w, out_into)   # bilinear(align_corners=False) from a 1x1 map == broadcast
 
 
 class ASPP(nn.Module):
@@ -42,13 +42,20 @@ class ASPP(nn.Module):
 
     def forward(self, x):
         import torch
-        if torch.is_grad_enabled() and x.requires_grad:
-            # x feeds five branches; chaining the four convolutions through their input taps (ops.conv2d) makes every branch's
-            # dgrad add the gradient accumulated so far in its own store pass instead of four torch adds over 554 MB tensors
-            outs, cur = [], x
-            for m in list(self.convs)[:-1]:
+        # the five branches write their outputs straight into the channel slices of ONE [N,H,W,1280] buffer (no concat copies,
+        # and the backward reads each slice of the gradient in place)
+        n, h, w, _ = x.shape
+        oc = self.project[0].in_channels // len(self.convs)
+        buf = torch.empty((n, h, w, oc * len(self.convs)), dtype=x.dtype, device=x.device)
+        chain = torch.is_grad_enabled() and x.requires_grad
+        # x feeds five branches; chaining the four convolutions through their input taps (ops.conv2d) makes every branch's
+        # dgrad add the gradient accumulated so far in its own store pass instead of four torch adds over 554 MB tensors
+        outs, cur = [], x
+        for i, m in enumerate(list(self.convs)[:-1]):
+            if chain:
                 y, cur = m[0](cur, tap=True)
-                outs.append(m[1](y, relu=True))
-            outs.append(self.convs[-1](cur))
-            return self.project(ops.cat_channels(*outs))
-        return self.project(ops.cat_channels(*[conv(x) for conv in self.convs]))
+            else:
+                y = m[0](cur)
+            outs.append(m[1](y, relu=True, out_into=(buf, i * oc)))
+        outs.append(self.convs[-1](cur, out_into=(buf, (len(self.convs) - 1) * oc)))
+        return self.project(ops.cat_from_views(buf, *outs))

@@ -260,12 +260,25 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def _row_stride(t):
+    """Leading dimension of an NHWC tensor that is contiguous or a channel slice of a contiguous buffer, else None."""
+    if t.stride(-1) != 1:
+        return None
+    ld = t.stride(-2)
+    exp = ld
+    for d in range(t.dim() - 2, -1, -1):
+        if t.stride(d) != exp:
+            return None
+        exp *= t.shape[d]
+    return ld if ld >= t.shape[-1] else None
+
+
 class _BNAct(torch.autograd.Function):
     """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -310,10 +323,17 @@ class _BNAct(torch.autograd.Function):
                      float(eps), mean, invstd, scale, shift, c, dev, st)
         else:
             call("css_bn_eval_coeff", gamma, beta, running_mean, running_var, float(eps), scale, shift, c, dev, st)
-        out = torch.empty_like(y)
-        call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
+        if out_into is not None:      # write straight into a channel slice of a concat buffer (cat_from_views): no copy later
+            buf, off = out_into
+            out, ldo = buf[..., off:off + c], buf.shape[-1]
+            assert buf.is_contiguous() and buf.dtype == dt and buf.shape[:-1] == y.shape[:-1]
+            call("css_bn_apply", y, c, res, c, buf.data_ptr() + off * buf.element_size(), ldo, scale, shift, m, c, int(relu), mg, dc, dev, st)
+        else:
+            out = torch.empty_like(y)
+            call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
         if training:
             # ReLU mask in backward: from `out` when a residual was added, else recomputed from y*scale+shift (one read less)
+            assert out_into is None or not (relu and res is not None)
             ctx.save_for_backward(y, out if (relu and res is not None) else None, mean, invstd, gamma, scale, shift)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
@@ -329,12 +349,14 @@ class _BNAct(torch.autograd.Function):
         m = y.numel() // c
         mg = m // g
         dt = y.dtype
-        da = da.contiguous()
+        ldda = _row_stride(da)          # a channel slice of a concat gradient is read in place (cat_from_views)
+        if ldda is None or (da.data_ptr() % 16) or (ldda * da.element_size()) % 16:
+            da, ldda = da.contiguous(), c
         dev, st = dev_stream(da)
         dc = dtype_code(dt)
         nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
         partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
-        call("css_bn_bwd_reduce", da, c, a, c, y, c, mean, invstd, scale, shift, mg, g, c, int(relu), partial, dc, dev, st)
+        call("css_bn_bwd_reduce", da, ldda, a, c, y, c, mean, invstd, scale, shift, mg, g, c, int(relu), partial, dc, dev, st)
         sums = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
         # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
         sg, sb = _grad_sink(gamma, (c,)), _grad_sink(ctx.beta_ref, (c,))
@@ -349,9 +371,9 @@ class _BNAct(torch.autograd.Function):
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call("css_bn_bwd_apply", da, c, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, m, c,
+        call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, m, c,
              int(relu), mg, dc, dev, st)
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
@@ -386,9 +408,9 @@ def count_bn_batch(counter):
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
-           groups=None):
+           groups=None, out_into=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
-                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None))
+                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into)
 
 
 # --------------------------------------------------------------------------
@@ -486,10 +508,14 @@ class _Broadcast(torch.autograd.Function):
     """[N,1,1,C] -> [N,H,W,C] (bilinear resize of a 1x1 map, aspp.py:38)."""
 
     @staticmethod
-    def forward(ctx, x, h, w):
+    def forward(ctx, x, h, w, out_into=None):
         n, _, _, c = x.shape
-        out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         dev, st = dev_stream(x)
+        if out_into is not None:
+            buf, off = out_into
+            call("css_spatial_bcast", x, buf.data_ptr() + off * buf.element_size(), buf.shape[-1], n, h * w, c, 1.0, dtype_code(x.dtype), dev, st)
+            return buf[..., off:off + c]
+        out = torch.empty((n, h, w, c), dtype=x.dtype, device=x.device)
         call("css_spatial_bcast", x, out, c, n, h * w, c, 1.0, dtype_code(x.dtype), dev, st)
         return out
 
@@ -500,11 +526,39 @@ class _Broadcast(torch.autograd.Function):
         dx = torch.empty((n, 1, 1, c), dtype=dout.dtype, device=dout.device)
         dev, st = dev_stream(dout)
         call("css_spatial_sum", dout, c, dx, n, h * w, c, 1.0, dtype_code(dout.dtype), dev, st)
-        return dx, None, None
+        return dx, None, None, None
 
 
-def broadcast_hw(x, h, w):
-    return _Broadcast.apply(x, h, w)
+def broadcast_hw(x, h, w, out_into=None):
+    return _Broadcast.apply(x, h, w, out_into)
+
+
+class _CatFromViews(torch.autograd.Function):
+    """The concatenation whose pieces were WRITTEN IN PLACE into ``buf`` by their producers (``out_into=(buf, offset)`` of
+    bn_act / broadcast_hw): forward is free, backward hands every producer its channel slice of the gradient as a view."""
+
+    @staticmethod
+    def forward(ctx, buf, *views):
+        off = 0
+        for v in views:
+            assert v.data_ptr() == buf.data_ptr() + off * buf.element_size() and v.shape[:-1] == buf.shape[:-1]
+            off += v.shape[-1]
+        assert off == buf.shape[-1]
+        ctx.cs = [v.shape[-1] for v in views]
+        return buf.view(buf.shape)
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout = dout.contiguous()
+        outs, off = [None], 0
+        for i, c in enumerate(ctx.cs):
+            outs.append(dout[..., off:off + c] if ctx.needs_input_grad[i + 1] else None)
+            off += c
+        return tuple(outs)
+
+
+def cat_from_views(buf, *views):
+    return _CatFromViews.apply(buf, *views)
 
 
 class _CatChannels(torch.autograd.Function):
