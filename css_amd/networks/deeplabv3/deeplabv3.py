@@ -84,17 +84,21 @@ class DeepLabv3Plus_with_rep(nn.Module):
         x = self.resnet_maxpool(x)
         x_low = self.resnet_layer1(x)
         fuse = torch.is_grad_enabled() and x_low.requires_grad    # fold fan-out gradient sums into dgrad store passes (ops.conv2d taps)
+        # decoder input = [project(x_low) | up-sampled ASPP feature]: both producers write into one buffer (no concat copy)
+        n, hl, wl, _ = x_low.shape
+        c_low, c_up = self.project[0].out_channels, self.ASPP.project[0].out_channels
+        dbuf = torch.empty((n, hl, wl, c_low + c_up), dtype=x_low.dtype, device=x_low.device)
         if fuse:
             p, x_low = self.project[0](x_low, tap=True)
-            low = self.project[1](p, relu=True)
         else:
-            low = self.project(x_low)
+            p = self.project[0](x_low)
+        low = self.project[1](p, relu=True, out_into=(dbuf, 0))
         x = self.resnet_layer2(x_low)
         x = self.resnet_layer3(x)
         x = self.resnet_layer4(x)
         feature = self.ASPP(x)
-        up = ops.bilinear(feature, low.shape[1], low.shape[2])
-        dec = ops.cat_channels(low, up)
+        up = ops.bilinear(feature, hl, wl, out_into=(dbuf, c_low))
+        dec = ops.cat_from_views(dbuf, low, up)
         if fuse:
             pred, dec = self.classifier(dec, tap=True)
             return pred, self.representation(dec)

@@ -457,27 +457,35 @@ class _Bilinear(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=True) on NHWC tensors; output dtype selectable."""
 
     @staticmethod
-    def forward(ctx, x, hd, wd, out_dtype):
+    def forward(ctx, x, hd, wd, out_dtype, out_into=None):
         n, hs, ws, c = x.shape
-        out = torch.empty((n, hd, wd, c), dtype=out_dtype, device=x.device)
         dev, st = dev_stream(x)
-        call("css_bilinear", x, c, out, c, n, hs, ws, c, hd, wd, dtype_code(x.dtype), dtype_code(out_dtype), 0, dev, st)
         ctx.cfg = (x.shape, x.dtype)
+        if out_into is not None:      # straight into a channel slice of a concat buffer (cat_from_views)
+            buf, off = out_into
+            assert buf.dtype == out_dtype and buf.is_contiguous() and tuple(buf.shape[:3]) == (n, hd, wd)
+            call("css_bilinear", x, c, buf.data_ptr() + off * buf.element_size(), buf.shape[-1], n, hs, ws, c, hd, wd, dtype_code(x.dtype),
+                 dtype_code(out_dtype), 0, dev, st)
+            return buf[..., off:off + c]
+        out = torch.empty((n, hd, wd, c), dtype=out_dtype, device=x.device)
+        call("css_bilinear", x, c, out, c, n, hs, ws, c, hd, wd, dtype_code(x.dtype), dtype_code(out_dtype), 0, dev, st)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (n, hs, ws, c), in_dtype = ctx.cfg
-        dout = dout.contiguous()
+        ldo = _row_stride(dout)       # a channel slice of a concat gradient is read in place
+        if ldo is None:
+            dout, ldo = dout.contiguous(), c
         hd, wd = dout.shape[1], dout.shape[2]
         dx = torch.empty((n, hs, ws, c), dtype=in_dtype, device=dout.device)
         dev, st = dev_stream(dout)
-        call("css_bilinear", dout, c, dx, c, n, hs, ws, c, hd, wd, dtype_code(dout.dtype), dtype_code(in_dtype), 1, dev, st)
-        return dx, None, None, None
+        call("css_bilinear", dout, ldo, dx, c, n, hs, ws, c, hd, wd, dtype_code(dout.dtype), dtype_code(in_dtype), 1, dev, st)
+        return dx, None, None, None, None
 
 
-def bilinear(x, hd, wd, out_dtype=None):
-    return _Bilinear.apply(x, hd, wd, out_dtype or x.dtype)
+def bilinear(x, hd, wd, out_dtype=None, out_into=None):
+    return _Bilinear.apply(x, hd, wd, out_dtype or x.dtype, out_into)
 
 
 class _GlobalAvgPool(torch.autograd.Function):
