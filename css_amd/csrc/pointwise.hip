@@ -316,6 +316,24 @@ __global__ __launch_bounds__(256) void spatial_bcast_kernel(const T* __restrict_
   }
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void spatial_bcast_vec_kernel(const T* __restrict__ x, T* __restrict__ out, int ldo, int N, int HW, int C,
+                                                                float scale) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)N * HW * CV;
+  GRID_STRIDE(idx, total) {
+    const int c = (int)(idx % CV) * VEC;
+    const size_t p = idx / CV;
+    const int n = (int)(p / HW);
+    Vec16<T> v, o;
+    v.load(x + (size_t)n * C + c);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, v.f(e) * scale);
+    o.store(out + p * ldo + c);
+  }
+}
+
 // ---- column sum: out[c] += sum_m x[m][c]  (bias gradients) ---------------
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ out) {
@@ -564,8 +582,13 @@ int css_launch_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int
 }
 int css_launch_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, hipStream_t st) {
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(spatial_bcast_kernel<T>, dim3(ew_grid((size_t)N * HW * C)), dim3(256), 0, st, (const T*)x, (T*)out, ldo, N, HW,
-                       C, scale);
+    constexpr int VEC = 16 / sizeof(T);
+    if (C % VEC == 0 && ldo % VEC == 0 && !(reinterpret_cast<uintptr_t>(x) & 15) && !(reinterpret_cast<uintptr_t>(out) & 15))
+      hipLaunchKernelGGL(spatial_bcast_vec_kernel<T>, dim3(ew_grid((size_t)N * HW * (C / VEC))), dim3(256), 0, st, (const T*)x, (T*)out, ldo, N,
+                         HW, C, scale);
+    else
+      hipLaunchKernelGGL(spatial_bcast_kernel<T>, dim3(ew_grid((size_t)N * HW * C)), dim3(256), 0, st, (const T*)x, (T*)out, ldo, N, HW,
+                         C, scale);
   });
   CSS_CHECK_LAUNCH();
   return CSS_OK;
