@@ -11,8 +11,8 @@ after which the reference's entry scripts' imports
     from generalframeworks.scheduler.my_lr_scheduler import PolyLR
     from generalframeworks.scheduler.rampscheduler import RampdownScheduler
 
-pick up the HIP-backed implementations.  Modules of the reference that are out of scope here (dataset_helpers, util,
-meter, augmentation) are left alone: if the real ``generalframeworks`` package is importable it keeps serving those.
+pick up the HIP-backed implementations.  Modules of the reference that are out of scope here (augmentation, the rest of
+util) are left alone: if the real ``generalframeworks`` package is importable it keeps serving those.
 """
 import importlib
 import sys
@@ -30,6 +30,9 @@ _MAP = {
     "generalframeworks.util.meter": "css_amd.util.meter",
     "generalframeworks.util.miou": "css_amd.util.miou",
     "generalframeworks.util.torch_dist_sum": "css_amd.util.torch_dist_sum",
+    # data path (SURVEY 8f-4 loaders on CPU workers; 8f-1 in-step augmentation on the device)
+    "generalframeworks.dataset_helpers.VOC": "css_amd.dataset_helpers.VOC",
+    "generalframeworks.dataset_helpers.Cityscapes": "css_amd.dataset_helpers.Cityscapes",
 }
 
 

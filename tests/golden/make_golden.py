@@ -463,10 +463,56 @@ def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
     save(tag, **out)
 
 
+def gen_dataset(seed=61):
+    """the torchvision-free functions of the reference's dataset helpers (split readers, Cityscapes path and
+    id mapping) run on a scratch tree; recorded as JSON (strings + small integer tables)."""
+    import json
+    import tempfile
+    from generalframeworks.dataset_helpers import VOC as ref_voc
+    from generalframeworks.dataset_helpers import Cityscapes as ref_city
+    rng = np.random.RandomState(seed)
+    ids_u8 = np.arange(256, dtype=np.uint8)
+    odd = np.array([-1, 0, 7, 33, 34, 255, 256, 300, -7], dtype=np.int16)
+    tile = rng.randint(0, 34, size=(6, 9)).astype(np.uint8)
+    names = ["aachen_000000_000019_leftImg8bit", "frankfurt_000001_083852_leftImg8bit ", "x_1_leftImg8bit", "nounderscore"]
+    paths = []
+    for nme in names:
+        for mode in ("train", "val"):
+            img, city = ref_city.image_root_transform(nme, mode=mode)
+            paths.append(dict(name=nme, mode=mode, image=img, city=city, label=ref_city.label_root_transform(nme, city, mode=mode)))
+    with tempfile.TemporaryDirectory() as d:
+        files = {"labeled_filename.txt": "2007_000032\n2007_000039\n\n2007_000063", "unlabeled_filename.txt": "a\nb\r\nc\n",
+                 "valid_filename.txt": ""}
+        os.makedirs(f"{d}/662/3407")
+        for k, v in files.items():
+            with open(f"{d}/662/3407/{k}", "w", newline="") as f:
+                f.write(v)
+        split_voc = [list(x) for x in ref_voc.get_pascal_idx_via_txt(d, 662, 3407)]
+        split_city = [list(x) for x in ref_city.get_cityscapes_idx_via_txt(d, "662", "3407")]
+        bd = ref_voc.VOC_BuildData(data_path="/data/voc", txt_path=d, label_num=662, seed=3407, crop_size=[321, 321])
+        sets = [dict(root=s.root, n=len(s), crop=list(s.crop_size), scale=list(s.scale_size), aug=s.augmentation, train=s.train)
+                for s in bd.build()]
+        cd = ref_city.City_BuildData(data_path="~/city", txt_path=d, label_num=662, seed=3407, crop_size=[769, 769])
+        csets = [dict(root=s.root, n=len(s), crop=list(s.crop_size), scale=list(s.scale_size), aug=s.augmentation, train=s.train)
+                 for s in cd.build()]
+        battr = dict(image_size=bd.image_size, num_segments=bd.num_segments, scale_size=list(bd.scale_size))
+        cattr = dict(im_size=cd.im_size, num_segments=cd.num_segments, scale_size=list(cd.scale_size))
+    out = dict(class_map_u8=ref_city.cityscapes_class_map(ids_u8).tolist(), odd_in=odd.tolist(),
+               class_map_odd=ref_city.cityscapes_class_map(odd).tolist(), tile_in=tile.tolist(),
+               class_map_tile=ref_city.cityscapes_class_map(tile).tolist(), paths=paths, split_files=files, split_voc=split_voc,
+               split_city=split_city, voc_sets=sets, city_sets=csets, voc_attrs=battr, city_attrs=cattr,
+               home=os.path.expanduser("~"))
+    with open(os.path.join(HERE, "dataset_helpers.json"), "w") as f:
+        json.dump(out, f, separators=(',', ':'))
+    print("dataset_helpers.json written")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval"]
+    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval", "dataset"]
     if "eval" in which:
         gen_eval()
+    if "dataset" in which:
+        gen_dataset()
     if "net" in which:
         gen_network("tv", 65, 21, 101, "net_tv_65")
         gen_network("stem", 65, 19, 102, "net_stem_65")
