@@ -11,6 +11,7 @@ Weak scaling: every rank owns its own B+B crops; SyncBN statistics, prototype su
 exchanges (RCCL).  Rank 0 prints ONE JSON line.
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -123,7 +124,8 @@ def main():
     # 8-bit quantisation; css_amd/csrc/aug.hip) instead of the identity stand-in
     cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5) if a.aug == "pil" else (1.0, 1.0), "mix_mode": a.mix, "device_aug": a.aug}}
     bb = resnet.resnet101_tv(zero_init_residual=False) if backbone == "tv" else resnet.resnet101(zero_init_residual=False)
-    model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
+    with contextlib.redirect_stdout(sys.stderr):     # the constructor prints like the reference's; stdout carries the ONE JSON line only
+        model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
     # seeded non-degenerate weights: Kaiming convs (constructor), BN gamma~U(.5,1.5), beta~N(0,.1)
     g = torch.Generator().manual_seed(3407)
     with torch.no_grad():

@@ -15,7 +15,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from .. import _lib
+from .. import _lib, ops
 from .._lib import call, dev_stream, dtype_code, query
 from ..functional import nhwc
 
@@ -183,7 +183,7 @@ class _ContrastCore(torch.autograd.Function):
         chunkhist = torch.empty(nch * 64, **i32)
         listV, listH = torch.empty(P, **i32), torch.empty(P, **i32)
         call("css_contrast_compact", cls, hard, P, K, chunkhist, listV, listH, meta, dev, st)
-        if group_sync and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if group_sync and ops.collectives_on():
             # replaces the two all_gathers of loss.py:77,81 (545 MB/rank) by K*(C+1) numbers: mean = sum/count
             dist.all_reduce(sums)
         call("css_contrast_proto_update", prototypes, sums, K, C, float(alpha), meta, dev, st)

@@ -6,6 +6,8 @@ bookkeeping; every arithmetic operation below is a HIP kernel in ``css_amd/csrc`
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -260,6 +262,15 @@ def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def collectives_on():
+    """True when the data-parallel exchanges (SyncBN statistics, prototype sums, gradient all-reduce) must run: more than one
+    rank, or CSS_FORCE_COLLECTIVES=1 with an initialised group (a 1-rank RCCL group: exercises every collective call, dtype and
+    stream hand-over on a single MI355X; the results are unchanged)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("CSS_FORCE_COLLECTIVES") == "1"
+
+
 def _row_stride(t):
     """Leading dimension of an NHWC tensor that is contiguous or a channel slice of a contiguous buffer, else None."""
     if t.stride(-1) != 1:
@@ -295,7 +306,7 @@ class _BNAct(torch.autograd.Function):
         if training and fused is not None and fused[1:] == (mg, g, c):
             # statistics came out of the producing convolution's epilogue (fp32 rows per 128-row slab)
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
-            if sync and _world() > 1:
+            if sync and collectives_on():
                 stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
                      None, stats, c, dev, st)
@@ -311,7 +322,7 @@ class _BNAct(torch.autograd.Function):
             partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
             call("css_bn_stats", y, mg, g, c, c, partial, dc, dev, st)
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
-            if sync and _world() > 1:
+            if sync and collectives_on():
                 stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
                 call("css_bn_reduce", partial, nrb, c, g, stats, None, None, 0, dev, st)
                 dist.all_reduce(stats)          # SyncBN: (sum, sum of squares) of every rank; equal pixel counts per rank
@@ -367,7 +378,7 @@ class _BNAct(torch.autograd.Function):
             dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
             call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, dev, st)
-        if sync and _world() > 1:
+        if sync and collectives_on():
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None

@@ -81,7 +81,7 @@ class MixTrainer:
         with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
             total.backward()
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if world > 1:
+        if ops.collectives_on():
             dist.all_reduce(self.flat_g)                                     # DDP gradient all-reduce (mean), one bucket
         decay = min(1 - 1 / (m.step + 1), m.alpha)
         dev, st = dev_stream(self.flat_p)

@@ -164,3 +164,70 @@ def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
     assert torch.equal(pa, pb), float((pa - pb).abs().max())                         # same summed gradient -> same update
     assert torch.equal(torch.tensor(a["ema"]), torch.tensor(b["ema"]))
     assert torch.equal(torch.tensor(a["rm"]), torch.tensor(b["rm"]))                 # SyncBN: global statistics on both ranks
+
+
+RCCL_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from css_amd.networks import resnet
+from css_amd.networks.ddp_model import Model_mix
+from css_amd.train_step import MixTrainer
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+if os.environ.get("CSS_FORCE_COLLECTIVES") == "1":
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # "nccl" IS RCCL on ROCm
+K, S = 21, 65
+torch.manual_seed(11)
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix"}}
+m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
+m.model.train(); m.ema_model.train()
+m.set_compute_dtype(torch.bfloat16)
+tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
+g = torch.Generator().manual_seed(100)
+import numpy as np
+np.random.seed(3)
+losses = []
+for it in range(2):
+    l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
+    u = torch.randn(2, 3, S, S, generator=g).to(dev)
+    out = tr.step(l, y, u)
+    losses.append([float(out["sup"]), float(out["contrast"])])
+torch.cuda.synchronize()
+probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
+json.dump(dict(losses=losses, p=probe.tolist(), proto=tr.prototypes.double().cpu().flatten().tolist(),
+               rm=m.model.resnet_bn1.running_mean.double().cpu().tolist()), open(sys.argv[1], "w"))
+if dist.is_initialized():
+    dist.destroy_process_group()
+'''
+
+
+def test_rccl_collectives_on_one_rank_change_nothing(tmp_path):
+    """The data-parallel exchanges through RCCL itself (backend "nccl") on the one GPU a test box has: a 1-rank group with
+    CSS_FORCE_COLLECTIVES=1 sends every SyncBN statistics tensor (fp64, forward and backward), the prototype sums (fp64) and the
+    flat gradient (fp32, 238 MB) through ncclAllReduce on RCCL's stream and back.  Sum over one rank is the identity, so the two
+    training steps must reproduce the no-group run (first step: to rounding; second: to the reordering noise of the atomic weight-gradient
+    sums) - which also pins the stream hand-over between the compute stream and RCCL's (a missing wait shows up as garbage statistics)."""
+    import json
+    import torch
+    outs = []
+    for force in ("0", "1"):
+        out = str(tmp_path / f"r{force}.json")
+        env = dict(os.environ, CSS_FORCE_COLLECTIVES=force, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", WORLD_SIZE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.Popen([sys.executable, "-c", RCCL_WORKER % ROOT, out], env=env)
+        assert p.wait(timeout=900) == 0
+        outs.append(json.load(open(out)))
+    a, b = outs
+    # the forward pass is deterministic; the weight-gradient kernels accumulate with fp32 atomics, so the second step is compared at
+    # atomics-reordering level
+    for x, y in zip(a["losses"][0], b["losses"][0]):
+        assert abs(x - y) <= 1e-6 * max(1.0, abs(x)), (a["losses"], b["losses"])
+    for x, y in zip(a["losses"][1], b["losses"][1]):
+        assert abs(x - y) <= 2e-2 * max(1.0, abs(x)), (a["losses"], b["losses"])
+    pa, pb = torch.tensor(a["p"]), torch.tensor(b["p"])
+    assert ((pa - pb).norm() / pa.norm()).item() < 1e-3
+    ra, rb = torch.tensor(a["rm"]), torch.tensor(b["rm"])
+    assert ((ra - rb).abs().max() / ra.abs().max()).item() < 1e-3
+    qa, qb = torch.tensor(a["proto"]), torch.tensor(b["proto"])
+    assert ((qa - qb).norm() / qa.norm().clamp_min(1e-12)).item() < 2e-2
