@@ -474,14 +474,20 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_b
 #endif
 }
 
-__global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
+// Template: BM x BN tile with NWM x NWN waves of 64 x (BN/NWN) outputs.  <256,128,4,2> is the kernel described above; the 4-wave
+// instances <128,128,2,2> / <128,64,2,2> serve leftover rows and the narrow layers (rows per DMA pass = 8 per wave, so a thread's
+// rows are prow + 8*NW*i and the swizzle term ((r >> 1) & 7) stays the same for all of them; vmcnt = A_IT + B_IT).
+template <int BM, int BN, int NWM, int NWN, int NST = 3>
+__global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const ConvArgs a) {
   using T = bf16_t;
-  constexpr int BM = 256, BN = 128, BK = 64, VEC = 8, NST = 3;
-  constexpr int A_IT = 4, B_IT = 2;                    // DMA wave-instructions per thread per stage (rows t>>3 + 64 i)
+  constexpr int BK = 64, VEC = 8, NW = NWM * NWN, RP = 8 * NW;     // NST LDS stages, NST-1 K tiles in flight
+  constexpr int A_IT = BM / RP, B_IT = BN / RP;        // DMA wave-instructions per thread per stage (rows t>>3 + RP i)
+  static_assert(BM % RP == 0 && BN % RP == 0 && BM / NWM == 64 && RP % 16 == 0, "tile / wave mapping");
   constexpr int ROWB = BK * 2;                         // 128 bytes per LDS row
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int WTM = 64, WTN = 64, TM = 2, TN = 2, CSTR = WTN + VEC;
-  static_assert(8 * WTM * CSTR * 2 <= NST * ST_BYTES, "epilogue staging fits");
+  constexpr int WTM = 64, WTN = BN / NWN, TM = 2, TN = WTN / 32, CSTR = WTN + VEC;
+  constexpr int NPAIR = (BM / 128) * NWN;              // (slab, wave column) pairs of the statistics hand-over
+  static_assert(NW * WTM * CSTR * 2 <= NST * ST_BYTES, "epilogue staging fits");
   // ONE LDS object on purpose: with a second __shared__ variable the LDS lowering tags every access with alias scopes and
   // the waitcnt pass then puts s_waitcnt vmcnt(0) in front of the fragment reads (it must assume the in-flight LDS-DMA
   // writes alias them), which serialises the two-tiles-in-flight pipeline (measured: 64 -> 90 ms per step).
@@ -490,14 +496,14 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
   float* sstat = reinterpret_cast<float*>(smem);
   constexpr bool DSTATS = false;
 #else
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + 4 * 12 * 64 * 4];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + NPAIR * 12 * WTN * 4];
   float* sstat = reinterpret_cast<float*>(smem + NST * ST_BYTES);   // 4 wave pairs x [counter + pad | slot | slot], see store_wave_tile
   constexpr bool DSTATS = true;
-  if (a.stats && threadIdx.x < 4) reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * 64] = 0;   // ordered by the main loop's barriers
+  if (a.stats && threadIdx.x < NPAIR) reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * WTN] = 0;   // ordered by the main loop's barriers
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / NWN, wn = wave % NWN;
   const int nt_n = (a.Cd + BN - 1) / BN;
   const int ntiles = gridDim.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
@@ -513,7 +519,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
   int a_base[A_IT], a_h[A_IT], a_w[A_IT];
 #pragma unroll
   for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + prow + i * 64;
+    const int m = m0 + prow + i * RP;
     if (m < a.M) {
       const int hw = a.Hd * a.Wd;
       const int n_img = m / hw;
@@ -537,7 +543,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
   unsigned b_off[B_IT];
 #pragma unroll
   for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + prow + i * 64;
+    const int n = n0 + prow + i * RP;
     b_off[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u : OOB;
   }
   int kc = cch * VEC, tr = 0, ts = 0;
@@ -609,15 +615,15 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
   };
   tap_offsets();
-  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*512 + w*64, +64) of the stage image
+  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*64*NW + w*64, +64) of the stage image
   auto issue = [&](int stage) {
     unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
     unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * 8192, offA[i]);
+    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * (NW * 1024), offA[i]);
     const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * 2u : OOB;
 #pragma unroll
-    for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * 8192, (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
+    for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * (NW * 1024), (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
     kglob += BK;
     kc += BK;
     if (kc >= a.Cs) {          // next tap (uniform across the block whenever Cs is a multiple of BK)
@@ -678,18 +684,18 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
   };
 
-  issue(0);
-  issue(1);
-  int st_c = 0, st_i = 2;
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
+  int st_c = 0, st_i = NST - 1;
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (A_IT + B_IT)) : "memory");   // this wave's share of tile kt landed, later tiles may fly
     __builtin_amdgcn_s_barrier();
-    issue(st_i);                       // tile kt+2 (past the end: all-OOB = zeros into a free stage)
+    issue(st_i);                       // tile kt+NST-1 (past the end: all-OOB = zeros into a free stage)
 #ifndef CSS_DMA_NOCOMPUTE
     compute(st_c);
 #endif
-    st_c = st_c == 2 ? 0 : st_c + 1;
-    st_i = st_i == 2 ? 0 : st_i + 1;
+    st_c = st_c == NST - 1 ? 0 : st_c + 1;
+    st_i = st_i == NST - 1 ? 0 : st_i + 1;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must land before the stages are reused below
   __builtin_amdgcn_s_barrier();
@@ -720,7 +726,7 @@ __global__ __launch_bounds__(512) void conv_igemm_dma_kernel(const ConvArgs a) {
     }
   }
   __syncthreads();
-  store_wave_tile<T, WTM, WTN, CSTR, BN, DSTATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane, sstat + ((wm >> 1) * 2 + wn) * 12 * WTN);
+  store_wave_tile<T, WTM, WTN, CSTR, BN, DSTATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane, sstat + ((wm >> 1) * NWN + wn) * 12 * WTN);
 }
 
 // --------------------------------------------------------------------------
@@ -1296,6 +1302,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
 // --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
+// 128-row tiles (leftover rows of the big-tile kernels, layers with Cout <= 64): LDS-DMA instances; CSS_SMALL_DMA=0 selects the
+// register-staged kernels instead (kept for the fp32 path and as the A/B reference)
+static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b) {
+  static const bool dma = !(getenv("CSS_SMALL_DMA") && atoi(getenv("CSS_SMALL_DMA")) == 0) && !getenv("CSS_NO_DMA_CONV");
+  if (dma && b.Cs % 64 == 0) {      // (channel counts that are not whole K tiles - the 7x7 stem - change tap inside a tile: register-staged)
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2>), g, dim3(256), 0, st, b);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, b);
+  }
+}
+static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
+  static const bool dma = !(getenv("CSS_SMALL_DMA") && atoi(getenv("CSS_SMALL_DMA")) == 0) && !getenv("CSS_NO_DMA_CONV");
+  if (dma && b.Cs % 64 == 0) {
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), g, dim3(256), 0, st, b);
+  } else {
+    hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, b);
+  }
+}
+
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   auto P0 = [&](bool big, double share) { if (prof) prof->begin(big, share); };
   auto P1 = [&]() { if (prof) prof->end(); };
@@ -1337,9 +1362,9 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
           static const int rem_mode = getenv("CSS_REM_N64") ? atoi(getenv("CSS_REM_N64")) : 1;
           const int wgs128 = cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128);
           if ((rem_mode == 1 && wgs128 * 2 <= n_cu) || (rem_mode == 2 && wgs128 <= n_cu))
-            hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), dim3(256), 0, st, b);
+            launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b);
           else
-            hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(wgs128), dim3(256), 0, st, b);
+            launch_small_n128(dim3(wgs128), st, b);
         }
         P1();
       }
@@ -1357,25 +1382,25 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
         P0(false, (double)(b.M - b.m_begin) / a.M);
-        hipLaunchKernelGGL(conv_igemm_dma_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<256, 128, 4, 2>), dim3(full_mt * nt_n), dim3(512), 0, st, b);
         P1();
       }
       if (full_mt < mt) {
         ConvArgs b = a;
         b.m_begin = full_mt * 256;
         P0(false, (double)(b.M - b.m_begin) / a.M);
-        hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), dim3(cdiv(a.M - b.m_begin, 128) * nt_n), dim3(256), 0, st, b);
+        launch_small_n128(dim3(cdiv(a.M - b.m_begin, 128) * nt_n), st, b);
         P1();
       }
     } else if (a.Cd > 64) {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 128));
       P0(false, (double)(a.M - a.m_begin) / a.M);
-      hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, a);
+      launch_small_n128(g, st, a);
       P1();
     } else {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 64));
       P0(false, (double)(a.M - a.m_begin) / a.M);
-      hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, a);
+      launch_small_n64(g, st, a);
       P1();
     }
   } else if (dtype == CSS_F32) {

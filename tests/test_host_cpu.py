@@ -167,7 +167,7 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
                    check=True, capture_output=True, timeout=600)
     lines = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z21conv_igemm_dma_kernel"))
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z21conv_igemm_dma_kernelILi256ELi128ELi4ELi2ELi3EE"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
     mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
@@ -179,6 +179,19 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     # no hidden stack objects promoted to LDS (a dynamically indexed register vector once cost 8 KiB and ~25 % of the kernel)
     lds = next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:"))
     assert lds == 3 * (256 + 128) * 128 + 4 * 12 * 64 * 4, lds
+    # the 4-wave instances of the same kernel (leftover rows, narrow layers): 128x128 (8 DMA pieces per thread and stage) and 128x64 (6)
+    for sym, nmfma, cnt, lds_bytes in (("_Z21conv_igemm_dma_kernelILi128ELi128ELi2ELi2ELi3EE", 16, 8, 3 * (128 + 128) * 128 + 2 * 12 * 64 * 4),
+                                       ("_Z21conv_igemm_dma_kernelILi128ELi64ELi2ELi2ELi3EE", 8, 6, 3 * (128 + 64) * 128 + 2 * 12 * 32 * 4)):
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mfma) == nmfma, (sym, len(mfma))
+        first_label = max(i for i in range(mfma[0]) if body[i].startswith(".LBB"))
+        assert not any("vmcnt(0)" in l for l in body[first_label:mfma[-1] + 1]), sym
+        assert any(f"s_waitcnt vmcnt({cnt})" in l for l in body), sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == lds_bytes, sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
     # same checks for the 256x256x32 kernel (three tiles in flight: vmcnt(8))
     start = next(i for i, l in enumerate(lines) if l.startswith("_Z24conv_igemm_dma256_kernel"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
