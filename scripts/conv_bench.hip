@@ -15,7 +15,9 @@ int main() {
       {"head 3x3 304->256", 32, 129, 129, 304, 256, 3, 1, 1, 1},
       {"l1 1x1 64->256", 32, 129, 129, 64, 256, 1, 1, 0, 1},
   };
+  const int only = getenv("CB_ONLY") ? atoi(getenv("CB_ONLY")) : -1;   // run a single shape (index into the table)
   for (auto& s : shapes) {
+    if (only >= 0 && &s - shapes.data() != only) continue;
     const int Ho = (s.H + 2 * s.pad - s.dil * (s.R - 1) - 1) / s.stride + 1, Wo = Ho;
     size_t nx = (size_t)s.N * s.H * s.W * s.Cin, nw = (size_t)s.Cout * s.R * s.R * s.Cin, ny = (size_t)s.N * Ho * Wo * s.Cout;
     std::vector<unsigned short> hx(nx), hw(nw);
