@@ -103,8 +103,12 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # CSS_FORCE_COLLECTIVES=1 on one GPU: a 1-rank RCCL group with every data-parallel exchange switched on (ops.collectives_on) -
+    # measures what the ~450 collective calls of a step cost before any wire time
+    forced = world == 1 and os.environ.get("CSS_FORCE_COLLECTIVES") == "1"
+    if world > 1 or forced:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29581")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
 
@@ -210,7 +214,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
         print(json.dumps(res))
-    if world > 1:
+    if world > 1 or forced:
         dist.destroy_process_group()
 
 
