@@ -398,7 +398,8 @@ static inline int pick_rows_per_block(int Mg, int G, int C, int vec) {
   const int ybl = (CV + TPC - 1) / TPC;
   const long bytes = (long)Mg * C * (16 / vec);
   long want = bytes / (64 * 1024) / ybl;
-  const long cap = 1024 / ((long)ybl * G) > 0 ? 1024 / ((long)ybl * G) : 1;
+  static const long total_cap = getenv("CSS_BN_RED_BLOCKS") ? atol(getenv("CSS_BN_RED_BLOCKS")) : 1024;   // (one block per CU wins the stand-alone microbenchmark by up to 22 % but loses 0.4 ms in the step, where the tensors come from the Infinity Cache)
+  const long cap = total_cap / ((long)ybl * G) > 0 ? total_cap / ((long)ybl * G) : 1;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
   int rpb = cdiv(Mg, want);
@@ -471,10 +472,10 @@ static inline int ew_grid(size_t total) {
 }
 
 // rows per block for the elementwise kernels: ~2048 blocks in total, >= EW_UNROLL rows per thread
-static inline int pick_rows_ew(int Mg, int G, int C, int vec, int min_rows = EW_UNROLL) {
+static inline int pick_rows_ew(int Mg, int G, int C, int vec, int min_rows = EW_UNROLL, long total_ew = 2048) {
   const int CV = C / vec, TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
   const int ybl = (CV + TPC - 1) / TPC;
-  long want = 2048 / ((long)ybl * G);
+  long want = total_ew / ((long)ybl * G);
   if (want < 1) want = 1;
   int rpb = cdiv(Mg, want);
   rpb = cdiv(rpb, RPB) * RPB;
@@ -535,7 +536,10 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
       (relu && !a && (!scale || !shift)))
     return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
-  const int rpb = pick_rows_ew(Mg, G, C, VEC, 16);   // amortise the 7-coefficient prologue (measured: 44 -> 30 us at 135200x128)
+  // amortise the 7-coefficient prologue (measured: 44 -> 30 us at 135200x128), and ONE block per CU: with 3-5 streams per block the
+  // backward kernel is 5-25 % faster on 256 blocks than on 2048 (bn_bench.py; the forward apply kernel is the opposite)
+  static const long bwd_blocks = getenv("CSS_BN_BWD_EW_BLOCKS") ? atol(getenv("CSS_BN_BWD_EW_BLOCKS")) : 256;
+  const int rpb = pick_rows_ew(Mg, G, C, VEC, 16, bwd_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy,
                      (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, Mg, C, relu, rpb);
