@@ -489,7 +489,8 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
-  const int rpb = pick_rows_ew(Mg, G, C, VEC);
+  static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 2048;
+  const int rpb = pick_rows_ew(Mg, G, C, VEC, EW_UNROLL, apply_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_apply_kernel<T>, g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, Mg, C,
                      relu, rpb);
