@@ -16,7 +16,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "csrc", "libcss_hip.so")
+LIB_PATH = os.environ.get("CSS_HIP_LIB") or os.path.join(_HERE, "csrc", "libcss_hip.so")   # (override: A/B builds of the library)
 HEADER_PATH = os.path.join(_ROOT, "include", "css_hip.h")
 
 F32, BF16 = 0, 1

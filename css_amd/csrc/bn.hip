@@ -70,7 +70,10 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
 // 128 (all groups of a launch run concurrently), 8 independent loads in flight per thread, tree reduction in LDS.
 // rows(g, lo, hi, extra): partial rows [lo, hi) plus row `extra` (or -1) belong to group g.  emit(g, t0, t1, c) is called
 // by ONE thread per channel, for g = 0..G-1 in order (the running statistics take their G momentum updates in order).
-constexpr int S2_CH = 8, S2_NP = 128;
+#ifndef S2_CH_V
+#define S2_CH_V 8
+#endif
+constexpr int S2_CH = S2_CH_V, S2_NP = 1024 / S2_CH_V;
 template <typename PT, typename Rows, typename Emit>
 __device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, int C, int G, Rows rows, Emit emit) {
   __shared__ double red[2][S2_NP][S2_CH];
