@@ -463,6 +463,93 @@ def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
     save(tag, **out)
 
 
+def gen_train_trace_w5(kind, seed, gain=0.25):
+    """ONE iteration of the train body of cross_label.py:162-198 (kind 'cross', warm-up branch: class-predictor pseudo labels) or
+    ori_pseudo.py:158-187 (kind 'ori') driven through the reference's Model_cross / Model_ori_pseudo, Contrast_Loss,
+    Attention_Threshold_Loss, label_onehot, SGD(nesterov) and PolyLR, with identity augmentation (the batch_transform* used by the
+    model patched to the label convention 255 -> -1, mix_mode 'none')."""
+    import io
+    import contextlib
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    K, S, B, weak = 21, 65, 2, 0.0
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Loss": {"weak_threshold": weak}}
+    with contextlib.redirect_stdout(io.StringIO()):
+        if kind == "cross":
+            model = ref_ddp.Model_cross(TVResNet101(), num_classes=K, output_dim=256, config=cfg, temp=0.5)
+        else:
+            model = ref_ddp.Model_ori_pseudo(TVResNet101(), num_classes=K, output_dim=256, config=cfg)
+    sd = O.init_state("tv", K, 256, seed, gain)
+    model.model.load_state_dict(sd, strict=True)
+    model.ema_model.load_state_dict(sd, strict=True)
+
+    def fix(lab):
+        lab = lab.long().clone()
+        lab[lab == 255] = -1
+        return lab
+
+    def ident1(images, labels, logits=None, crop_size=None, scale_size=None, augmentation=True):
+        return images, fix(labels), logits
+
+    def ident3(images, l1, l2, g1=None, g2=None, crop_size=None, scale_size=None, augmentation=True):
+        return images, fix(l1), fix(l2), g1, g2
+
+    ref_ddp.batch_transform = ident1
+    ref_ddp.batch_transform_3 = ident3
+    # the reference's generate_cut_gather / _3 have no 'none' mode (VOC.py:390,468 raise): no mixing = identity
+    ref_ddp.generate_cut_gather = lambda image, label, logits, mode=None: (image, label, logits)
+    ref_ddp.generate_cut_gather_3 = lambda image, l1, l2, g1, g2, mode=None: (image, l1, l2, g1, g2)
+    model.train()
+    crit_c = ref_loss.Contrast_Loss(strong_threshold=0.8, num_queries=64, num_negatives=128, temp=0.5, alpha=0.99)
+    crit_u = ref_loss.Attention_Threshold_Loss(0.97)
+    crit_s = nn.CrossEntropyLoss(ignore_index=-1)
+    opt = torch.optim.SGD(model.model.parameters(), lr=6.4e-3, weight_decay=5e-4, momentum=0.9, nesterov=True)
+    sch = PolyLR(opt, 100, min_lr=1e-4)
+    protos = torch.zeros(K, 256)
+    g = torch.Generator().manual_seed(seed)
+    l_img = torch.randn(B, 3, S, S, generator=g)
+    u_img = torch.randn(B, 3, S, S, generator=g)
+    blk = torch.randint(0, K, (B, 5, 5), generator=g)
+    l_lab = blk.repeat_interleave(13, 1).repeat_interleave(13, 2)[:, :S, :S].clone()
+    l_lab[torch.rand(B, S, S, generator=g) < 0.05] = -1
+    out = dict(seed=seed, residual_gain=gain, l_img=l_img, u_img=u_img, l_lab=l_lab.to(torch.int16), weak=weak)
+    with Recorder() as rec:
+        if kind == "cross":
+            pl, pu, ulab_cls, ulab_rep, ulc, ulr, rep_all, pred_all = model(l_img, u_img, protos)
+            ulab = ulab_cls
+            out["ulab_rep"] = ulab_rep.to(torch.int16)
+        else:
+            pl, pu, ulab, ulc, rep_all, pred_all, pu_raw = model(l_img, u_img)
+        sup = crit_s(pl, l_lab)
+        unsup = crit_u(pu, ulab, ulc)                       # cross_label.py:174-175 (epoch < warmup) / ori_pseudo.py:167
+        with torch.no_grad():
+            umask = ulc.ge(weak).float()
+            mask_all = torch.cat(((l_lab.unsqueeze(1) >= 0).float(), umask.unsqueeze(1)))
+            mask_all = F.interpolate(mask_all, size=pred_all.shape[2:], mode="nearest")
+            label_l = F.interpolate(ref_utils.label_onehot(l_lab, K), size=pred_all.shape[2:], mode="nearest")
+            label_u = F.interpolate(ref_utils.label_onehot(ulab, K), size=pred_all.shape[2:], mode="nearest")
+            label_all = torch.cat((label_l, label_u))
+            prob_all = pred_all if kind == "cross" else torch.softmax(pred_all, dim=1)      # ori_pseudo.py:178
+        con = crit_c(rep_all, label_all, mask_all, prob_all, protos)
+    total = sup + unsup + con
+    opt.zero_grad()
+    total.backward()
+    opt.step()
+    model.ema_update()
+    sch.step()
+    out.update(sup=sup.detach(), unsup=unsup.detach(), con=con.detach(), ulab=ulab.to(torch.int16), ulc=ulc, protos=protos.clone(),
+               n_anchor=len(rec.anchor), lr_next=opt.param_groups[0]["lr"])
+    for i, (a, n) in enumerate(zip(rec.anchor, rec.negative)):
+        out[f"anchor{i}"] = np.asarray(a, dtype=np.int32)
+        out[f"negative{i}"] = np.asarray(n, dtype=np.int32)
+    sdm, sde = model.model.state_dict(), model.ema_model.state_dict()
+    for p in ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]:
+        out[f"student::{p}"] = probe_slice(sdm[p])
+        out[f"teacher::{p}"] = probe_slice(sde[p])
+    out["teacher_rm::resnet_bn1"] = sde["resnet_bn1.running_mean"].clone()
+    save(f"train_trace_{kind}", **out)
+
+
 def gen_dataset(seed=61):
     """the torchvision-free functions of the reference's dataset helpers (split readers, Cityscapes path and
     id mapping) run on a scratch tree; recorded as JSON (strings + small integer tables)."""
@@ -508,11 +595,14 @@ def gen_dataset(seed=61):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval", "dataset"]
+    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval", "dataset", "trace_w5"]
     if "eval" in which:
         gen_eval()
     if "dataset" in which:
         gen_dataset()
+    if "trace_w5" in which:
+        gen_train_trace_w5("cross", 47)
+        gen_train_trace_w5("ori", 49)
     if "net" in which:
         gen_network("tv", 65, 21, 101, "net_tv_65")
         gen_network("stem", 65, 19, 102, "net_stem_65")
