@@ -231,3 +231,118 @@ def test_rccl_collectives_on_one_rank_change_nothing(tmp_path):
     assert ((ra - rb).abs().max() / ra.abs().max()).item() < 1e-3
     qa, qb = torch.tensor(a["proto"]), torch.tensor(b["proto"])
     assert ((qa - qb).norm() / qa.norm().clamp_min(1e-12)).item() < 2e-2
+
+
+DDP_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np
+import torch, torch.distributed as dist
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.nn.parallel import DistributedDataParallel
+import css_amd.compat
+css_amd.compat.install()
+# ---- the imports of mix_label.py:9-21, resolved by the aliases ----
+from generalframeworks.networks import resnet
+from generalframeworks.networks.ddp_model import Model_mix
+from generalframeworks.scheduler.my_lr_scheduler import PolyLR
+from generalframeworks.scheduler.rampscheduler import RampdownScheduler
+from generalframeworks.utils import label_onehot, label_onehot_2
+from generalframeworks.loss.loss import ProbOhemCrossEntropy2d, Attention_Threshold_Loss, Contrast_Loss
+from css_amd.loss.loss import CrossEntropyLoss
+from oracle import css_oracle as O
+
+rank = 0
+torch.cuda.set_device(rank)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", rank))
+g = dict(np.load(os.path.join(%r, "tests", "golden", "train_trace_damped.npz")))
+seed, gain = int(g["seed"]), float(g["residual_gain"])
+K, S = 21, 65
+config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Network": {"num_class": K}}
+backbone = resnet.resnet101_tv()
+model = Model_mix(backbone, num_classes=K, output_dim=256, config=config, temp=0.5)
+sd = O.init_state("tv", K, 256, seed, gain)
+model.model.load_state_dict(sd, strict=True); model.ema_model.load_state_dict(sd, strict=True)
+model = model.cuda()                                                                   # mix_label.py:75
+model = nn.SyncBatchNorm.convert_sync_batchnorm(model)                                 # :76
+model = DistributedDataParallel(model, device_ids=[rank], find_unused_parameters=True)  # :77
+criterion = {"ce_loss": CrossEntropyLoss(ignore_index=-1).cuda(), "unsup_loss": Attention_Threshold_Loss(0.97).cuda(),
+             "contrast_loss": Contrast_Loss(strong_threshold=0.8, num_queries=64, num_negatives=128, temp=0.5, alpha=0.99).cuda()}
+optimizer = torch.optim.SGD(model.module.model.parameters(), lr=6.4e-3, weight_decay=5e-4, momentum=0.9, nesterov=True)
+scheduler = PolyLR(optimizer, 100, min_lr=1e-4)
+sche_d = RampdownScheduler(begin_epoch=0, max_epoch=200, current_epoch=0, max_value=1.0, min_value=0.1, ramp_mult=-5.0)
+prototypes = torch.zeros(K, 256).cuda()
+num_class, weak = K, 0.0
+model.module.model.train(); model.module.ema_model.train()
+T = lambda a: torch.from_numpy(np.asarray(a))
+train_l_image, train_l_label = T(g["0::l_img"]).cuda(), T(g["0::l_lab"]).long().cuda()
+train_u_image = T(g["0::u_img"]).cuda()
+# ---- mix_label.py:166-196 ----
+pred_l_large, pred_u_large, train_u_aug_label, train_u_aug_logits_cls, train_u_aug_logits_rep, rep_all, pred_all = model(train_l_image, train_u_image, prototypes)
+sup_loss = criterion["ce_loss"](pred_l_large, train_l_label)
+unsup_loss = criterion["unsup_loss"](pred_u_large, train_u_aug_label, train_u_aug_logits_cls)
+with torch.no_grad():
+    train_u_aug_mask = train_u_aug_logits_cls.ge(weak).float()
+    mask_all = torch.cat(((train_l_label.unsqueeze(1) >= 0).float(), train_u_aug_mask.unsqueeze(1)))
+    mask_all = F.interpolate(mask_all, size=pred_all.shape[2:], mode="nearest")
+    label_l = F.interpolate(label_onehot(train_l_label, num_class), size=pred_all.shape[2:], mode="nearest")
+    label_u = F.interpolate(label_onehot_2(train_u_aug_label, num_class), size=pred_all.shape[2:], mode="nearest")
+    label_u = label_u[:, 1:, :, :]
+    label_all = torch.cat((label_l, label_u))
+rec = {}
+O.contrast_loss(rep_all.detach().float().cpu(), label_all.cpu(), mask_all.cpu(), pred_all.detach().float().cpu(), prototypes.cpu().clone(),
+                64, 128, 0.5, 0.8, 0.99, record=rec)
+anchors, negs, j = [], [], 0
+for hn in rec["hard_num"]:
+    if hn > 0:
+        anchors.append(g[f"0::anchor{j}"].astype(np.int64)); negs.append(g[f"0::negative{j}"].astype(np.int64)); j += 1
+    else:
+        anchors.append(None); negs.append(None)
+assert j == int(g["0::n_anchor"])
+contrast_loss = criterion["contrast_loss"](rep_all, label_all, mask_all, pred_all, prototypes, _injected=dict(anchor=anchors, negative=negs))
+total_loss = sup_loss + unsup_loss + contrast_loss * sche_d.value
+optimizer.zero_grad()
+total_loss.backward()
+optimizer.step()
+model.module.ema_update()
+scheduler.step()
+# ----
+def rel(a, b):
+    a, b = a.double().flatten(), b.double().flatten()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+def probe(t):
+    return t.detach().flatten()[:: max(1, t.numel() // 2048)][:2048]
+sdm, sde = model.module.model.state_dict(), model.module.ema_model.state_dict()
+out = dict(sup=[sup_loss.item(), float(g["0::sup"])], unsup=[unsup_loss.item(), float(g["0::unsup"])], con=[contrast_loss.item(), float(g["0::con"])],
+           ramp=float(sche_d.value), mism=float((train_u_aug_label.cpu() != T(g["0::ulab"]).long()).float().mean()),
+           protos=rel(prototypes.cpu(), T(g["0::protos"])),
+           w={p: [rel(probe(sdm[p]).cpu(), T(g[f"0::student::{p}"])), rel(probe(sde[p]).cpu(), T(g[f"0::teacher::{p}"]))]
+              for p in ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]},
+           grads_none=[n for n, p in model.module.model.named_parameters() if p.grad is None])
+json.dump(out, open(sys.argv[1], "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_mix_label_body_under_ddp_matches_reference_trace(tmp_path):
+    """mix_label.py:75-77 + :166-196 verbatim: the reference's imports resolved by css_amd.compat, `.cuda()`,
+    `SyncBatchNorm.convert_sync_batchnorm`, `DistributedDataParallel(find_unused_parameters=True)` over RCCL, the loop body with the
+    one-hot / nearest label assembly, `torch.optim.SGD`, `model.module.ema_update()`, PolyLR, RampdownScheduler - against the first
+    iteration of the trace captured from the reference (train_trace_damped.npz, recorded sampler draws injected)."""
+    import json
+    out = str(tmp_path / "ddp.json")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29580", RANK="0", WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, "-c", DDP_WORKER % (ROOT, ROOT, ROOT), out], env=env)
+    assert p.wait(timeout=900) == 0
+    r = json.load(open(out))
+    print(r)
+    assert abs(r["ramp"] - 1.0) < 1e-12                      # RampdownScheduler at epoch 0
+    for k, tol in (("sup", 2e-3), ("unsup", 3e-2), ("con", 2e-3)):
+        hip, ref = r[k]
+        assert abs(hip - ref) < tol * max(1.0, abs(ref)), (k, hip, ref)
+    assert r["mism"] < 1e-3 and r["protos"] < 2e-3
+    for name, (es, et) in r["w"].items():
+        assert es < 3e-2 and et < 3e-2, (name, es, et)
+    assert r["grads_none"] == [], r["grads_none"][:5]        # every student parameter received a gradient through DDP
