@@ -155,7 +155,7 @@ class Model_cross(_StudentTeacher):
         self._init_common(base_encoder, num_classes, output_dim, ema_alpha, config)
         self.temp = temp
 
-    def forward(self, train_l_image, train_u_image, prototypes):
+    def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
@@ -167,11 +167,13 @@ class Model_cross(_StudentTeacher):
             a = generate_cut_gather_3(*a, mode=cfg["mix_mode"])
             u_img, u_lab_c, u_lab_r, u_lc, u_lr = batch_transform_3(*a, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                                     augmentation=True)
-        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
-        with torch.no_grad():
-            _, prob_all, _ = Fn.similarity(rep_all, prototypes, self.temp, want_prob=True)
-        return (pred_l_large, pred_u_large, u_lab_c, u_lab_r, u_lc, u_lr, rep_all.permute(0, 3, 1, 2),
-                prob_all.permute(0, 3, 1, 2))
+        _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
+        prob_all = None
+        if _want_prob:                                                     # the fused trainer derives the hard flags directly instead
+            with torch.no_grad():
+                _, prob_all, _ = Fn.similarity(rep_all, prototypes, self.temp, want_prob=True)
+            prob_all = prob_all.permute(0, 3, 1, 2)
+        return (pred_l_large, pred_u_large, u_lab_c, u_lab_r, u_lc, u_lr, rep_all.permute(0, 3, 1, 2), prob_all)
 
 
 class Model_ori_pseudo(_StudentTeacher):
@@ -179,11 +181,11 @@ class Model_ori_pseudo(_StudentTeacher):
         super().__init__()
         self._init_common(base_encoder, num_classes, output_dim, ema_alpha, config)
 
-    def forward(self, train_l_image, train_u_image):
+    def forward(self, train_l_image, train_u_image, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
             pred_u, _ = self._teacher(train_u_image)
-            raw = ops.bilinear(pred_u, hw[0], hw[1], torch.float32)
+            raw = None if _small_logits else ops.bilinear(pred_u, hw[0], hw[1], torch.float32)   # (7th output: unused by the train body)
             # softmax + max in class space only: the pseudo-label kernel with a constant similarity map
             zero_sim = torch.zeros((*pred_u.shape[:3], self.num_classes), dtype=torch.float32, device=pred_u.device)
             _, _, logits, labels, _ = Fn.pseudo_labels(zero_sim, pred_u, 1.0, hw)
@@ -192,9 +194,9 @@ class Model_ori_pseudo(_StudentTeacher):
                                                  augmentation=False)
             u_img, u_lab, u_lg = generate_cut_gather(u_img, u_lab, u_lg, mode=cfg["mix_mode"])
             u_img, u_lab, u_lg = batch_transform(u_img, u_lab, u_lg, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0), augmentation=True)
-        pred_all, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:])
+        pred_all, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
         return (pred_l_large, pred_u_large, u_lab, u_lg, rep_all.permute(0, 3, 1, 2), pred_all.permute(0, 3, 1, 2),
-                raw.permute(0, 3, 1, 2))
+                None if raw is None else raw.permute(0, 3, 1, 2))
 
 
 @torch.no_grad()

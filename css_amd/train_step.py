@@ -53,6 +53,23 @@ class MixTrainer:
             else:
                 p.grad = self.flat_g[o:o + n].view(p.shape)
 
+    # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
+    def _student_outputs(self, l_img, u_img):
+        """-> low-resolution logits of both halves, (label, confidence) of the unsupervised loss, (label, confidence) behind the
+        contrastive label / mask assembly, rep_all [2B,C,h,w] (NHWC memory), low-resolution logits of all 2B images or None."""
+        pred_l, pred_u, u_lab, u_lc, u_lr, rep_all, _ = self.model.forward(l_img, u_img, self.prototypes, _want_prob=False, _small_logits=True)
+        return pred_l, pred_u, (u_lab, u_lc), (u_lab, u_lc), rep_all, None
+
+    def _contrast_labels(self, u_lab):
+        """mix_label.py:181-182: label_onehot_2 + dropped channel 0 - an ignored (-1) pseudo label belongs to no class."""
+        return u_lab
+
+    def _hard_flags(self, rep_nhwc, cls, pred_small):
+        """A valid pixel is hard when the probability of its own class (prototype similarity soft-max, ddp_model.py:147-154) is
+        below the strong threshold (loss.py:90-91)."""
+        _, _, hard = Fn.similarity(rep_nhwc, self.prototypes, self.model.temp, cls=cls, strong_threshold=self.crit_contrast.strong_threshold)
+        return hard
+
     @property
     def lr(self):
         return poly_lr(self.base_lr, self.it, self.total_iter, 0.9, self.min_lr)
@@ -62,20 +79,19 @@ class MixTrainer:
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
         # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
         # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144
-        pred_l, pred_u, u_lab, u_lc, u_lr, rep_all, _ = m.forward(l_img, u_img, self.prototypes, _want_prob=False, _small_logits=True)
+        pred_l, pred_u, (un_lab, un_conf), (u_lab, u_lc), rep_all, pred_small = self._student_outputs(l_img, u_img)
         if self.fused_loss and fused_upsample_ok(pred_l.shape[1:3], l_img.shape[2:]):
             sup = (self.crit_ohem or self.crit_ce).forward_small(pred_l, l_lab)
-            unsup = self.crit_unsup.forward_small(pred_u, u_lab, u_lc)
+            unsup = self.crit_unsup.forward_small(pred_u, un_lab, un_conf)
         else:
             hh, ww = l_img.shape[2:]
             sup = (self.crit_ohem or self.crit_ce)(ops.bilinear(pred_l, hh, ww, torch.float32).permute(0, 3, 1, 2), l_lab)
-            unsup = self.crit_unsup(ops.bilinear(pred_u, hh, ww, torch.float32).permute(0, 3, 1, 2), u_lab, u_lc)
+            unsup = self.crit_unsup(ops.bilinear(pred_u, hh, ww, torch.float32).permute(0, 3, 1, 2), un_lab, un_conf)
         b2, c, h, w = rep_all.shape
         rep_rows = rep_all.permute(0, 2, 3, 1).reshape(b2 * h * w, c)         # zero-copy: rep_all is NHWC memory
         with torch.no_grad():
-            cls = Fn.class_map(l_lab, u_lab, u_lc, self.weak_threshold, (h, w))
-            _, _, hard = Fn.similarity(rep_rows.view(b2, h, w, c), self.prototypes, m.temp, cls=cls,
-                                       strong_threshold=self.crit_contrast.strong_threshold)
+            cls = Fn.class_map(l_lab, self._contrast_labels(u_lab), u_lc, self.weak_threshold, (h, w))
+            hard = self._hard_flags(rep_rows.view(b2, h, w, c), cls, pred_small)
         con = self.crit_contrast.forward_fused(rep_rows, cls, hard, self.prototypes, self.K, _injected)
         total = sup + unsup + con * ramp
         with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
@@ -91,3 +107,41 @@ class MixTrainer:
         m.step += 1
         self.it += 1
         return dict(sup=sup.detach(), unsup=unsup.detach(), contrast=con.detach(), total=total.detach(), pseudo=u_lab)
+
+
+class CrossTrainer(MixTrainer):
+    """The train body of cross_label.py:162-198 for ``Model_cross``: the unsupervised loss follows the class-predictor pseudo labels
+    while ``warmup`` is set (epoch < args.warmup, :174-175) and the representation-space ones afterwards (:176-177); the contrastive
+    label / mask assembly always uses the class-predictor maps through ``label_onehot`` (:186-187), whose ReLU sends an ignored (-1)
+    label to class 0."""
+
+    def __init__(self, *a, warmup=True, **k):
+        super().__init__(*a, **k)
+        self.warmup = warmup
+
+    def _student_outputs(self, l_img, u_img):
+        pred_l, pred_u, u_lab_c, u_lab_r, u_lc, u_lr, rep_all, _ = self.model.forward(l_img, u_img, self.prototypes, _want_prob=False,
+                                                                                    _small_logits=True)
+        un = (u_lab_c, u_lc) if self.warmup else (u_lab_r, u_lr)
+        return pred_l, pred_u, un, (u_lab_c, u_lc), rep_all, None
+
+    def _contrast_labels(self, u_lab):
+        return torch.relu(u_lab)
+
+
+class OriTrainer(MixTrainer):
+    """The train body of ori_pseudo.py:158-187 for ``Model_ori_pseudo``: no prototype similarity in the model; ``prob_all`` of the
+    contrastive loss is the soft-max of the student's own low-resolution logits (:178), labels through ``label_onehot`` (ReLU)."""
+
+    def _student_outputs(self, l_img, u_img):
+        pred_l, pred_u, u_lab, u_lg, rep_all, pred_all, _ = self.model.forward(l_img, u_img, _small_logits=True)
+        return pred_l, pred_u, (u_lab, u_lg), (u_lab, u_lg), rep_all, pred_all
+
+    def _contrast_labels(self, u_lab):
+        return torch.relu(u_lab)
+
+    def _hard_flags(self, rep_nhwc, cls, pred_small):
+        b2, k, h, w = pred_small.shape                                    # logical NCHW view of NHWC memory
+        prob = torch.softmax(pred_small.detach().permute(0, 2, 3, 1).reshape(b2 * h * w, k).float(), dim=1)
+        own = prob.gather(1, cls.clamp(min=0).long().unsqueeze(1)).squeeze(1)
+        return ((cls >= 0) & (own < self.crit_contrast.strong_threshold)).to(torch.uint8)

@@ -127,3 +127,71 @@ def test_entry_script_train_body_vs_reference_trace(golden, kind):
         assert es < 3e-2 and et < 3e-2
     assert rel_err(sde["resnet_bn1.running_mean"].float().cpu(), T(g["teacher_rm::resnet_bn1"])) < 1e-3
     assert all(torch.isfinite(q).all() for q in model.model.parameters())
+
+
+def _build(kind, g):
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_cross, Model_ori_pseudo
+    from oracle import css_oracle as O
+    seed, gain, weak = int(g["seed"]), float(g["residual_gain"]), float(g["weak"])
+    config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Loss": {"weak_threshold": weak}}
+    if kind == "cross":
+        model = Model_cross(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=config, temp=0.5)
+    else:
+        model = Model_ori_pseudo(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=config)
+    sd = O.init_state("tv", K, 256, seed, gain)
+    model.model.load_state_dict(sd, strict=True)
+    model.ema_model.load_state_dict(sd, strict=True)
+    model = model.to(dev())
+    model.model.train()
+    model.ema_model.train()
+    return model, weak
+
+
+@pytest.mark.parametrize("kind", ["cross", "ori"])
+def test_fused_trainers_vs_reference_trace(golden, kind):
+    """CrossTrainer / OriTrainer (css_amd/train_step.py: the same bodies with the fused losses, the class-id map instead of one-hot
+    tensors, direct gradient accumulation and the fused SGD+EMA kernel) against the same captured iteration."""
+    from css_amd.train_step import CrossTrainer, OriTrainer
+    from css_amd.utils import label_onehot
+    g = golden(f"train_trace_{kind}")
+    l_img, u_img, l_lab = T(g["l_img"]).to(dev()), T(g["u_img"]).to(dev()), T(g["l_lab"]).long().to(dev())
+    # the sampler draws of the reference run, lined up through a plain forward of a twin model
+    twin, weak = _build(kind, g)
+    with torch.no_grad():
+        protos0 = torch.zeros(K, 256, device=dev())
+        if kind == "cross":
+            _, _, ulab, _, ulc, _, rep_all, prob_all = twin(l_img, u_img, protos0)
+        else:
+            _, _, ulab, ulc, rep_all, pred_all, _ = twin(l_img, u_img)
+            prob_all = torch.softmax(pred_all, dim=1)
+        mask_all = torch.cat(((l_lab.unsqueeze(1) >= 0).float(), ulc.ge(weak).float().unsqueeze(1)))
+        mask_all = F.interpolate(mask_all, size=prob_all.shape[2:], mode="nearest")
+        label_all = torch.cat((F.interpolate(label_onehot(l_lab, K), size=prob_all.shape[2:], mode="nearest"),
+                               F.interpolate(label_onehot(ulab, K), size=prob_all.shape[2:], mode="nearest")))
+        inj = _injection(g, rep_all, label_all, mask_all, prob_all, protos0)
+    del twin
+    model, weak = _build(kind, g)
+    cls = CrossTrainer if kind == "cross" else OriTrainer
+    tr = cls(model, K, lr=6.4e-3, total_iter=100, min_lr=1e-4, num_queries=64, num_negatives=128, strong_threshold=0.8,
+             weak_threshold=weak, un_threshold=0.97)
+    r = tr.step(l_img, l_lab, u_img, ramp=1.0, _injected=inj)
+    fails = []
+    for name, key, tol in (("sup", "sup", 2e-3), ("unsup", "unsup", 3e-2), ("con", "contrast", 2e-3)):
+        ref = float(g[name])
+        print(f"fused {kind} {name}: hip {r[key].item():.6f} reference {ref:.6f}")
+        if not abs(r[key].item() - ref) < tol * max(1.0, abs(ref)):
+            fails.append((name, r[key].item(), ref))
+    assert not fails, fails
+    assert (r["pseudo"].cpu() != T(g["ulab"]).long()).float().mean().item() < 1e-3
+    e = rel_err(tr.prototypes.cpu(), T(g["protos"]))
+    print(f"fused {kind}: prototypes rel err {e:.2e}")
+    assert e < 2e-3
+    assert abs(tr.lr - float(g["lr_next"])) < 1e-9
+    sdm, sde = model.model.state_dict(), model.ema_model.state_dict()
+    for p in PROBES:
+        es = rel_err(probe_slice(sdm[p]).float().cpu(), T(g[f"student::{p}"]))
+        et = rel_err(probe_slice(sde[p]).float().cpu(), T(g[f"teacher::{p}"]))
+        print(f"fused {kind} {p}: student {es:.2e} teacher {et:.2e}")
+        assert es < 3e-2 and et < 3e-2
+    assert rel_err(sde["resnet_bn1.running_mean"].float().cpu(), T(g["teacher_rm::resnet_bn1"])) < 1e-3
