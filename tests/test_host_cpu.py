@@ -84,6 +84,13 @@ def test_module_surface_and_checkpoint_keys():
     assert list(inspect.signature(Model_mix.__init__).parameters)[1:] == ["base_encoder", "num_classes", "output_dim", "ema_alpha", "config", "temp"]
     assert list(inspect.signature(Contrast_Loss.__init__).parameters)[1:] == ["num_queries", "num_negatives", "temp", "mean", "strong_threshold", "alpha"]
     assert list(inspect.signature(Contrast_Loss.forward).parameters)[1:6] == ["rep", "label", "mask", "prob", "prototypes"]
+    # the public call signatures of the two other step wrappers (ddp_model.py:184, :32); internal flags are keyword-only extras
+    assert list(inspect.signature(Model_cross.forward).parameters)[1:4] == ["train_l_image", "train_u_image", "prototypes"]
+    assert list(inspect.signature(Model_ori_pseudo.forward).parameters)[1:3] == ["train_l_image", "train_u_image"]
+    assert list(inspect.signature(Model_cross.__init__).parameters)[1:] == ["base_encoder", "num_classes", "output_dim", "ema_alpha", "config", "temp"]
+    assert list(inspect.signature(Model_ori_pseudo.__init__).parameters)[1:] == ["base_encoder", "num_classes", "output_dim", "ema_alpha", "config"]
+    from css_amd.train_step import CrossTrainer, MixTrainer, OriTrainer
+    assert issubclass(CrossTrainer, MixTrainer) and issubclass(OriTrainer, MixTrainer)
     import io, contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         m = Model_mix(resnet.resnet101_tv(), num_classes=21, config={"Dataset": {}}, temp=0.5)
