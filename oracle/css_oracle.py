@@ -630,6 +630,72 @@ def train_step_mix(st: MixState, l_img, l_lab, u_img, *, lr, temp_model=0.5, str
                 pred_l=pred_l.detach(), rep_all=rep_all.detach(), pseudo=u_aug_label, grads=grads)
 
 
+def build_label_mask_relu(l_label, u_label, u_logits, weak_threshold, num_class, out_hw):
+    """cross_label.py:180-188 / ori_pseudo.py:170-177: as build_label_mask, but the unlabeled half goes through ``label_onehot``
+    (ReLU: an ignored -1 pseudo label becomes class 0) instead of ``label_onehot_2``."""
+    u_mask = u_logits.ge(weak_threshold).float()
+    mask_all = torch.cat(((l_label.unsqueeze(1) >= 0).float(), u_mask.unsqueeze(1)))
+    mask_all = F.interpolate(mask_all, size=out_hw, mode="nearest")
+    label_l = F.interpolate(label_onehot(l_label, num_class), size=out_hw, mode="nearest")
+    label_u = F.interpolate(label_onehot(u_label, num_class), size=out_hw, mode="nearest")
+    return torch.cat((label_l, label_u)), mask_all
+
+
+def train_step_w5(st: MixState, kind, l_img, l_lab, u_img, *, lr, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.7,
+                  un_threshold=0.97, num_queries=256, num_negatives=512, temp_loss=0.5, alpha_proto=0.99, ema_alpha=0.99, ramp=1.0,
+                  warmup=True, injected=None, record=None):
+    """One iteration of the train body of cross_label.py:162-198 (``kind='cross'``: Model_cross.forward ddp_model.py:184-239;
+    ``warmup`` = epoch < args.warmup selects the class-predictor pseudo labels for the unsupervised loss, :174-177) or of
+    ori_pseudo.py:158-187 (``kind='ori'``: Model_ori_pseudo.forward ddp_model.py:32-70, teacher on the unlabeled batch only,
+    prob_all = softmax of the student's logits :178, no ramp), identity augmentation as in train_step_mix."""
+    K = st.num_classes
+    H, W = l_img.shape[2:]
+    for n in st.pnames:
+        st.student[n].requires_grad_(True)
+        st.student[n].grad = None
+    with torch.no_grad():
+        if kind == "cross":
+            deeplab_forward(st.teacher, l_img, st.backbone, True, K, st.output_dim)           # ddp_model.py:187 (running stats)
+            pred_u, rep_u = deeplab_forward(st.teacher, u_img, st.backbone, True, K, st.output_dim)
+            lg_rep, lb_rep, lg_cls, lb_cls, _ = pseudo_labels_mix(pred_u, rep_u, st.prototypes, temp_model, (H, W), K)
+            lab_cls, lab_rep = identity_aug_label(lb_cls), identity_aug_label(lb_rep)
+        else:
+            pred_u, _ = deeplab_forward(st.teacher, u_img, st.backbone, True, K, st.output_dim)   # ddp_model.py:35
+            pred_large = F.interpolate(pred_u, size=(H, W), mode="bilinear", align_corners=True)
+            lg_cls, lb_cls = torch.max(torch.softmax(pred_large, dim=1), dim=1)
+            lab_cls = identity_aug_label(lb_cls)
+    pred_l, rep_l = deeplab_forward(st.student, l_img, st.backbone, True, K, st.output_dim)
+    pred_l_large = F.interpolate(pred_l, size=(H, W), mode="bilinear", align_corners=True)
+    pred_u2, rep_u2 = deeplab_forward(st.student, u_img, st.backbone, True, K, st.output_dim)
+    pred_u_large = F.interpolate(pred_u2, size=(H, W), mode="bilinear", align_corners=True)
+    rep_all = torch.cat((rep_l, rep_u2))
+    with torch.no_grad():
+        if kind == "cross":
+            prob_all = prob_all_from_rep(rep_all, st.prototypes, temp_model)
+        else:
+            prob_all = torch.softmax(torch.cat((pred_l, pred_u2)), dim=1)                   # ori_pseudo.py:178 on ddp_model.py:61
+    sup_loss = ce_loss(pred_l_large, l_lab)
+    if kind == "cross" and not warmup:
+        unsup_loss = attention_threshold_loss(pred_u_large, lab_rep, lg_rep, un_threshold)
+    else:
+        unsup_loss = attention_threshold_loss(pred_u_large, lab_cls, lg_cls, un_threshold)
+    with torch.no_grad():
+        label_all, mask_all = build_label_mask_relu(l_lab, lab_cls, lg_cls, weak_threshold, K, rep_all.shape[2:])
+    c_loss = contrast_loss(rep_all, label_all, mask_all, prob_all, st.prototypes, num_queries, num_negatives,
+                           temp_loss, strong_threshold, alpha_proto, injected=injected, record=record)
+    total = sup_loss + unsup_loss + c_loss * (ramp if kind == "cross" else 1.0)
+    total.backward()
+    params = [st.student[n] for n in st.pnames]
+    grads = [p.grad for p in params]
+    with torch.no_grad():
+        sgd_nesterov_step(params, grads, st.mom, lr)
+        st.step = ema_update([st.teacher[n] for n in st.pnames], params, st.step, ema_alpha)
+    for n in st.pnames:
+        st.student[n].requires_grad_(False)
+    return dict(sup=float(sup_loss), unsup=float(unsup_loss), contrast=float(c_loss), total=float(total), pseudo=lab_cls,
+                logits_cls=lg_cls, pseudo_rep=lab_rep if kind == "cross" else None)
+
+
 # ---------------------------------------------------------------------------
 # evaluation path (SURVEY 8f-3): mix_label.py:199-225, util/meter.py:39-48, util/miou.py:3-9
 # ---------------------------------------------------------------------------

@@ -234,6 +234,43 @@ def test_train_trace(golden, tag):
         close(st.teacher["resnet_bn1.running_mean"], g[f"{it}::teacher_rm::resnet_bn1"], lt * 4, 1e-6)
 
 
+@pytest.mark.parametrize("kind", ["cross", "ori"])
+def test_train_trace_w5(golden, kind):
+    """One iteration of the cross_label.train / ori_pseudo.train bodies vs the reference's Model_cross / Model_ori_pseudo traces."""
+    import copy
+    g = golden(f"train_trace_{kind}")
+    st = O.MixState("tv", 21, 256, int(g["seed"]), float(g["residual_gain"]))
+    args = dict(lr=6.4e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=float(g["weak"]), un_threshold=0.97,
+                num_queries=64, num_negatives=128)
+    l_img, l_lab, u_img = T(g["l_img"]), T(g["l_lab"]).long(), T(g["u_img"])
+    rec = {}
+    O.train_step_w5(copy.deepcopy(st), kind, l_img, l_lab, u_img, record=rec, **args)
+    anchors, negs, j = [], [], 0
+    for hn in rec["hard_num"]:
+        if hn > 0:
+            anchors.append(g[f"anchor{j}"].astype(np.int64))
+            negs.append(g[f"negative{j}"].astype(np.int64))
+            j += 1
+        else:
+            anchors.append(None)
+            negs.append(None)
+    assert j == int(g["n_anchor"])
+    r = O.train_step_w5(st, kind, l_img, l_lab, u_img, injected=dict(anchor=anchors, negative=negs), **args)
+    close(r["sup"], g["sup"], 1e-4, 1e-6)
+    close(r["unsup"], g["unsup"], 4e-4, 1e-6)
+    close(r["contrast"], g["con"], 1e-4, 1e-6)
+    assert torch.equal(r["pseudo"], T(g["ulab"]).long())
+    if kind == "cross":
+        assert torch.equal(r["pseudo_rep"], T(g["ulab_rep"]).long())
+    close(r["logits_cls"], g["ulc"], 1e-4, 1e-6)
+    close(st.prototypes, g["protos"], 4e-4, 1e-6)
+    for p in ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]:
+        close(probe_slice(st.student[p]), g[f"student::{p}"], 5e-3, 1e-6)
+        close(probe_slice(st.teacher[p]), g[f"teacher::{p}"], 5e-3, 1e-6)
+    close(st.teacher["resnet_bn1.running_mean"], g["teacher_rm::resnet_bn1"], 4e-4, 1e-6)
+    assert abs(O.poly_lr(6.4e-3, 1, 100) - float(g["lr_next"])) < 1e-12
+
+
 def test_eval_confusion_matrix_and_miou(golden):
     """Eval path (mix_label.py:199-225): oracle == the reference's ConfMatrix / mean_intersection_over_union on the fixture."""
     g = golden("eval")
