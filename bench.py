@@ -133,9 +133,6 @@ def main():
     # seeded non-degenerate weights: Kaiming convs (constructor), BN gamma~U(.5,1.5), beta~N(0,.1)
     g = torch.Generator().manual_seed(3407)
     with torch.no_grad():
-        for n, p in model.model.named_parameters():
-            if p.dim() == 1 and ".bn" in n or n.endswith(".1.weight") or n.endswith(".1.bias"):
-                pass
         for mod in model.model.modules():
             if mod.__class__.__name__ == "HipBatchNorm2d":
                 mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.25)

@@ -81,7 +81,8 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
     p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"][: len(r1["pred"])])
     # rank 0 of the 2-rank run holds the first two images: compare against the first half of the single-process output
     n = len(r2["pred"])
-    assert ((p1[:n] - torch.tensor(r2["pred"])).abs().max() / p1.abs().max()).item() < 1e-3 or True
+    # (rank 0 of the 2-rank run holds the first two images; reported, the assertions are on loss, gradient and running statistics)
+    print("world1 vs world2: max logit difference", ((p1[:n] - torch.tensor(r2["pred"])).abs().max() / p1.abs().max()).item())
     g1, g2 = torch.tensor(r1["grad"]), torch.tensor(r2["grad"])
     cos = torch.nn.functional.cosine_similarity(g1, g2, dim=0).item()
     rel = ((g1 - g2).norm() / g1.norm()).item()
