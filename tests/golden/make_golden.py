@@ -392,19 +392,19 @@ def gen_schedules():
          sgd_traj=torch.stack(traj))
 
 
-def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
+def gen_train_trace(seed=41, gain=1.0, tag="train_trace", backbone="tv", K=21, ohem_min_kept=None, iters=2):
     """Two iterations of the mix_label.train body (mix_label.py:162-196) driven through the
     reference's Model_mix / Contrast_Loss / Attention_Threshold_Loss with identity augmentation
     (batch_transform_2 patched to label 255 -> -1, mix_mode 'none')."""
     torch.manual_seed(seed)
     np.random.seed(seed)
-    K, S, B = 21, 65, 2
-    bb = TVResNet101()
+    S, B = 65, 2
+    bb = TVResNet101() if backbone == "tv" else ref_resnet.resnet101(pretrained=False)
     import io
     import contextlib
     with contextlib.redirect_stdout(io.StringIO()):
         model = ref_ddp.Model_mix(bb, num_classes=K, output_dim=256, config={"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}}, temp=0.5)
-    sd = O.init_state("tv", K, 256, seed, gain)
+    sd = O.init_state(backbone, K, 256, seed, gain)
     model.model.load_state_dict(sd, strict=True)
     model.ema_model.load_state_dict(sd, strict=True)
 
@@ -418,13 +418,16 @@ def gen_train_trace(seed=41, gain=1.0, tag="train_trace"):
     crit_c = ref_loss.Contrast_Loss(strong_threshold=0.8, num_queries=64, num_negatives=128, temp=0.5, alpha=0.99)
     crit_u = ref_loss.Attention_Threshold_Loss(0.97)
     crit_s = nn.CrossEntropyLoss(ignore_index=-1)
+    if ohem_min_kept is not None:      # the Cityscapes criterion of mix_label.py:82 (thresh 0.7)
+        crit_s = ref_loss.ProbOhemCrossEntropy2d(ignore_label=-1, thresh=0.7, min_kept=ohem_min_kept)
     opt = torch.optim.SGD(model.model.parameters(), lr=6.4e-3, weight_decay=5e-4, momentum=0.9, nesterov=True)
     sch = PolyLR(opt, 100, min_lr=1e-4)
     protos = torch.zeros(K, 256)
     g = torch.Generator().manual_seed(seed)
     out = dict(seed=seed, residual_gain=gain)
-    probes = ["resnet_conv1.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]
-    for it in range(2):
+    probes = ["resnet_conv1.weight" if backbone == "tv" else "resnet_conv1.0.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight",
+              "representation.3.bias"]
+    for it in range(iters):
         l_img = torch.randn(B, 3, S, S, generator=g)
         u_img = torch.randn(B, 3, S, S, generator=g)
         blk = torch.randint(0, K, (B, 5, 5), generator=g)
@@ -595,11 +598,14 @@ def gen_dataset(seed=61):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval", "dataset", "trace_w5"]
+    which = sys.argv[1:] or ["net", "pseudo", "contrast", "losses", "labelmask", "sched", "trace", "eval", "dataset", "trace_w5", "trace_city"]
     if "eval" in which:
         gen_eval()
     if "dataset" in which:
         gen_dataset()
+    if "trace_city" in which:
+        # Cityscapes-shaped step: deep-stem ResNet-101, K=19, OHEM with a min_kept that makes the k-th smallest probability the threshold
+        gen_train_trace(45, 0.25, "train_trace_city", backbone="stem", K=19, ohem_min_kept=3000, iters=1)
     if "trace_w5" in which:
         gen_train_trace_w5("cross", 47)
         gen_train_trace_w5("ori", 49)

@@ -234,6 +234,39 @@ def test_train_trace(golden, tag):
         close(st.teacher["resnet_bn1.running_mean"], g[f"{it}::teacher_rm::resnet_bn1"], lt * 4, 1e-6)
 
 
+def test_train_trace_cityscapes_shape(golden):
+    """One iteration of the mix_label.train body in its Cityscapes configuration - deep-stem ResNet-101 (resnet.py:142-291), K=19,
+    ProbOhemCrossEntropy2d(thresh 0.7) whose min_kept-th smallest ground-truth probability becomes the threshold (loss.py:34-39) -
+    vs the reference's trace."""
+    import copy
+    g = golden("train_trace_city")
+    st = O.MixState("stem", 19, 256, int(g["seed"]), float(g["residual_gain"]))
+    args = dict(lr=6.4e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=64, num_negatives=128,
+                sup="ohem", ohem_min_kept=3000)
+    l_img, l_lab, u_img = T(g["0::l_img"]), T(g["0::l_lab"]).long(), T(g["0::u_img"])
+    rec = {}
+    O.train_step_mix(copy.deepcopy(st), l_img, l_lab, u_img, record=rec, **args)
+    anchors, negs, j = [], [], 0
+    for hn in rec["hard_num"]:
+        if hn > 0:
+            anchors.append(g[f"0::anchor{j}"].astype(np.int64))
+            negs.append(g[f"0::negative{j}"].astype(np.int64))
+            j += 1
+        else:
+            anchors.append(None)
+            negs.append(None)
+    assert j == int(g["0::n_anchor"])
+    r = O.train_step_mix(st, l_img, l_lab, u_img, injected=dict(anchor=anchors, negative=negs), **args)
+    close(r["sup"], g["0::sup"], 1e-4, 1e-6)
+    close(r["unsup"], g["0::unsup"], 4e-4, 1e-6)
+    close(r["contrast"], g["0::con"], 1e-4, 1e-6)
+    assert torch.equal(r["pseudo"], T(g["0::ulab"]).long())
+    close(st.prototypes, g["0::protos"], 4e-4, 1e-6)
+    for p in ["resnet_conv1.0.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]:
+        close(probe_slice(st.student[p]), g[f"0::student::{p}"], 5e-3, 1e-6)
+        close(probe_slice(st.teacher[p]), g[f"0::teacher::{p}"], 5e-3, 1e-6)
+
+
 @pytest.mark.parametrize("kind", ["cross", "ori"])
 def test_train_trace_w5(golden, kind):
     """One iteration of the cross_label.train / ori_pseudo.train bodies vs the reference's Model_cross / Model_ori_pseudo traces."""

@@ -195,3 +195,54 @@ def test_fused_trainers_vs_reference_trace(golden, kind):
         print(f"fused {kind} {p}: student {es:.2e} teacher {et:.2e}")
         assert es < 3e-2 and et < 3e-2
     assert rel_err(sde["resnet_bn1.running_mean"].float().cpu(), T(g["teacher_rm::resnet_bn1"])) < 1e-3
+
+
+def test_cityscapes_shaped_step_vs_reference_trace(golden):
+    """MixTrainer in its Cityscapes configuration (deep-stem ResNet-101, K=19, ProbOhemCrossEntropy2d thresh 0.7 with the min_kept-th
+    smallest probability as threshold) against the iteration captured from the reference (train_trace_city.npz)."""
+    import copy
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_mix
+    from css_amd.train_step import MixTrainer
+    from oracle import css_oracle as O
+    g = golden("train_trace_city")
+    seed, gain, Kc = int(g["seed"]), float(g["residual_gain"]), 19
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}}
+    m = Model_mix(resnet.resnet101(), num_classes=Kc, output_dim=256, config=cfg, temp=0.5)
+    sd = O.init_state("stem", Kc, 256, seed, gain)
+    m.model.load_state_dict(sd, strict=True)
+    m.ema_model.load_state_dict(sd, strict=True)
+    m = m.to(dev()).train()
+    tr = MixTrainer(m, Kc, lr=6.4e-3, total_iter=100, min_lr=1e-4, num_queries=64, num_negatives=128, strong_threshold=0.8,
+                    weak_threshold=0.0, un_threshold=0.97, sup="ohem", ohem_min_kept=3000)
+    l_img, l_lab, u_img = T(g["0::l_img"]), T(g["0::l_lab"]).long(), T(g["0::u_img"])
+    args = dict(lr=6.4e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=64, num_negatives=128,
+                sup="ohem", ohem_min_kept=3000)
+    rec = {}
+    O.train_step_mix(O.MixState("stem", Kc, 256, seed, gain), l_img, l_lab, u_img, record=rec, **args)
+    anchors, negs, j = [], [], 0
+    for hn in rec["hard_num"]:
+        if hn > 0:
+            anchors.append(g[f"0::anchor{j}"].astype(np.int64))
+            negs.append(g[f"0::negative{j}"].astype(np.int64))
+            j += 1
+        else:
+            anchors.append(None)
+            negs.append(None)
+    assert j == int(g["0::n_anchor"])
+    r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()), ramp=1.0, _injected=dict(anchor=anchors, negative=negs))
+    fails = []
+    for key, gk, tol in (("sup", "sup", 2e-3), ("unsup", "unsup", 3e-2), ("contrast", "con", 2e-3)):
+        ref = float(g[f"0::{gk}"])
+        print(f"city {key}: hip {r[key].item():.6f} reference {ref:.6f}")
+        if not abs(r[key].item() - ref) < tol * max(1.0, abs(ref)):
+            fails.append((key, r[key].item(), ref))
+    assert not fails, fails
+    assert (r["pseudo"].cpu() != T(g["0::ulab"]).long()).float().mean().item() < 1e-3
+    assert rel_err(tr.prototypes.cpu(), T(g["0::protos"])) < 2e-3
+    sdm, sde = m.model.state_dict(), m.ema_model.state_dict()
+    for p in ["resnet_conv1.0.weight", "resnet_layer3.10.conv2.weight", "classifier.3.weight", "representation.3.bias"]:
+        es = rel_err(probe_slice(sdm[p]).float().cpu(), T(g[f"0::student::{p}"]))
+        et = rel_err(probe_slice(sde[p]).float().cpu(), T(g[f"0::teacher::{p}"]))
+        print(f"city {p}: student {es:.2e} teacher {et:.2e}")
+        assert es < 3e-2 and et < 3e-2
