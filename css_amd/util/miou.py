@@ -3,6 +3,9 @@ import torch
 
 
 def mean_intersection_over_union(mat: torch.Tensor):
-    h = mat.float()
-    iu = torch.diag(h) / (h.sum(1) + h.sum(0) - torch.diag(h))
-    return torch.mean(iu).item()
+    """Mean over classes of TP / (row sum + column sum - TP) of a K x K confusion matrix (rows = ground truth), as a Python float.
+    A class that never occurs and is never predicted contributes 0/0 = NaN, like the reference's expression."""
+    counts = mat.to(torch.float32)
+    hits = counts.diagonal()
+    union = counts.sum(dim=1) + counts.sum(dim=0) - hits
+    return float((hits / union).mean())
