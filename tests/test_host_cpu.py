@@ -247,3 +247,23 @@ def test_eval_and_checkpoint_modules_import_without_gpu_and_alias():
         ConfMatrix(2).update(torch.zeros(2, dtype=torch.int64), torch.zeros(2, dtype=torch.int64))     # CPU tensors: no CPU path
     import css_amd.checkpoint as ck
     assert callable(ck.save_checkpoint) and callable(ck.load_checkpoint)
+
+
+def test_collectives_switch(tmp_path):
+    """ops.collectives_on(): off without a process group, on for a multi-rank group, and on for a ONE-rank group only with
+    CSS_FORCE_COLLECTIVES=1 (the single-GPU RCCL exercise of tests/test_dist_gpu.py and bench.py)."""
+    import subprocess
+    import sys
+    code = (
+        "import os, sys; sys.path.insert(0, %r)\n"
+        "import torch.distributed as dist\n"
+        "from css_amd import ops\n"
+        "assert ops.collectives_on() is False\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT='29583')\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "assert ops.collectives_on() is (os.environ.get('CSS_FORCE_COLLECTIVES') == '1')\n"
+        "assert ops._world() == 1\n"
+        "dist.destroy_process_group()\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for force in ("0", "1"):
+        env = dict(os.environ, CSS_FORCE_COLLECTIVES=force)
+        assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
