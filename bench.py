@@ -2,18 +2,28 @@
 """Throughput of the CSS mix_label training step on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" = one iteration of mix_label.train (teacher fwd on labeled+unlabeled, student fwd+bwd on labeled+augmented
-unlabeled, CE + confidence-weighted CE + prototype contrastive loss, fused SGD+EMA) over B labeled + B unlabeled
-synthetic 513x513 crops per GPU (BASELINE.json configs[1]: VOC-shaped, torchvision-shaped ResNet-101 DeepLabv3+, B=16, bf16).
-Weak scaling: every rank owns its own B+B crops; SyncBN statistics, prototype sums and the flat gradient are the only
-exchanges (RCCL).  Rank 0 prints ONE JSON line.
+N > 1 with WORLD_SIZE unset: this process starts N fresh children of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+environment, one per GPU) BEFORE it touches the GPU, relays rank 0's line and exits non-zero if any child fails - the counterpart of
+the reference's own ``mp.spawn`` (/root/reference/mix_label.py:265).  Under ``python -m torch.distributed.run`` (WORLD_SIZE set) it is
+one rank of that job.
+
+A "step" = one iteration of mix_label.train (teacher fwd on labeled+unlabeled, student fwd+bwd on labeled+augmented unlabeled,
+CE + confidence-weighted CE + prototype contrastive loss, fused SGD+EMA; /root/reference/mix_label.py:162-196) over B labeled + B
+unlabeled synthetic crops per GPU.  Default workload c2 = BASELINE.json configs[1]: VOC-shaped 513x513, torchvision-shaped ResNet-101
+DeepLabv3+, B=16, bf16.  Weak scaling: every rank owns its own B+B crops; SyncBN statistics, prototype sums and the flat gradient are
+the only exchanges (RCCL).  Rank 0 prints ONE JSON line; at N=1 it also carries
+  * ``extra.c4``: 3 steps of the Cityscapes-shaped 769x769 workload (BASELINE configs[3] shape on one GPU),
+  * ``extra.c2_forced_valid``: 2 steps of c2 with every unlabeled pixel valid (SURVEY 8d "forced-valid": worst-case contrastive load),
+  * ``cpu_baseline``: the CPU oracle timed on the host cores.
 """
 import argparse
 import contextlib
+import ctypes
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,11 +34,58 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FWD_FLOP_513_TV = 541.7e9          # forward FLOPs / image, tv-R101, 513^2, K=21
+FWD_FLOP_769_STEM = 1239.1e9       # deep-stem R101, 769^2, K=19
 PEAK_BF16 = 2.5e15                 # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F32 = 157.3e12
+PEAK_HBM = 8.0e12                  # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s measured by a float4 copy)
+
+KINDS = ((0, "conv_fwd_other"), (1, "conv_dgrad_other"), (2, "conv_wgrad_other"), (3, "contrast_gather"), (4, "similarity"),
+         (5, "igemm256_fwd"), (6, "igemm256_dgrad"), (7, "wgrad256"), (8, "bn_apply"), (9, "bn_bwd_apply"), (10, "bn_bwd_reduce"),
+         (11, "sgd_ema"), (12, "conv1x1_short_k_fwd"))
+WORKLOADS = {
+    # name: (K, S, B, backbone, sup, Q, N, BASELINE configs index)
+    "c2": (21, 513, 16, "tv", "ce", 256, 512, 1),
+    "c4": (19, 769, 8, "stem", "ohem", 256, 512, 3),
+    "c5": (19, 769, 8, "stem", "ohem", 1024, 2048, 4),
+}
 
 
+# ---- N > 1 without a launcher: start the ranks ourselves -------------------------------------------------------------------------
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_children(n, argv):
+    """Start n fresh python processes of this file (never a re-exec of a process that touched the GPU), wait for all, relay rank 0's
+    stdout (children inherit it: only rank 0 prints) and return non-zero if any of them failed."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        for p in list(alive):
+            r = p.poll()
+            if r is None:
+                continue
+            alive.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 1
+                for q in alive:           # a dead rank leaves the others blocked in a collective: stop exactly the PIDs we started
+                    q.terminate()
+        time.sleep(0.05)
+    return rc
+
+
+# ---- workload ------------------------------------------------------------------------------------------------------------------------
 def synth_batch(B, S, K, seed, dev):
-    """images N(0,1); labels piecewise-constant 32x32 blocks uniform over K classes, 5 % of blocks = -1."""
+    """images N(0,1); labels piecewise-constant 32x32 blocks uniform over K classes, 5 % of blocks = -1.
+    Also returns block labels for the unlabeled crops (no ignore blocks): used by the forced-valid variant only."""
     g = torch.Generator().manual_seed(seed)
     l_img = torch.randn(B, 3, S, S, generator=g)
     u_img = torch.randn(B, 3, S, S, generator=g)
@@ -36,101 +93,46 @@ def synth_batch(B, S, K, seed, dev):
     blk = torch.randint(0, K, (B, nb, nb), generator=g)
     blk[torch.rand(B, nb, nb, generator=g) < 0.05] = -1
     l_lab = blk.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :S, :S].contiguous()
-    return l_img.to(dev), l_lab.to(dev), u_img.to(dev)
+    ublk = torch.randint(0, K, (B, nb, nb), generator=g)
+    u_blk = ublk.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :S, :S].contiguous()
+    return l_img.to(dev), l_lab.to(dev), u_img.to(dev), u_blk.to(dev)
 
 
-def cpu_baseline(threads=None):
-    """The oracle (CPU restatement of the reference path, kind 'port') on BASELINE config 1 (321x321, B=2+2, fp32,
-    tv-R101, Q=256, N=512): one un-timed teacher-only warm-up, then ONE timed training step (bounded sample)."""
-    import numpy as np
-    from oracle import css_oracle as O
-    if threads:
-        torch.set_num_threads(threads)
-    K, S, B = 21, 321, 2
-    st = O.MixState("tv", K, 256, 3407)
-    g = torch.Generator().manual_seed(3407)
-    l_img, u_img = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
-    blk = torch.randint(0, K, (B, 11, 11), generator=g)
-    l_lab = blk.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :S, :S].contiguous()
-    torch.manual_seed(0)
-    np.random.seed(0)
-    with torch.no_grad():
-        O.deeplab_forward(st.teacher, l_img[:1], "tv", False, K, 256)     # warm the allocator / oneDNN primitives
-    t0 = time.time()
-    O.train_step_mix(st, l_img, l_lab, u_img, lr=6.4e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97,
-                     num_queries=256, num_negatives=512)
-    dt = time.time() - t0
-    return {"value": round(2 * B / dt, 4), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 step of mix_label.train semantics at BASELINE configs[0] (321x321, B=2+2, fp32, tv-R101, Q=256, N=512), {dt:.1f} s"}
+def make_trainer_class(forced_valid):
+    from css_amd.train_step import MixTrainer
+    if not forced_valid:
+        return MixTrainer
+
+    class ForcedValidTrainer(MixTrainer):
+        """SURVEY 8(d) "forced-valid": the teacher still runs (no work is skipped), but the pseudo labels that reach the losses are
+        the synthetic block labels with confidence 1 and every valid pixel counts as hard - so the unlabeled half feeds the
+        unsupervised loss, all K classes have >= Q hard pixels and the contrastive pool is at its largest (mask_all = 1)."""
+        forced_labels = None
+
+        def _student_outputs(self, l_img, u_img):
+            pred_l, pred_u, (u_lab, u_lc), _, rep_all, small = super()._student_outputs(l_img, u_img)
+            lab = self.forced_labels
+            conf = torch.ones_like(u_lc)
+            return pred_l, pred_u, (lab, conf), (lab, conf), rep_all, small
+
+        def _hard_flags(self, rep_nhwc, cls, pred_small):
+            return (cls >= 0).to(torch.uint8)
+
+    return ForcedValidTrainer
 
 
-def pmc_traffic():
-    """HBM bytes per conv_igemm_dma256_kernel launch from the committed rocprofv3 PMC passes (profiles/*pmc_hbm_traffic.csv: separate
-    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction of the guide)."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_hbm_traffic.csv")))
-    if not files:
-        return None
-    rd = wr = n = 0.0
-    for r in csv.DictReader(open(files[-1])):
-        if "conv_igemm_dma256" in r["kernel"]:
-            k = float(r["launches"])
-            rd += float(r["read_MB_per_launch_corrected_x2"]) * k
-            wr += float(r["write_MB_per_launch"]) * k
-            n += k
-    return round((rd + wr) / n * 1e6) if n else None
-
-
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--size", type=int, default=513)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--mix", default="cutmix")
-    ap.add_argument("--aug", default="identity", choices=["identity", "pil"])
-    ap.add_argument("--workload", default="c2", choices=["c2", "c4", "c5"],
-                    help="c2: VOC-shaped 513^2 tv-R101 B=16 (default, the headline metric); c4: Cityscapes-shaped 769^2 deep-stem R101 "
-                         "K=19 OHEM B=8; c5: c4 with Q=1024, N=2048")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    a = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    # CSS_FORCE_COLLECTIVES=1 on one GPU: a 1-rank RCCL group with every data-parallel exchange switched on (ops.collectives_on) -
-    # measures what the ~450 collective calls of a step cost before any wire time (DESIGN.md section 6)
-    forced = world == 1 and os.environ.get("CSS_FORCE_COLLECTIVES") == "1"
-    if world > 1 or forced:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29581")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}"
-
-    from css_amd import _lib
+def build(workload, dev, rank, dtype="bf16", mix="cutmix", aug="identity", forced_valid=False, size=None, batch=None):
+    """-> (trainer, (l_img, l_lab, u_img), meta) for one rank: seeded non-degenerate weights (Kaiming convs from the
+    constructor, BN gamma ~ U(.25,.75), beta ~ N(0,.1)), synthetic crops of the workload's shape."""
     from css_amd.networks import resnet
     from css_amd.networks.ddp_model import Model_mix
-    from css_amd.train_step import MixTrainer
-
-    K, S, B = 21, a.size, a.batch
-    backbone, sup, Q, N = "tv", "ce", 256, 512
-    if a.workload in ("c4", "c5"):
-        K, S, B, backbone, sup = 19, 769, 8, "stem", "ohem"
-        if a.workload == "c5":
-            Q, N = 1024, 2048
+    K, S, B, backbone, sup, Q, N, cfg_idx = WORKLOADS[workload]
+    S, B = size or S, batch or B
     torch.manual_seed(3407)
-    # --aug pil: the reference's in-step PIL pipeline on the device (random rescale 0.5-1.5, pad, crop, colour jitter, blur, flip,
-    # 8-bit quantisation; css_amd/csrc/aug.hip) instead of the identity stand-in
-    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5) if a.aug == "pil" else (1.0, 1.0), "mix_mode": a.mix, "device_aug": a.aug}}
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5) if aug == "pil" else (1.0, 1.0), "mix_mode": mix, "device_aug": aug}}
     bb = resnet.resnet101_tv(zero_init_residual=False) if backbone == "tv" else resnet.resnet101(zero_init_residual=False)
     with contextlib.redirect_stdout(sys.stderr):     # the constructor prints like the reference's; stdout carries the ONE JSON line only
         model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
-    # seeded non-degenerate weights (SURVEY 8d): Kaiming convs (constructor), BN gamma~U(.5,1.5), beta~N(0,.1)
     g = torch.Generator().manual_seed(3407)
     with torch.no_grad():
         for mod in model.model.modules():
@@ -138,27 +140,46 @@ def main():
                 mod.weight.copy_(torch.rand(mod.weight.shape, generator=g) * 0.5 + 0.25)
                 mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
         model.ema_model.load_state_dict(model.model.state_dict())
-    model = model.to(dev).train().set_compute_dtype(torch.bfloat16 if a.dtype == "bf16" else torch.float32)
-    tr = MixTrainer(model, K, lr=6.4e-3, total_iter=80000, num_queries=Q, num_negatives=N, strong_threshold=0.8, weak_threshold=0.7,
-                    un_threshold=0.97, sup=sup, ohem_min_kept=50000 * B)
-    l_img, l_lab, u_img = synth_batch(B, S, K, 3407 + rank, dev)
+    model = model.to(dev).train().set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32)
+    tr = make_trainer_class(forced_valid)(model, K, lr=6.4e-3, total_iter=80000, num_queries=Q, num_negatives=N, strong_threshold=0.8,
+                                          weak_threshold=0.7, un_threshold=0.97, sup=sup, ohem_min_kept=50000 * B)
+    l_img, l_lab, u_img, u_blk = synth_batch(B, S, K, 3407 + rank, dev)
+    if forced_valid:
+        tr.forced_labels = u_blk
+    meta = dict(K=K, S=S, B=B, backbone=backbone, sup=sup, Q=Q, N=N, cfg_idx=cfg_idx,
+                fwd_flop=(FWD_FLOP_513_TV * (S / 513.0) ** 2 if backbone == "tv" else FWD_FLOP_769_STEM * (S / 769.0) ** 2))
+    return tr, (l_img, l_lab, u_img), meta
+
+
+def read_prof():
+    from css_amd import _lib
+    prof = {}
+    for kind, name in KINDS:
+        ms, n, w = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        _lib.lib().css_prof_read(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
+        prof[name] = (ms.value, n.value, w.value)
+    return prof
+
+
+def timed_run(tr, batch, steps, warmup, world, dev, profile=True):
+    """W untimed steps, then EXACTLY K timed steps bracketed by barrier + synchronize on both sides; MAX over ranks.
+    Per-kernel HIP-event bracketing (roofline leg; ~2.8 us per event pair on the launch stream) is on for the LAST timed step only."""
+    from css_amd import _lib
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
-        tr.step(l_img, l_lab, u_img)
-    # Per-kernel HIP-event bracketing (roofline leg) costs ~2.8 us per event pair on the stream, 2.6 ms per step over the
-    # ~920 conv kernel launches of a step: it is switched on for the LAST of the K timed steps only.
+    for _ in range(warmup):
+        tr.step(*batch)
     _lib.lib().css_prof_reset()
     sync()
     t0 = time.perf_counter()
-    for i in range(a.steps):
-        if i == a.steps - 1 and not os.environ.get("CSS_BENCH_NOPROF"):
+    for i in range(steps):
+        if i == steps - 1 and profile and not os.environ.get("CSS_BENCH_NOPROF"):
             _lib.lib().css_prof_enable(1)
-        out = tr.step(l_img, l_lab, u_img)
+        out = tr.step(*batch)
     sync()
     dt = time.perf_counter() - t0
     _lib.lib().css_prof_enable(0)
@@ -166,50 +187,203 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
-    import ctypes
-    prof = {}
-    KINDS = ((0, "conv_fwd_other"), (1, "conv_dgrad_other"), (2, "conv_wgrad_other"), (3, "contrast_gather"), (4, "similarity"),
-             (5, "igemm256_fwd"), (6, "igemm256_dgrad"), (7, "wgrad256"))
-    for kind, name in KINDS:
-        ms, n, w = ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
-        _lib.lib().css_prof_read(kind, ctypes.byref(ms), ctypes.byref(n), ctypes.byref(w))
-        prof[name] = (ms.value, n.value, w.value)
-    if rank == 0:
-        losses = {k: float(v) for k, v in out.items() if k != "pseudo"}
+    prof = read_prof()
+    _lib.lib().css_prof_reset()
+    return dt, out, prof
 
-        def tot(*names):
-            return tuple(sum(prof[n][i] for n in names) for i in range(3))
-        # dominant kernel: conv_igemm_dma256_kernel (forward + dgrad launches; one event pair per kernel launch)
-        ig_ms, ig_n, ig_fl = tot("igemm256_fwd", "igemm256_dgrad")
-        ach = ig_fl / (ig_ms * 1e-3) / 1e12 if ig_ms > 0 else 0.0
-        groups = {"conv_igemm_dma256_kernel": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_dma256_kernel": prof["wgrad256"],
-                  "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
-                  "conv_wgrad_all_kernels": tot("conv_wgrad_other", "wgrad256"), "contrast_gather": prof["contrast_gather"],
-                  "similarity": prof["similarity"]}
+
+def pmc_traffic(workload):
+    """HBM bytes per conv_igemm_dma256_kernel launch, REPLAYED from the committed rocprofv3 PMC passes of this workload (separate
+    FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -
+    PMC counters cannot be collected from inside the run that prints the line.  (None, None) when no pass exists for the workload."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_hbm_traffic_{workload}.csv")))
+    if not files and workload == "c2":
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.csv")))
+    if not files:
+        return None, None
+    rd = wr = n = 0.0
+    for r in csv.DictReader(open(files[-1])):
+        if "conv_igemm_dma256" in r["kernel"]:
+            k = float(r["launches"])
+            rd += float(r["read_MB_per_launch_corrected_x2"]) * k
+            wr += float(r["write_MB_per_launch"]) * k
+            n += k
+    if not n:
+        return None, None
+    return round((rd + wr) / n * 1e6), f"profiles/{os.path.basename(files[-1])} (replayed)"
+
+
+def rooflines(prof, dtype, workload):
+    def tot(*names):
+        return tuple(sum(prof[n][i] for n in names) for i in range(3))
+    peak = PEAK_BF16 if dtype == "bf16" else PEAK_F32
+    ig_ms, ig_n, ig_fl = tot("igemm256_fwd", "igemm256_dgrad")
+    ach = ig_fl / (ig_ms * 1e-3) if ig_ms > 0 else 0.0
+    traffic, src = pmc_traffic(workload)
+    roof = {"bound": "mfma", "kernel": "conv_igemm_dma256_kernel (forward + dgrad launches of the last timed step)",
+            "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+            "traffic": traffic, "traffic_source": src, "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
+            "alg_flops_per_launch": ig_fl / max(ig_n, 1)}
+    mfma_groups = {"conv_igemm_dma256_kernel": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_dma256_kernel": prof["wgrad256"],
+                   "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
+                   "conv_wgrad_all_kernels": tot("conv_wgrad_other", "wgrad256")}
+    hbm_groups = {k: prof[k] for k in ("bn_apply", "bn_bwd_apply", "bn_bwd_reduce", "sgd_ema", "conv1x1_short_k_fwd", "contrast_gather", "similarity")}
+    kernels = {}
+    for k, v in mfma_groups.items():
+        rate = v[2] / max(v[0] * 1e-3, 1e-12)
+        kernels[k] = {"bound": "mfma", "ms_per_step": round(v[0], 3), "launches_per_step": v[1], "achieved_TFLOPs": round(rate / 1e12, 2),
+                      "frac": round(rate / peak, 4)}
+    for k, v in hbm_groups.items():
+        rate = v[2] / max(v[0] * 1e-3, 1e-12)
+        kernels[k] = {"bound": "hbm", "ms_per_step": round(v[0], 3), "launches_per_step": v[1], "achieved_GBs": round(rate / 1e9, 1),
+                      "peak_GBs": PEAK_HBM / 1e9, "frac": round(rate / PEAK_HBM, 4)}
+    return roof, kernels
+
+
+def cpu_baseline(budget_s=150.0):
+    """The oracle (CPU restatement of the reference path, kind 'port') on BASELINE configs[0] (321x321, B=2+2, fp32, tv-R101,
+    Q=256, N=512, the GPU step's thresholds), protocol of BASELINE.md section 4: 1 warm-up step + 3 timed steps at N = all host
+    threads, then N = 8 for comparison with the build container - bounded: once ``budget_s`` of wall time is spent no further step
+    is started (at least one timed step always runs; the sample string says what was done)."""
+    import numpy as np
+    from oracle import css_oracle as O
+    K, S, B = 21, 321, 2
+    g = torch.Generator().manual_seed(3407)
+    l_img, u_img = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
+    blk = torch.randint(0, K, (B, 11, 11), generator=g)
+    l_lab = blk.repeat_interleave(32, 1).repeat_interleave(32, 2)[:, :S, :S].contiguous()
+    args = dict(lr=6.4e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.7, un_threshold=0.97, num_queries=256, num_negatives=512)
+    t_start = time.time()
+    n_all = torch.get_num_threads()
+
+    def run(threads, max_timed):
+        torch.set_num_threads(threads)
+        st = O.MixState("tv", K, 256, 3407)
+        torch.manual_seed(0)
+        np.random.seed(0)
+        O.train_step_mix(st, l_img, l_lab, u_img, **args)                 # warm-up step (allocator, oneDNN primitives)
+        ts = []
+        while len(ts) < max_timed and (not ts or time.time() - t_start + ts[-1] < budget_s):
+            t0 = time.time()
+            O.train_step_mix(st, l_img, l_lab, u_img, **args)
+            ts.append(time.time() - t0)
+        return ts
+
+    ts = run(n_all, 3)
+    res = {"value": round(2 * B * len(ts) / sum(ts), 4), "unit": "images/s", "cores": n_all, "kind": "port",
+           "sample": f"1 warm-up + {len(ts)} timed steps of mix_label.train semantics at BASELINE configs[0] (321x321, B=2+2, fp32, tv-R101, "
+                     f"Q=256, N=512, weak_threshold=0.7), {sum(ts) / len(ts):.1f} s per step"}
+    if n_all > 8 and time.time() - t_start + 2.5 * ts[-1] < budget_s:
+        t8 = run(8, 1)
+        res["at_8_threads"] = {"value": round(2 * B * len(t8) / sum(t8), 4), "cores": 8, "sample": f"1 warm-up + {len(t8)} timed step"}
+    else:
+        res["at_8_threads"] = None if n_all > 8 else "same run (the host has 8 threads or fewer)"
+    torch.set_num_threads(n_all)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=None, help="crops per GPU of each kind (default: the workload's)")
+    ap.add_argument("--size", type=int, default=None, help="crop size (default: the workload's)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--mix", default="cutmix")
+    ap.add_argument("--aug", default="identity", choices=["identity", "pil"])
+    ap.add_argument("--workload", default="c2", choices=list(WORKLOADS),
+                    help="c2: VOC-shaped 513^2 tv-R101 B=16 (default, the headline metric); c4: Cityscapes-shaped 769^2 deep-stem R101 "
+                         "K=19 OHEM B=8; c5: c4 with Q=1024, N=2048, forced-valid")
+    ap.add_argument("--forced-valid", action="store_true", help="SURVEY 8(d) forced-valid variant (always on for c5)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.c4 / extra.c2_forced_valid legs")
+    ap.add_argument("--cpu-budget", type=float, default=150.0)
+    a = ap.parse_args()
+
+    # ---- launch decision: BEFORE anything touches the GPU ----
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_children(a.gpus, sys.argv[1:]))
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # launcher self-test (tests/test_host_cpu.py): rendezvous + one collective over gloo on CPU, no GPU, no model
+    if os.environ.get("CSS_BENCH_LAUNCH_TEST"):
+        if os.environ["CSS_BENCH_LAUNCH_TEST"] == f"fail{rank}":
+            sys.exit(3)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launch_test": True, "n_gpus": world, "sum": float(t)}))
+        dist.destroy_process_group()
+        return
+    # CSS_BENCH_SHARE_GPU=1: every rank on cuda:0 with gloo collectives - the N > 1 code path on a one-GPU box (tests only)
+    share = os.environ.get("CSS_BENCH_SHARE_GPU") == "1"
+    if share:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    # CSS_FORCE_COLLECTIVES=1 on one GPU: a 1-rank RCCL group with every data-parallel exchange switched on (ops.collectives_on) -
+    # measures what the collective calls of a step cost before any wire time (DESIGN.md section 6)
+    forced = world == 1 and os.environ.get("CSS_FORCE_COLLECTIVES") == "1"
+    if world > 1 or forced:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29581")
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    def run_leg(workload, steps, warmup, forced_valid, profile=True, size=None, batch=None):
+        tr, batch_t, meta = build(workload, dev, rank, a.dtype, a.mix, a.aug, forced_valid, size, batch)
+        dt, out, prof = timed_run(tr, batch_t, steps, warmup, world, dev, profile)
+        roof, kernels = rooflines(prof, a.dtype, workload)
+        losses = {k: round(float(v), 4) for k, v in out.items() if k != "pseudo"}
+        del tr, batch_t
+        torch.cuda.empty_cache()
+        return dt, losses, roof, kernels, meta
+
+    fv = a.forced_valid or a.workload == "c5"
+    dt, losses, roof, kernels, meta = run_leg(a.workload, a.steps, a.warmup, fv, True, a.size, a.batch)
+    S, B, K = meta["S"], meta["B"], meta["K"]
+    if rank == 0:
+        shape = "VOC-shaped" if meta["backbone"] == "tv" else "Cityscapes-shaped"
+        net = "tv-ResNet-101" if meta["backbone"] == "tv" else "deep-stem ResNet-101"
         res = {
-            "metric": "training images/sec at 513x513 R101-DeepLabv3+ (mix_label step, labeled+unlabeled crops consumed)",
+            "metric": f"training images/sec at {S}x{S} R101-DeepLabv3+ (mix_label step, labeled+unlabeled crops consumed)",
             "value": round(2 * B * world * a.steps / dt, 3), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
-            "config": {"workload": (f"BASELINE configs[1]: VOC-shaped mix_label step, tv-ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, "
-                                    f"K={K}, Q={Q}, N={N}, mix_mode={a.mix}" + (", device_aug=pil" if a.aug == "pil" else "")) if a.workload == "c2" else
-                                   (f"BASELINE configs[{3 if a.workload == 'c4' else 4}] shape on {world} GPU(s): Cityscapes-shaped mix_label step, deep-stem "
-                                    f"ResNet-101 DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, OHEM, Q={Q}, N={N}, mix_mode={a.mix}"),
+            "config": {"workload": (f"BASELINE configs[{meta['cfg_idx']}]{' shape' if a.workload != 'c2' else ''}: {shape} mix_label step, {net} "
+                                    f"DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, sup={meta['sup']}, Q={meta['Q']}, N={meta['N']}, "
+                                    f"mix_mode={a.mix}, device_aug={a.aug}" + (", forced-valid pseudo labels" if fv else "")),
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_dma256_kernel (forward + dgrad launches of the last timed step)",
-                         "achieved": round(ach, 2), "peak": PEAK_BF16 / 1e12 if a.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                         "frac": round(ach * 1e12 / (PEAK_BF16 if a.dtype == "bf16" else 157.3e12), 4),
-                         "traffic": pmc_traffic(), "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
-                         "alg_flops_per_launch": ig_fl / max(ig_n, 1)},
-            "kernels": {k: {"ms_per_step": round(v[0], 3), "launches_per_step": v[1],
-                            "alg_tflops_or_GBs": round(v[2] / max(v[0] * 1e-3, 1e-12) / (1e12 if k.startswith("conv") else 1e9), 2)}
-                        for k, v in groups.items()},
-            "step_alg_tflops": round(8 * B * (FWD_FLOP_513_TV * (S / 513.0) ** 2 if backbone == "tv" else 1239.1e9 * (S / 769.0) ** 2)
-                                     / (dt / a.steps) / 1e12, 2),
-            "losses": {k: round(v, 4) for k, v in losses.items()},
+            "roofline": roof, "kernels": kernels,
+            "step_alg_tflops": round(8 * B * meta["fwd_flop"] / (dt / a.steps) / 1e12, 2),
+            "losses": losses,
         }
+    if world == 1 and not a.no_extra and a.workload == "c2" and a.size is None and a.batch is None:
+        extra = {}
+        d4, l4, r4, k4, m4 = run_leg("c4", 3, 2, False)
+        extra["c4"] = {"workload": "BASELINE configs[3] shape on one GPU: Cityscapes-shaped, deep-stem ResNet-101, 769x769, B=8+8, K=19, OHEM",
+                       "value": round(2 * m4["B"] * 3 / d4, 3), "unit": "images/s", "ms_per_step": round(d4 / 3 * 1e3, 3), "steps": 3, "warmup": 2,
+                       "roofline": {k: r4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us")},
+                       "step_alg_tflops": round(8 * m4["B"] * m4["fwd_flop"] / (d4 / 3) / 1e12, 2), "losses": l4}
+        d2, l2, r2, k2, m2 = run_leg("c2", 2, 2, True, profile=False)
+        extra["c2_forced_valid"] = {"what": "c2 with SURVEY 8(d) forced-valid pseudo labels (unlabeled half feeds the unsupervised loss and the "
+                                            "contrastive pool: losses.unsup != 0)",
+                                    "value": round(2 * m2["B"] * 2 / d2, 3), "unit": "images/s", "ms_per_step": round(d2 / 2 * 1e3, 3), "steps": 2,
+                                    "warmup": 2, "losses": l2}
+        res["extra"] = extra
+    if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(a.cpu_budget)
         print(json.dumps(res))
     if world > 1 or forced:
         dist.destroy_process_group()

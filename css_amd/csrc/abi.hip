@@ -27,8 +27,8 @@ int cu_count(int device) {
 }
 
 // ---- profiling ----
-struct ProfRec { hipEvent_t a, b; int kind; double work; };
-constexpr int PROF_KINDS = 8;
+struct ProfRec { hipEvent_t a, b; int kind; double work; bool alias; };   // alias: second record over the same event pair (not pooled)
+constexpr int PROF_KINDS = 13;
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;       // recorded this epoch
@@ -47,13 +47,21 @@ struct ProfScope {
     else if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) { on = false; return; }
     r.kind = kind;
     r.work = work;
+    r.alias = false;
     (void)hipEventRecord(r.a, st);
   }
+  int alias_kind = -1;      // also file this launch under a second kind (HBM view of a kernel that is listed under an MFMA kind)
+  double alias_work = 0;
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(r.b, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
+    if (alias_kind >= 0) {
+      ProfRec q = r;
+      q.kind = alias_kind; q.work = alias_work; q.alias = true;
+      g_prof.push_back(q);
+    }
   }
 };
 // one ProfScope per KERNEL launch of a convolution call: the 256x256 LDS-DMA kernels get their own kinds (5/6/7)
@@ -63,10 +71,20 @@ struct ConvProf : LaunchProf {
   hipStream_t st;
   alignas(ProfScope) unsigned char buf[sizeof(ProfScope)];
   ProfScope* cur = nullptr;
+  double hbm_bytes = 0;     // > 0: an HBM-bound shape class (short-K 1x1 forward): its launches are also filed under kind 12 with their bytes
   ConvProf(int ko, int kb, double f, hipStream_t s) : kind_other(ko), kind_big(kb), flops(f), st(s) {}
-  void begin(bool big, double share) override { cur = new (buf) ProfScope(big ? kind_big : kind_other, flops * share, st); }
+  void begin(bool big, double share) override {
+    cur = new (buf) ProfScope(big ? kind_big : kind_other, flops * share, st);
+    if (hbm_bytes > 0) { cur->alias_kind = 12; cur->alias_work = hbm_bytes * share; }
+  }
   void end() override { if (cur) { cur->~ProfScope(); cur = nullptr; } }
 };
+// the write-bound 1x1 class (resnet.py:131-133, conv3 of a Bottleneck: K = planes <= 512 in, 4 x planes out): algorithmic bytes of one call
+double short_k_bytes(const ConvArgs& a, int dtype) {
+  if (a.R != 1 || a.S != 1 || a.Ktot > 512 || a.Cd < 4 * a.Ktot) return 0;
+  const double e = dtype == CSS_BF16 ? 2 : 4;
+  return ((double)a.M * a.Ktot + (double)a.M * a.Cd + (double)a.Cd * a.Ktot) * e;
+}
 }  // namespace
 
 extern "C" {
@@ -77,7 +95,7 @@ int css_device_cu_count(int device) { return cu_count(device); }
 int css_prof_enable(int on) { g_prof_on = on != 0; return 0; }
 int css_prof_reset(void) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  for (auto& r : g_prof) g_prof_pool.push_back(r);
+  for (auto& r : g_prof) if (!r.alias) g_prof_pool.push_back(r);
   g_prof.clear();
   return 0;
 }
@@ -108,6 +126,7 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
   ConvProf cp(0, 5, alg_flops, S(stream));
+  cp.hbm_bytes = short_k_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
@@ -123,6 +142,7 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   a.stats = stats; a.stat_Mg = Mg;
   if (!stats || Mg < 128 || a.M % Mg) return CSS_ERR_ARG;
   ConvProf cp(0, 5, alg_flops, S(stream));
+  cp.hbm_bytes = short_k_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
@@ -163,6 +183,11 @@ int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int
   ConvProf cp(2, 7, alg_flops, S(stream));
   return css_launch_wgrad(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
+int css_wgrad_splits(int M, int Ktot, int Cout, int dtype, int n_cu) {
+  int splits = 0, mps = 0;
+  css_wgrad_plan_(M, Ktot, Cout, dtype, n_cu > 0 ? n_cu : 256, &splits, &mps);
+  return splits;
+}
 int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_weight_layout(w, out, Cout, taps, Cin, CinPad, dgrad, dtype, S(stream));
@@ -180,10 +205,10 @@ int css_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, i
   set_dev(device);
   return css_launch_bn_stats(y, Mg, G, C, ld, partial, dtype, S(stream));
 }
-int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
-                  css_stream_t stream) {
+int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate, double count_local,
+                  int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_reduce(partial, nrb, C, G, sums, dgamma, dbeta, accumulate, S(stream));
+  return css_launch_bn_reduce(partial, nrb, C, G, sums, dgamma, dbeta, accumulate, count_local, S(stream));
 }
 int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta, float* running_mean,
                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
@@ -199,10 +224,11 @@ int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, dou
   return css_launch_bn_reduce_slabs(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                                     sums_out, C, S(stream));
 }
-int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean, float* running_var,
-                    float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device, css_stream_t stream) {
+int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device,
+                    css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_finalize(sums, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
+  return css_launch_bn_finalize(sums, G, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
 }
 int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                       float* shift, int C, int device, css_stream_t stream) {
@@ -212,19 +238,22 @@ int css_bn_eval_coeff(const float* gamma, const float* beta, const float* runnin
 int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C, int relu,
                  int Mg, int dtype, int device, css_stream_t stream) {
   set_dev(device);
+  ProfScope ps(8, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (res ? 1 : 0)), S(stream));
   return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, dtype, S(stream));
 }
 int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, int device,
                       css_stream_t stream) {
   set_dev(device);
+  ProfScope ps(10, (double)Mg * G * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (a ? 1 : 0)), S(stream));
   return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, dtype, S(stream));
 }
 int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                      const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
-                     double count, int M, int C, int relu, int Mg, int dtype, int device, css_stream_t stream) {
+                     double count, const double* count_dev, int M, int C, int relu, int Mg, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg,
+  ProfScope ps(9, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (3 + (a ? 1 : 0) + (dres ? 1 : 0)), S(stream));
+  return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg,
                                  dtype, S(stream));
 }
 
@@ -271,6 +300,7 @@ int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int 
 int css_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
                 float grad_scale, int device, css_stream_t stream) {
   set_dev(device);
+  ProfScope ps(11, (double)n * 28.0, S(stream));     // p, g, momentum, ema read + p, momentum, ema written: 7 x 4 bytes per element
   return css_launch_sgd_ema(p, g, buf, ema, n, lr, momentum, wd, first, decay, grad_scale, S(stream));
 }
 int css_ema(float* ema, const float* p, long n, float decay, int device, css_stream_t stream) {
@@ -288,6 +318,11 @@ int css_similarity(const void* rep, int ld, const void* proto_n, float* sim, flo
   set_dev(device);
   ProfScope ps(4, (double)P * C * (dtype == CSS_BF16 ? 2 : 4), S(stream));
   return css_launch_similarity(rep, ld, proto_n, sim, prob, cls, hard, P, K, C, temp, strong_thr, dtype, cu_count(device), S(stream));
+}
+int css_softmax_hard_flags(const void* pred, int ld, const int* cls, int P, int K, float strong_thr, uint8_t* hard, int dtype, int device,
+                           css_stream_t stream) {
+  set_dev(device);
+  return css_launch_softmax_hard(pred, ld, cls, P, K, strong_thr, hard, dtype, S(stream));
 }
 int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
                      int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, int device, css_stream_t stream) {

@@ -148,8 +148,10 @@ __device__ __forceinline__ void bn_finalize_one(double a0, double a1, double cou
 }
 // grid = ceil(C/8), block 1024.  partial is [G][nrb][2][C] (fp64); sums is [G][2][C].
 __global__ __launch_bounds__(1024) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, int G, double* __restrict__ sums,
-                                                         float* __restrict__ g1, float* __restrict__ g0, int accumulate) {
+                                                         float* __restrict__ g1, float* __restrict__ g0, int accumulate, double count_local) {
   double t0 = 0, t1 = 0;
+  // SyncBN with per-rank pixel counts: the local count of every group rides behind the sums and is all-reduced with them
+  if (sums && count_local > 0 && blockIdx.x == 0 && threadIdx.x < G) sums[(size_t)G * 2 * C + threadIdx.x] = count_local;
   stage2_reduce(
       partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
       [&](int g, double a0, double a1, int c) {
@@ -184,6 +186,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
                                                                float* running_mean, float* running_var, float momentum, float eps,
                                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                                                                double* sums_out, int C) {
+  if (sums_out && blockIdx.x == 0 && threadIdx.x < G) sums_out[(size_t)G * 2 * C + threadIdx.x] = (double)Mg;   // local count, see bn_reduce_kernel
   stage2_reduce(
       partial, C, G,
       [&](int g, int& lo, int& hi, int& extra) {
@@ -221,14 +224,14 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, 
   channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
 }
 
-__global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, double count,
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, double count, const double* __restrict__ count_dev,
                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float* running_mean, float* running_var, float momentum, float eps,
                                    float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
   int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   for (int g = 0; g < G; ++g)
-    bn_finalize_one(sums[(size_t)g * 2 * C + c], sums[(size_t)g * 2 * C + C + c], count, gamma[c], beta[c], running_mean, running_var, momentum, eps,
+    bn_finalize_one(sums[(size_t)g * 2 * C + c], sums[(size_t)g * 2 * C + C + c], count_dev ? count_dev[g] : count, gamma[c], beta[c], running_mean, running_var, momentum, eps,
                     mean_out + g * C, invstd_out + g * C, scale_out + g * C, shift_out + g * C, c);
 }
 
@@ -338,8 +341,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            T* __restrict__ dres, int lddr, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, const float* __restrict__ scale,
-                                                           const float* __restrict__ shift, double count, int Mg, int C, int relu,
-                                                           int rows_per_block) {
+                                                           const float* __restrict__ shift, double count, const double* __restrict__ count_dev,
+                                                           int Mg, int C, int relu, int rows_per_block) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
@@ -347,7 +350,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   const int cv = blockIdx.y * TPC + cvi;
   if (rg >= RPB || cv >= CV) return;
   const int c = cv * VEC, g = blockIdx.z;
-  const float inv_n = (float)(1.0 / count);
+  const float inv_n = (float)(1.0 / (count_dev ? count_dev[g] : count));
   float mu[VEC], is[VEC], gi[VEC], m1[VEC], m2[VEC], sc[VEC], sh[VEC];
 #pragma unroll
   for (int e = 0; e < VEC; ++e) {
@@ -432,8 +435,9 @@ int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* par
   return dtype == CSS_BF16 ? bn_stats_T<bf16_t>(y, Mg, G, C, ld, partial, st)
          : dtype == CSS_F32 ? bn_stats_T<float>(y, Mg, G, C, ld, partial, st) : CSS_ERR_DTYPE;
 }
-int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, hipStream_t st) {
-  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, nrb, C, G, sums, g1, g0, accumulate);
+int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, double count_local,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(bn_reduce_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, nrb, C, G, sums, g1, g0, accumulate, count_local);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
@@ -454,10 +458,10 @@ int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, doubl
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
-                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
-                           hipStream_t st) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sums, G, count, gamma, beta, running_mean, running_var,
+int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                           float* shift, int C, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, st, sums, G, count, count_dev, gamma, beta, running_mean, running_var,
                      momentum, eps, mean, invstd, scale, shift, C);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
@@ -534,7 +538,8 @@ int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, c
 template <typename T>
 static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                           void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                          const float* scale, const float* shift, double count, int M, int C, int relu, int Mg, hipStream_t st) {
+                          const float* scale, const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg,
+                          hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && a && lda % VEC) || (dres && lddr % VEC) ||
       (relu && !a && (!scale || !shift)))
@@ -546,18 +551,19 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
   const int rpb = pick_rows_ew(Mg, G, C, VEC, 16, bwd_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy,
-                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, Mg, C, relu, rpb);
+                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, relu, rpb);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                             void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
-                            const float* scale, const float* shift, double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
+                            const float* scale, const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg,
+                            int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
   if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
   return dtype == CSS_BF16
-             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, st)
          : dtype == CSS_F32
-             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, st)
              : CSS_ERR_DTYPE;
 }

@@ -1417,6 +1417,31 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
   return CSS_OK;
 }
 
+// Pixel splits of the weight gradient: a multiple of 8 (one slice per XCD at a time, see the kernels) chosen so that the tiles
+// an XCD owns (tiles per slice x slices per XCD) fill its 32 CUs x resident workgroups in whole rounds, with >= 4 iterations each.
+void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out) {
+  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
+  const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
+  const int bn = dtype == CSS_BF16 ? (big ? 256 : 128) : 64, bkc = bn, bp = dtype == CSS_BF16 ? (big ? 32 : 64) : 16;
+  const int tiles = cdiv(Ktot, bkc) * cdiv(Cd, bn);
+  const int slots = (n_cu / 8) * (big ? 1 : 2);
+  int best_k = 1;
+  double best_eff = 0;
+  for (int k = 1; k <= 64; ++k) {
+    const int mps_k = cdiv(cdiv(M, 8 * k), bp) * bp;
+    if (k > 1 && mps_k < 4 * bp) break;
+    const int txcd = tiles * k;
+    const double eff = (double)txcd / ((double)cdiv(txcd, slots) * slots);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = k; }
+    if (eff >= 0.93) break;
+  }
+  int splits = 8 * best_k;
+  const int mps = cdiv(cdiv(M, splits), bp) * bp;
+  splits = cdiv(M, mps);
+  *splits_out = splits;
+  *mps_out = mps;
+}
+
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   if (a.M <= 0) return CSS_OK;
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
@@ -1441,23 +1466,8 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
     a.x_bytes = (unsigned)xb;
     a.dy_bytes = (unsigned)yb;
   }
-  // Pixel splits: a multiple of 8 (one slice per XCD at a time, see the kernel) chosen so that the tiles an XCD owns
-  // (tiles per slice x slices per XCD) fill its 32 CUs x 2 resident workgroups in whole rounds, with >= 4 iterations each.
-  const int tiles = cdiv(a.Ktot, bkc) * cdiv(a.Cd, bn);
-  const int slots = (n_cu / 8) * (big ? 1 : 2);
-  int best_k = 1;
-  double best_eff = 0;
-  for (int k = 1; k <= 64; ++k) {
-    const int mps_k = cdiv(cdiv(a.M, 8 * k), bp) * bp;
-    if (k > 1 && mps_k < 4 * bp) break;
-    const int txcd = tiles * k;
-    const double eff = (double)txcd / ((double)cdiv(txcd, slots) * slots);
-    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = k; }
-    if (eff >= 0.93) break;
-  }
-  int splits = 8 * best_k;
-  int mps = cdiv(cdiv(a.M, splits), bp) * bp;
-  splits = cdiv(a.M, mps);
+  int splits, mps;
+  css_wgrad_plan_(a.M, a.Ktot, a.Cd, dtype, n_cu, &splits, &mps);
   a.m_per_split = mps;
   a.splits = splits;
   a.tiles_k = cdiv(a.Ktot, bkc);

@@ -44,19 +44,21 @@ struct LaunchProf {
 };
 int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
+void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
 
 int css_bn_nrb_(int Mg, int G, int C, int dtype);
 int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st);
-int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, hipStream_t st);
+int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, double count_local,
+                         hipStream_t st);
 int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                   float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                   float* shift, int C, hipStream_t st);
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                float* shift, double* sums_out, int C, hipStream_t st);
-int css_launch_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
-                           float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
-                           hipStream_t st);
+int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
+                           float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                           float* shift, int C, hipStream_t st);
 int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int C,
                              hipStream_t st);
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
@@ -65,7 +67,7 @@ int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, c
                              const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st);
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                             const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
-                            double count, int M, int C, int relu, int Mg, int dtype, hipStream_t st);
+                            double count, const double* count_dev, int M, int C, int relu, int Mg, int dtype, hipStream_t st);
 
 int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
                            int dtype, hipStream_t st);
@@ -103,6 +105,7 @@ int css_launch_confusion_bincount(const int64_t* pred, const int64_t* label, lon
 int css_launch_proto_normalize(const float* proto, void* out, int K, int C, int dtype, hipStream_t st);
 int css_launch_similarity(const void* rep, int ld, const void* pn, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
                           float temp, float strong_thr, int dtype, int n_cu, hipStream_t st);
+int css_launch_softmax_hard(const void* pred, int ld, const int* cls, int P, int K, float strong_thr, uint8_t* hard, int dtype, hipStream_t st);
 int css_launch_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
                             int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, hipStream_t st);
 int css_launch_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_logits, float weak_thr, int B, int H, int W, int h, int w,

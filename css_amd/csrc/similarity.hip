@@ -208,7 +208,36 @@ __global__ __launch_bounds__(256) void class_map_kernel(const int64_t* __restric
   }
 }
 
+// ---- hard flags from the student's own class logits (ori_pseudo.py:178-180: prob_all = softmax(pred_all), loss.py:90-91) -----
+// hard[p] = cls[p] >= 0 && softmax(pred[p])[cls[p]] < strong_thr; pred: low-resolution logits [P][ld], one pixel per lane
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_hard_kernel(const T* __restrict__ pred, int ld, const int* __restrict__ cls, int P, int K,
+                                                           float strong_thr, uint8_t* __restrict__ hard) {
+  for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    const int c = cls[p];
+    const T* row = pred + (size_t)p * ld;
+    float m = -INFINITY;
+    for (int k = 0; k < K; ++k) m = fmaxf(m, (float)row[k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf((float)row[k] - m);
+    const float own = c >= 0 ? expf((float)row[c] - m) / s : 1.f;
+    hard[p] = (c >= 0 && own < strong_thr) ? 1 : 0;
+  }
+}
+
 // ---- launchers -----------------------------------------------------------
+int css_launch_softmax_hard(const void* pred, int ld, const int* cls, int P, int K, float strong_thr, uint8_t* hard, int dtype, hipStream_t st) {
+  if (P <= 0) return CSS_OK;
+  if (K <= 0 || ld < K) return CSS_ERR_ARG;
+  int grid = (P + 255) / 256;
+  if (grid > 8192) grid = 8192;
+  if (dtype == CSS_BF16) hipLaunchKernelGGL(softmax_hard_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)pred, ld, cls, P, K, strong_thr, hard);
+  else if (dtype == CSS_F32) hipLaunchKernelGGL(softmax_hard_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)pred, ld, cls, P, K, strong_thr, hard);
+  else return CSS_ERR_DTYPE;
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+
 int css_launch_proto_normalize(const float* proto, void* out, int K, int C, int dtype, hipStream_t st) {
   if (K > 32) return CSS_ERR_ARG;
   if (dtype == CSS_BF16) hipLaunchKernelGGL(proto_normalize_kernel<bf16_t>, dim3(32), dim3(64), 0, st, proto, (bf16_t*)out, K, C);

@@ -2,10 +2,11 @@
 (``batch_transform_2/3`` + ``generate_cut_gather_2/3``, generalframeworks/dataset_helpers/VOC.py:325-352,393-477).
 
 The reference round-trips every unlabeled image GPU -> CPU -> PIL -> GPU in the middle of ``Model_*.forward`` (SURVEY.md
-section 8f-1).  Two modes, chosen by ``config['Dataset']['device_aug']`` (``aug_mode``):
-  * ``"identity"`` (default, what the golden step traces were captured with): geometry and colours untouched; only the label
-    convention 255 ("disagree") -> -1, int64 (VOC.py:184-185);
-  * ``"pil"``: the reference's whole PIL pipeline restated on 8-bit planes by HIP kernels (csrc/aug.hip), BIT-EXACT to PIL on
+section 8f-1).  Two modes, chosen by ``config['Dataset']['device_aug']`` (``aug_mode``); the step wrappers use ``"pil"`` when the key
+is absent (the reference's YAML files do not have it, and the drop-in path must augment like the reference does):
+  * ``"identity"`` (what the golden step traces were captured with; benchmarks and parity tests ask for it explicitly): geometry
+    and colours untouched; only the label convention 255 ("disagree") -> -1, int64 (VOC.py:184-185);
+  * ``"pil"`` (the default of ``Model_*``): the reference's whole PIL pipeline restated on 8-bit planes by HIP kernels (csrc/aug.hip), BIT-EXACT to PIL on
     identical random draws (tests/test_aug_gpu.py vs oracle/aug_oracle.py): tensor_to_pil_2's denormalise + 8-bit quantisation
     of the image and both confidence maps, random rescale (PIL BILINEAR two-pass fixed point / NEAREST), pad (reflect / 255 / 0),
     random crop, ColorJitter (PIL blends + 8-bit HSV hue shift, random order), GaussianBlur (PIL's three box passes per axis),
@@ -31,8 +32,9 @@ _MODE = "identity"
 
 class aug_mode:
     """``with aug_mode("pil")``: batch_transform* run the reference's PIL pipeline on the device (csrc/aug.hip, bit-exact to PIL:
-    random rescale, pad, crop, 8-bit quantisation, colour jitter, blur, flip); ``"identity"`` (default): geometry and colours
-    untouched, label convention only.  Model_* pick the mode from ``config['Dataset'].get('device_aug', 'identity')``."""
+    random rescale, pad, crop, 8-bit quantisation, colour jitter, blur, flip); ``"identity"``: geometry and colours
+    untouched, label convention only (also the state outside any ``aug_mode`` context, for direct callers of batch_transform*).
+    Model_* pick the mode from ``config['Dataset'].get('device_aug', 'pil')`` (ddp_model._StudentTeacher._device_aug)."""
 
     def __init__(self, mode):
         if mode not in ("identity", "pil"):

@@ -63,6 +63,13 @@ class _StudentTeacher(nn.Module):
         self.config = config
         self._flat = None
 
+    def _device_aug(self):
+        """In-step augmentation mode.  The reference's YAML files have no such key: with the key ABSENT the drop-in path must train
+        like the reference does, i.e. with its whole PIL pipeline (random rescale, crop, colour jitter, blur, flip, 8-bit
+        quantisation of the confidence maps: VOC.py:325-352) - the device restatement 'pil'.  'identity' (geometry and colours
+        untouched) is for parity traces and benchmarks, which ask for it explicitly."""
+        return self.config["Dataset"].get("device_aug", "pil")
+
     def set_compute_dtype(self, dtype):
         self.model.set_compute_dtype(dtype)
         self.ema_model.set_compute_dtype(dtype)
@@ -99,7 +106,16 @@ class _StudentTeacher(nn.Module):
     # The reference calls each network twice per step (labeled batch, unlabeled batch: ddp_model.py:102-103,140-143).  Here
     # both batches go through the network in ONE pass, concatenated along dim 0, with two batch-norm statistics groups
     # (css_amd.ops.bn_groups): identical arithmetic, half the kernel launches, twice the rows per launch.
+    @staticmethod
+    def _check_pair(xl, xu):
+        # the two passes are batched as ONE tensor with two statistics groups split at half its rows: that is the reference's two
+        # separate calls only when both batches have the same shape
+        if xl.shape != xu.shape:
+            raise ValueError(f"labeled and unlabeled batches must have the same shape (got {tuple(xl.shape)} and {tuple(xu.shape)}): "
+                             "the batched two-group pass splits the rows at the half")
+
     def _teacher_pair(self, xl, xu):
+        self._check_pair(xl, xu)
         with ops.bn_groups(2):
             pred, rep = self.ema_model.forward_nhwc(ops.stage_inputs([xl, xu], self.ema_model.compute_dtype))
         b = xl.shape[0]
@@ -112,6 +128,7 @@ class _StudentTeacher(nn.Module):
         """-> pred [2B,h,w,K], rep_all [2B,h,w,C] (labeled first), pred_l_large, pred_u_large (logical NCHW, fp32).
         ``small=True`` (fused trainer): the last two are the two halves of the LOW-resolution NHWC logits instead - the losses then
         up-sample on the fly (loss._PixelCESmall) and the full-resolution logits are never materialised."""
+        self._check_pair(xl, xu)
         with ops.bn_groups(2):
             pred, rep = self.model.forward_nhwc(ops.stage_inputs([xl, xu], self.model.compute_dtype))
         if small:
@@ -130,7 +147,7 @@ class Model_mix(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
-        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
+        with torch.no_grad(), aug_mode(self._device_aug()):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, pseudo = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
@@ -157,7 +174,7 @@ class Model_cross(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
-        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
+        with torch.no_grad(), aug_mode(self._device_aug()):
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, _ = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
@@ -183,7 +200,7 @@ class Model_ori_pseudo(_StudentTeacher):
 
     def forward(self, train_l_image, train_u_image, _small_logits=False):
         hw = train_u_image.shape[2:]
-        with torch.no_grad(), aug_mode(self.config["Dataset"].get("device_aug", "identity")):
+        with torch.no_grad(), aug_mode(self._device_aug()):
             pred_u, _ = self._teacher(train_u_image)
             raw = None if _small_logits else ops.bilinear(pred_u, hw[0], hw[1], torch.float32)   # (7th output: unused by the train body)
             # softmax + max in class space only: the pseudo-label kernel with a constant similarity map

@@ -137,6 +137,24 @@ class direct_param_grads:
         _direct_grads = self.prev
 
 
+# Called with a parameter right after the kernels that ADD its gradient into the flat buffer were enqueued (direct mode only):
+# lets the trainer start the all-reduce of a gradient bucket while the rest of backward is still running (train_step.py)
+_grad_ready_cb = None
+
+
+def set_grad_ready_callback(cb):
+    global _grad_ready_cb
+    prev, _grad_ready_cb = _grad_ready_cb, cb
+    return prev
+
+
+def _grad_ready(*params):
+    if _grad_ready_cb is not None:
+        for p in params:
+            if p is not None:
+                _grad_ready_cb(p)
+
+
 def _grad_sink(param, phys_shape):
     """param.grad as a contiguous fp32 buffer in the kernel's physical layout, or None if it cannot be used in place."""
     g = getattr(param, "grad", None)
@@ -224,6 +242,7 @@ class _Conv2d(torch.autograd.Function):
             if sink is not None:      # the wgrad kernel accumulates atomically: add straight into param.grad
                 call("css_conv2d_wgrad", x, dyp, sink, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
                      dc, dev, st)
+                _grad_ready(weight)
             else:
                 dwp = torch.zeros((cout_pad, r, s, cp), dtype=torch.float32, device=dy.device)
                 call("css_conv2d_wgrad", x, dyp, dwp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil,
@@ -234,6 +253,7 @@ class _Conv2d(torch.autograd.Function):
             sink = _grad_sink(bias_p, (cout,)) if bias_p is not None else None
             if sink is not None:
                 call("css_colsum", dy, cout, n * ho * wo, cout, sink, dc, dev, st)
+                _grad_ready(bias_p)
             else:
                 db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
                 call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
@@ -303,16 +323,17 @@ class _BNAct(torch.autograd.Function):
         scale, shift = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
         mean = invstd = None
         count = float(mg)
+        count_t = None       # SyncBN: per-group global pixel counts on the device (all-reduced together with the sums)
         if training and fused is not None and fused[1:] == (mg, g, c):
             # statistics came out of the producing convolution's epilogue (fp32 rows per 128-row slab)
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
             if sync and collectives_on():
-                stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
+                stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)     # [G][2][C] sums + [G] local row counts
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
                      None, stats, c, dev, st)
-                dist.all_reduce(stats)
-                count = float(mg) * _world()
-                call("css_bn_finalize", stats, g, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                dist.all_reduce(stats)          # SyncBN: (sum, sum of squares, count) of every rank - counts may differ per rank
+                count_t = stats[g * 2 * c:]
+                call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
@@ -323,11 +344,11 @@ class _BNAct(torch.autograd.Function):
             call("css_bn_stats", y, mg, g, c, c, partial, dc, dev, st)
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
             if sync and collectives_on():
-                stats = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
-                call("css_bn_reduce", partial, nrb, c, g, stats, None, None, 0, dev, st)
-                dist.all_reduce(stats)          # SyncBN: (sum, sum of squares) of every rank; equal pixel counts per rank
-                count = float(mg) * _world()
-                call("css_bn_finalize", stats, g, count, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+                stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)
+                call("css_bn_reduce", partial, nrb, c, g, stats, None, None, 0, float(mg), dev, st)
+                dist.all_reduce(stats)
+                count_t = stats[g * 2 * c:]
+                call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
                 call("css_bn_reduce_finalize", partial, nrb, g, count, gamma, beta, running_mean, running_var, float(momentum),
@@ -345,7 +366,7 @@ class _BNAct(torch.autograd.Function):
         if training:
             # ReLU mask in backward: from `out` when a residual was added, else recomputed from y*scale+shift (one read less)
             assert out_into is None or not (relu and res is not None)
-            ctx.save_for_backward(y, out if (relu and res is not None) else None, mean, invstd, gamma, scale, shift)
+            ctx.save_for_backward(y, out if (relu and res is not None) else None, mean, invstd, gamma, scale, shift, count_t)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         return out
@@ -355,7 +376,7 @@ class _BNAct(torch.autograd.Function):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
             raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
-        y, a, mean, invstd, gamma, scale, shift = ctx.saved_tensors
+        y, a, mean, invstd, gamma, scale, shift, count_t = ctx.saved_tensors
         c = y.shape[-1]
         m = y.numel() // c
         mg = m // g
@@ -372,17 +393,18 @@ class _BNAct(torch.autograd.Function):
         # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
         sg, sb = _grad_sink(gamma, (c,)), _grad_sink(ctx.beta_ref, (c,))
         if sg is not None and sb is not None:
-            call("css_bn_reduce", partial, nrb, c, g, sums, sg, sb, 1, dev, st)
+            call("css_bn_reduce", partial, nrb, c, g, sums, sg, sb, 1, 0.0, dev, st)
             dgamma = dbeta = None
+            _grad_ready(gamma, ctx.beta_ref)
         else:
             dgamma = torch.empty(c, dtype=torch.float32, device=y.device)
             dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
-            call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, dev, st)
+            call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, 0.0, dev, st)
         if sync and collectives_on():
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, m, c,
+        call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
              int(relu), mg, dc, dev, st)
         return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 

@@ -11,17 +11,24 @@
     zero_grad; backward; SGD(nesterov) step; ema_update; lr   mix_label.py:192-196
 
 Data parallelism (mix_label.py:76-77): one process per GPU; SyncBN statistics and the contrastive prototype sums are
-all-reduced inside the ops; the gradient of every student parameter lives in ONE flat fp32 buffer that is all-reduced
-(RCCL, averaged like DDP) in a single collective, followed by ONE fused SGD+EMA kernel over 59.5 M elements.
+all-reduced inside the ops; the gradient of every student parameter lives in ONE flat fp32 buffer.  Like DDP's buckets
+(mix_label.py:77) the buffer is all-reduced in a few pieces WHILE backward is still running: the kernels report each parameter
+whose gradient has been enqueued (ops.set_grad_ready_callback); the first step records that order and cuts it into buckets of
+CSS_GRAD_BUCKET_MB (default 48) MB, every later step launches a bucket's all-reduce (async, on a process group of its own so
+that the latency-critical SyncBN collectives never queue behind 50 MB of gradients) as soon as its last parameter reported.
+Whatever is left (parameters whose gradient goes through autograd's own accumulation) is reduced after backward; then ONE fused
+SGD+EMA kernel over 59.5 M elements averages (1 / world) and applies.
 """
 from __future__ import annotations
+
+import os
 
 import torch
 import torch.distributed as dist
 
 from . import functional as Fn
 from . import ops
-from ._lib import call, dev_stream
+from ._lib import call, dev_stream, dtype_code
 from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d, fused_upsample_ok
 from .scheduler.my_lr_scheduler import poly_lr
 
@@ -45,13 +52,20 @@ class MixTrainer:
         self.flat_p, self.flat_ema = model._ensure_flat()
         self.flat_g = torch.zeros_like(self.flat_p)
         self.flat_m = torch.zeros_like(self.flat_p)
-        for p, o in zip(model.model.parameters(), model.model._css_flat_offsets):
+        self._span = {}                        # id(param) -> (start, end) of its slice of the flat buffers (16-byte aligned slots)
+        offs = list(model.model._css_flat_offsets) + [self.flat_p.numel()]
+        for i, (p, o) in enumerate(zip(model.model.parameters(), model.model._css_flat_offsets)):
             n = p.numel()
             if p.dim() == 4:
                 co, ci, r, s = p.shape
                 p.grad = self.flat_g[o:o + n].view(co, r, s, ci).permute(0, 3, 1, 2)
             else:
                 p.grad = self.flat_g[o:o + n].view(p.shape)
+            self._span[id(p)] = (o, offs[i + 1])
+        self.bucket_mb = float(os.environ.get("CSS_GRAD_BUCKET_MB", "48"))
+        self._grad_pg = None                   # process group of the gradient buckets (created on first use, on every rank)
+        self._ready_order = None               # parameter spans in the order their gradients were reported (recorded on the first step)
+        self._buckets = None                   # [(runs = [(start, end), ...], number of reports that complete the bucket)]
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -69,6 +83,100 @@ class MixTrainer:
         below the strong threshold (loss.py:90-91)."""
         _, _, hard = Fn.similarity(rep_nhwc, self.prototypes, self.model.temp, cls=cls, strong_threshold=self.crit_contrast.strong_threshold)
         return hard
+
+    # ---- backward with the gradient all-reduce overlapped (DDP's bucketing, mix_label.py:77) ---------------------------------
+    def _plan_buckets(self, order):
+        """Cut the recorded readiness order into buckets of ~bucket_mb; a bucket = the contiguous runs of the flat buffer its
+        parameters cover (backward runs the layers in reverse, so a bucket is one or two runs)."""
+        limit = self.bucket_mb * 2 ** 20 / 4
+        buckets, cur, cnt, size = [], [], 0, 0
+        for sp in order:
+            cur.append(sp)
+            cnt += 1
+            size += sp[1] - sp[0]
+            if size >= limit:
+                buckets.append((self._runs(cur), cnt))
+                cur, cnt, size = [], 0, 0
+        if cur:
+            buckets.append((self._runs(cur), cnt))
+        return buckets
+
+    @staticmethod
+    def _runs(spans):
+        runs = []
+        for a, b in sorted(spans):
+            if runs and runs[-1][1] == a:
+                runs[-1][1] = b
+            else:
+                runs.append([a, b])
+        return [tuple(r) for r in runs]
+
+    def _backward_and_reduce(self, total):
+        sync = ops.collectives_on()
+        overlap = sync and self.bucket_mb > 0
+        if not overlap:
+            with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
+                total.backward()
+            if sync:
+                dist.all_reduce(self.flat_g)     # one bucket, after backward
+            return
+        if self._grad_pg is None:
+            self._grad_pg = dist.new_group()     # same ranks, own communicator / stream
+        works, done, seen = [], [], set()
+        state = dict(n=0, b=0)
+        record = [] if self._buckets is None else None
+
+        def launch(runs):
+            for a, b in runs:
+                works.append(dist.all_reduce(self.flat_g[a:b], group=self._grad_pg, async_op=True))
+                done.append((a, b))
+
+        def ready(p):
+            sp = self._span.get(id(p))
+            if sp is None or sp in seen:
+                return
+            seen.add(sp)
+            if record is not None:
+                record.append(sp)
+                return
+            state["n"] += 1
+            while state["b"] < len(self._buckets) and state["n"] >= self._bucket_end[state["b"]]:
+                launch(self._buckets[state["b"]][0])
+                state["b"] += 1
+
+        prev = ops.set_grad_ready_callback(ready)
+        try:
+            with ops.direct_param_grads():
+                total.backward()
+        finally:
+            ops.set_grad_ready_callback(prev)
+        if record is not None:                   # first step: learn the order, reduce in one piece
+            self._ready_order = list(record)
+            self._buckets = self._plan_buckets(record)
+            ends, acc = [], 0
+            for _, cnt in self._buckets:
+                acc += cnt
+                ends.append(acc)
+            self._bucket_end = ends
+            self._n_reports = len(record)
+            dist.all_reduce(self.flat_g, group=self._grad_pg)
+            return
+        if state["n"] != self._n_reports:        # the graph changed (other losses / frozen layers): fall back, re-learn next step
+            for w in works:
+                w.wait()
+            self._buckets = None
+            raise RuntimeError("gradient readiness order changed between steps; buckets were reset - rebuild the trainer for a new graph")
+        # the rest of the buffer: parameters that never report (gradient through autograd's own accumulation) and alignment gaps
+        pos, rest = 0, []
+        for a, b in sorted(done):
+            if a > pos:
+                rest.append((pos, a))
+            pos = max(pos, b)
+        if pos < self.flat_g.numel():
+            rest.append((pos, self.flat_g.numel()))
+        launch(rest)
+        for w in works:
+            w.wait()                             # the compute stream waits for the buckets (host does not block on RCCL)
 
     @property
     def lr(self):
@@ -94,11 +202,8 @@ class MixTrainer:
             hard = self._hard_flags(rep_rows.view(b2, h, w, c), cls, pred_small)
         con = self.crit_contrast.forward_fused(rep_rows, cls, hard, self.prototypes, self.K, _injected)
         total = sup + unsup + con * ramp
-        with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
-            total.backward()
+        self._backward_and_reduce(total)
         world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
-        if ops.collectives_on():
-            dist.all_reduce(self.flat_g)                                     # DDP gradient all-reduce (mean), one bucket
         decay = min(1 - 1 / (m.step + 1), m.alpha)
         dev, st = dev_stream(self.flat_p)
         call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
@@ -142,6 +247,10 @@ class OriTrainer(MixTrainer):
 
     def _hard_flags(self, rep_nhwc, cls, pred_small):
         b2, k, h, w = pred_small.shape                                    # logical NCHW view of NHWC memory
-        prob = torch.softmax(pred_small.detach().permute(0, 2, 3, 1).reshape(b2 * h * w, k).float(), dim=1)
-        own = prob.gather(1, cls.clamp(min=0).long().unsqueeze(1)).squeeze(1)
-        return ((cls >= 0) & (own < self.crit_contrast.strong_threshold)).to(torch.uint8)
+        rows = pred_small.detach().permute(0, 2, 3, 1)
+        if not rows.is_contiguous():
+            rows = rows.contiguous()
+        hard = torch.empty(b2 * h * w, dtype=torch.uint8, device=rows.device)
+        dev, st = dev_stream(rows)
+        call("css_softmax_hard_flags", rows, k, cls, b2 * h * w, k, float(self.crit_contrast.strong_threshold), hard, dtype_code(rows.dtype), dev, st)
+        return hard

@@ -66,15 +66,19 @@ class ConfMatrix(object):
         self.mat += self.temp_mat
 
     @torch.no_grad()
-    def update_from_logits(self, pred, target, return_argmax=False):
-        """pred: the network's low-resolution logits, logical [B,K,h,w] (channels_last memory, as the HIP model returns them) or
-        an NHWC tensor [B,h,w,K]; target: int64 [B,H,W].  Equivalent to
+    def update_from_logits(self, pred, target, return_argmax=False, channels_last=False):
+        """pred: the network's low-resolution logits, logical [B,K,h,w] (channels_last memory, as the HIP model returns them), or -
+        with ``channels_last=True`` - an NHWC tensor [B,h,w,K]; the layout is never guessed from the shape (h or w may equal K).
+        target: int64 [B,H,W].  Equivalent to
         ``update(F.interpolate(pred, target.shape[1:], mode='bilinear', align_corners=True).argmax(1).flatten(), target.flatten())``."""
         self._ensure(pred.device)
         k = self.num_classes
         if pred.dim() != 4:
             raise ValueError("pred must be 4-d")
-        nhwc = pred if pred.shape[-1] == k and pred.shape[1] != k else pred.permute(0, 2, 3, 1)
+        if pred.shape[-1 if channels_last else 1] != k:
+            raise ValueError(f"pred has {pred.shape[-1 if channels_last else 1]} classes on its {'last' if channels_last else 'second'} "
+                             f"dimension, the meter has {k} (pass channels_last=True for [B,h,w,K] tensors)")
+        nhwc = pred if channels_last else pred.permute(0, 2, 3, 1)
         if not nhwc.is_contiguous():
             nhwc = nhwc.contiguous()
         if nhwc.dtype not in (torch.float32, torch.bfloat16):

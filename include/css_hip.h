@@ -32,7 +32,10 @@ CSS_API int css_device_cu_count(int device);
  * Every kernel launch of a bracketed call gets its own event pair.  kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad
  * (launches of every kernel but the 256x256 LDS-DMA ones), 3 = contrast loss gather, 4 = similarity,
  * 5 / 6 / 7 = conv_igemm_dma256_kernel forward / dgrad launches and conv_wgrad_dma256_kernel launches.
- * alg_work of a convolution launch = the call's algorithmic FLOPs x the share of output rows that launch covers. */
+ * alg_work of a convolution launch = the call's algorithmic FLOPs x the share of output rows that launch covers.
+ * HBM-bound kernels, alg_work = algorithmic BYTES (every operand read once, every result written once):
+ * 8 = bn_apply, 9 = bn_bwd_apply, 10 = bn_bwd_reduce, 11 = sgd_ema, 12 = the write-bound 1x1 forward convolutions
+ * (K <= 512 in, >= 4K out; the same launches are also counted under 0 / 5 with their FLOPs). */
 CSS_API int css_prof_enable(int on);
 CSS_API int css_prof_reset(void);
 CSS_API int css_prof_read(int kind, double* total_ms, double* launches, double* alg_work);
@@ -61,6 +64,9 @@ CSS_API int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, cons
 /* dw: fp32 [Cout][R][S][Cin], ACCUMULATED (atomic adds): zero it first unless accumulating on purpose */
 CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
+/* host-side query (no launch): the number of pixel slices css_conv2d_wgrad cuts M = N*Ho*Wo rows into on a device with n_cu compute
+ * units (one accumulation pass of fp32 atomics per slice); tests use it to check that bench-size layers take the split path */
+CSS_API int css_wgrad_splits(int M, int Ktot, int Cout, int dtype, int n_cu);
 /* fp32 master [Cout][taps][Cin] -> compute dtype; dgrad=0: [Cout][taps][CinPad], dgrad=1: [Cin][taps][Cout] */
 CSS_API int css_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, int device,
                               css_stream_t stream);
@@ -78,22 +84,27 @@ CSS_API int css_weight_dgrad_layout_batched(const float* flat, void* out, const 
  * (partial is [G][nrb][2][C], nrb = css_bn_nrb(Mg, G, C, dtype); plain stores, no atomics); css_bn_reduce sums them
  * (sums is [G][2][C]; can also emit the BN parameter gradients, summed over groups); css_bn_reduce_finalize fuses the sum
  * with the train-mode finalize for the single-rank case; css_bn_finalize starts from (all-reduced) sums.
- * mean / invstd / scale / shift are [G][C]. */
+ * mean / invstd / scale / shift are [G][C].
+ * SyncBN with per-rank pixel counts (nn.SyncBatchNorm exchanges counts, mix_label.py:76): a sums buffer handed to a collective is
+ * [G][2][C] + [G]: css_bn_reduce (count_local > 0) and css_bn_reduce_finalize_slabs (sums_out) put THIS rank's rows per group behind
+ * the sums, so one all-reduce yields the global sums and the global counts; css_bn_finalize / css_bn_bwd_apply read the count of group
+ * g from count_dev[g] when count_dev != NULL (the host value `count` is then ignored). */
 CSS_API int css_bn_nrb(int Mg, int G, int C, int dtype);
 CSS_API int css_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, int device, css_stream_t stream);
-CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate, int device,
-                          css_stream_t stream);
+CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* dgamma, float* dbeta, int accumulate,
+                          double count_local, int device, css_stream_t stream);
 CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                    float* shift, int C, int device, css_stream_t stream);
 /* stage 2 for css_conv2d_forward_bnstats: partial fp32 [ceil(M/128) + G][2][C] -> per-group sums (fp64).  sums_out == NULL:
- * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] (SyncBN all-reduces them, then css_bn_finalize) */
+ * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] + [G] local counts (SyncBN all-reduces them, then
+ * css_bn_finalize) */
 CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                                          float* scale, float* shift, double* sums_out, int C, int device, css_stream_t stream);
-CSS_API int css_bn_finalize(const double* sums, int G, double count, const float* gamma, const float* beta, float* running_mean,
-                            float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C,
-                            int device, css_stream_t stream);
+CSS_API int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                            float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                               float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
@@ -105,7 +116,8 @@ CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, 
                               css_stream_t stream);
 CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                              const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale,
-                             const float* shift, double count, int M, int C, int relu, int Mg, int dtype, int device, css_stream_t stream);
+                             const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg, int dtype, int device,
+                             css_stream_t stream);
 
 /* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
 CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
@@ -133,6 +145,10 @@ CSS_API int css_ema(float* ema, const float* p, long n, float decay, int device,
 CSS_API int css_proto_normalize(const float* proto, void* out, int K, int C, int dtype, int device, css_stream_t stream);
 CSS_API int css_similarity(const void* rep, int ld, const void* proto_n, float* sim, float* prob, const int* cls, uint8_t* hard, int P, int K, int C,
                            float temp, float strong_thr, int dtype, int device, css_stream_t stream);
+/* ori_pseudo.py:178-180 + loss.py:90-91: hard[p] = cls[p] >= 0 && softmax(pred[p][0..K))[cls[p]] < strong_thr, pred = the student's own
+ * low-resolution class logits [P][ld] (no prototype similarity in that script) */
+CSS_API int css_softmax_hard_flags(const void* pred, int ld, const int* cls, int P, int K, float strong_thr, uint8_t* hard, int dtype, int device,
+                                   css_stream_t stream);
 CSS_API int css_pseudo_label(const float* sim, const void* pred, int ldp, int B, int h, int w, int K, int H, int W, float temp, float* logits_rep,
                              int64_t* labels_rep, float* logits_cls, int64_t* labels_cls, float* pseudo, int dtype, int device,
                              css_stream_t stream);

@@ -15,7 +15,7 @@ def _trainer(seed, K=21, S=65):
     from css_amd.networks.ddp_model import Model_mix
     from css_amd.train_step import MixTrainer
     torch.manual_seed(seed)
-    cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "none"}}
+    cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "none", "device_aug": "identity"}}
     m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev())
     m.model.train()
     m.ema_model.train()

@@ -95,3 +95,88 @@ def test_world2_exchanges_equal_reference_gather():
         assert e_bn < 1e-5 and e_grad < 1e-6
     # class 4 lives on rank 1 only: rank 0 must leave its prototype row untouched, rank 1 updates it (reference behaviour)
     assert abs(res[0][4] - res[0][5]) < 1e-5 and abs(res[1][4] - res[1][5]) < 1e-5
+
+
+def _bucket_worker(rank, world, port, q):
+    """MixTrainer._backward_and_reduce on a toy graph (CPU tensors, gloo): layers whose backward ADDS the parameter gradient into the
+    flat buffer and reports the parameter (as the HIP conv / batch-norm backward do), one parameter whose gradient goes through
+    autograd's own accumulation (never reported), three steps: record, bucketed, bucketed."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from css_amd import ops
+    from css_amd.train_step import MixTrainer
+
+    class Lin(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            ctx.w = w
+            return x * w.sum()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            ctx.w.grad += (g * x).sum() * torch.ones_like(w)         # "kernel adds into the flat buffer"
+            ops._grad_ready(ctx.w)
+            return g * w.sum(), None
+
+    sizes = [5, 300, 8, 1000, 16, 700, 24]                           # 7 layers + 1 late parameter
+    offs, tot = [], 0
+    for n in sizes + [40]:
+        offs.append(tot)
+        tot += (n + 7) // 8 * 8
+    flat_p = torch.randn(tot, generator=torch.Generator().manual_seed(1))
+    flat_g = torch.zeros(tot)
+    params = []
+    for n, o in zip(sizes + [40], offs):
+        p = torch.nn.Parameter(flat_p[o:o + n].clone())
+        p.grad = flat_g[o:o + n]
+        params.append(p)
+    tr = MixTrainer.__new__(MixTrainer)
+    tr.flat_g = flat_g
+    tr._span = {id(p): (o, e) for p, o, e in zip(params, offs, offs[1:] + [tot])}
+    tr.bucket_mb = 4096 / 2 ** 20                                   # 1024 floats per bucket
+    tr._grad_pg = tr._ready_order = tr._buckets = None
+    errs = []
+    for step in range(3):
+        flat_g.zero_()
+        x = torch.full((), float(rank + 1 + step), requires_grad=True)
+        h = x
+        for p in params[:-1]:
+            h = Lin.apply(h, p)
+        total = h + (params[-1] * (rank + 2)).sum()                  # last parameter: plain autograd accumulation, never reported
+        # reference: the same backward without any collective, then one all-reduce
+        ref_g = torch.zeros(tot)
+        for p, o in zip(params, offs):
+            p.grad = ref_g[o:o + p.numel()]
+        total.backward(retain_graph=True)
+        dist.all_reduce(ref_g)
+        for p, o in zip(params, offs):
+            p.grad = flat_g[o:o + p.numel()]
+        tr._backward_and_reduce(total)
+        errs.append((flat_g - ref_g).abs().max().item())
+    q.put((rank, errs, len(tr._buckets), [r for r, _ in tr._buckets], len(tr._ready_order)))
+    dist.destroy_process_group()
+
+
+def test_world2_bucketed_gradient_all_reduce_equals_one_all_reduce():
+    os.environ["CSS_FORCE_COLLECTIVES"] = "0"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, errs, nb, runs, nrep in res:
+        assert max(errs) == 0.0, (rank, errs)                        # two ranks: a + b in any order is the same float
+        assert nrep == 7 and nb >= 2, (nb, nrep)
+        # backward visits the layers in reverse: every bucket is one contiguous run of the flat buffer
+        assert all(len(r) == 1 for r in runs), runs
+    assert res[0][3] == res[1][3]                                    # same plan on both ranks

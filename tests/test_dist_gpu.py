@@ -123,14 +123,16 @@ dev = torch.device("cuda:0")
 dist.init_process_group("gloo", rank=rank, world_size=world)
 K, S = 21, 65
 torch.manual_seed(11)                                   # same initial weights on every rank (DDP broadcasts rank 0's)
-cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix"}}
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix", "device_aug": "identity"}}
 m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
 m.model.train(); m.ema_model.train()
 m.set_compute_dtype(torch.bfloat16)
 tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
 g = torch.Generator().manual_seed(100 + rank)           # different data per rank
 losses = []
-for it in range(2):
+import numpy as np
+np.random.seed(5)                                        # cutmix boxes (host draws)
+for it in range(3):
     l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
     u = torch.randn(2, 3, S, S, generator=g).to(dev)
     out = tr.step(l, y, u)
@@ -139,26 +141,48 @@ probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
 ema = tr.flat_ema[:: tr.flat_ema.numel() // 4096][:4096].double().cpu()
 proto = tr.prototypes.double().cpu()
 rm = m.model.resnet_bn1.running_mean.double().cpu()
-json.dump(dict(losses=losses, p=probe.tolist(), ema=ema.tolist(), proto=proto.flatten().tolist(), rm=rm.tolist()), open(sys.argv[1] + str(rank), "w"))
+nb = [len(tr._buckets), sum(len(r) for r, _ in tr._buckets), len(tr._ready_order)] if tr._buckets else [0, 0, 0]
+json.dump(dict(losses=losses, p=probe.tolist(), ema=ema.tolist(), proto=proto.flatten().tolist(), rm=rm.tolist(), buckets=nb),
+          open(sys.argv[1] + str(rank), "w"))
 dist.destroy_process_group()
 '''
 
 
-def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
-    """MixTrainer.step on two ranks (bf16, different data per rank): SyncBN statistics, the prototype class sums and the flat
-    gradient are all-reduced, so after two steps both replicas hold the same parameters, EMA teacher, BN running statistics and
-    prototypes (for the classes both ranks see) - the data-parallel contract of mix_label.py:76-77."""
+def _trainer_pair(tmp_path, bucket_mb):
     import json
-    import torch
-    out = str(tmp_path / "r")
+    out = str(tmp_path / f"r{bucket_mb}_")
     code = TRAINER_WORKER % ROOT
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578")
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", CSS_GRAD_BUCKET_MB=bucket_mb)
         procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
     for p in procs:
         assert p.wait(timeout=900) == 0
-    a, b = json.load(open(out + "0")), json.load(open(out + "1"))
+    return json.load(open(out + "0")), json.load(open(out + "1"))
+
+
+def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
+    """The gradient all-reduce overlapped with backward in buckets (train_step.MixTrainer._backward_and_reduce; DDP's buckets at
+    mix_label.py:77) against ONE all-reduce after backward (CSS_GRAD_BUCKET_MB=0): three steps (the first records the readiness order,
+    the next two run bucketed), replicas bit-identical in both modes, and the two modes equal up to the order of the fp32 atomic adds."""
+    import torch
+    a8, b8 = _trainer_pair(tmp_path, "8")
+    a0, b0 = _trainer_pair(tmp_path, "0")
+    print("buckets / runs / parameters reported:", a8["buckets"])
+    assert a8["buckets"][0] >= 10 and a8["buckets"][2] > 300 and a0["buckets"] == [0, 0, 0]
+    assert a8["buckets"][1] <= a8["buckets"][0] + 4              # backward runs the layers in reverse: a bucket is one or two runs
+    for a, b in ((a8, b8), (a0, b0)):
+        assert torch.equal(torch.tensor(a["p"]), torch.tensor(b["p"])) and torch.equal(torch.tensor(a["ema"]), torch.tensor(b["ema"]))
+    p8, p0 = torch.tensor(a8["p"]), torch.tensor(a0["p"])
+    assert ((p8 - p0).norm() / p0.norm()).item() < 2e-3
+
+
+def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
+    """MixTrainer.step on two ranks (bf16, different data per rank): SyncBN statistics, the prototype class sums and the flat
+    gradient are all-reduced, so after three steps both replicas hold the same parameters, EMA teacher, BN running statistics and
+    prototypes (for the classes both ranks see) - the data-parallel contract of mix_label.py:76-77."""
+    import torch
+    a, b = _trainer_pair(tmp_path, "48")
     # (the unsupervised term is NaN-valued with zero gradient when no pseudo-label is confident, like the reference: SURVEY L2)
     assert all(v == v and abs(v) < 1e3 for l in a["losses"] + b["losses"] for v in l), (a["losses"], b["losses"])
     pa, pb = torch.tensor(a["p"]), torch.tensor(b["p"])
@@ -180,7 +204,7 @@ if os.environ.get("CSS_FORCE_COLLECTIVES") == "1":
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)      # "nccl" IS RCCL on ROCm
 K, S = 21, 65
 torch.manual_seed(11)
-cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix"}}
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix", "device_aug": "identity"}}
 m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
 m.model.train(); m.ema_model.train()
 m.set_compute_dtype(torch.bfloat16)
@@ -261,7 +285,7 @@ dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cu
 g = dict(np.load(os.path.join(%r, "tests", "golden", "train_trace_damped.npz")))
 seed, gain = int(g["seed"]), float(g["residual_gain"])
 K, S = 21, 65
-config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Network": {"num_class": K}}
+config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}, "Network": {"num_class": K}}
 backbone = resnet.resnet101_tv()
 model = Model_mix(backbone, num_classes=K, output_dim=256, config=config, temp=0.5)
 sd = O.init_state("tv", K, 256, seed, gain)
@@ -347,3 +371,92 @@ def test_mix_label_body_under_ddp_matches_reference_trace(tmp_path):
     for name, (es, et) in r["w"].items():
         assert es < 3e-2 and et < 3e-2, (name, es, et)
     assert r["grads_none"] == [], r["grads_none"][:5]        # every student parameter received a gradient through DDP
+
+
+UNEQUAL_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+import torch.nn.functional as F
+from css_amd import ops
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+bf16 = bool(os.environ.get("CSS_TEST_BF16"))
+dt = torch.bfloat16 if bf16 else torch.float32
+g = torch.Generator().manual_seed(3)
+n_all, c, cin, h, w = 8, 64, 64, 17, 17
+x = torch.randn(n_all, cin, h, w, generator=g) + 0.3
+wt = torch.randn(c, cin, 1, 1, generator=g) / 8
+go = torch.randn(n_all, c, h, w, generator=g)
+gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+if bf16:
+    x, wt, go = x.bfloat16().float(), wt.bfloat16().float(), go.bfloat16().float()
+# reference: ONE process over all 8 images (nn.SyncBatchNorm semantics = batch statistics of the global batch)
+xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+rm_r, rv_r = torch.zeros(c), torch.ones(c)
+yr = F.conv2d(xr, wt)
+if bf16:
+    yr = yr + (yr.detach().bfloat16().float() - yr.detach())      # the HIP path normalises the bf16-rounded conv output
+o = F.relu(F.batch_norm(yr, rm_r, rv_r, gr, br, True, 0.1, 1e-5))
+o.backward(go)
+# ranks own 6 and 2 images: unequal pixel counts per rank
+lo, hi = (0, 6) if rank == 0 else (6, 8)
+xg = x[lo:hi].permute(0, 2, 3, 1).contiguous().to(dev, dt).requires_grad_(True)
+wg = wt.to(dev).contiguous(memory_format=torch.channels_last)
+gg, bg = gamma.to(dev).requires_grad_(True), beta.to(dev).requires_grad_(True)
+rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+with ops.bn_groups(1):
+    y = ops.conv2d(xg, wg, None, 1, 0, 1, bn_stats=bf16)
+    assert hasattr(y, "_css_bnstats") == bf16
+    a = ops.bn_act(y, gg, bg, rm, rv, None, True, True, 0.1, 1e-5, True)
+a.backward(go[lo:hi].permute(0, 2, 3, 1).contiguous().to(dev, dt))
+def rel(p, q):
+    return float((p.double() - q.double()).abs().max() / q.double().abs().max())
+dgam, dbet = gg.grad.clone(), bg.grad.clone()
+dist.all_reduce(dgam); dist.all_reduce(dbet)                      # parameter gradients are local sums (DDP reduces them)
+out = dict(a=rel(a.detach().float().cpu().permute(0, 3, 1, 2), o.detach()[lo:hi]), dx=rel(xg.grad.float().cpu().permute(0, 3, 1, 2), xr.grad[lo:hi]),
+           rm=rel(rm.cpu(), rm_r), rv=rel(rv.cpu(), rv_r), dgamma=rel(dgam.cpu(), gr.grad), dbeta=rel(dbet.cpu(), br.grad))
+json.dump(out, open(sys.argv[1] + str(rank), "w"))
+dist.destroy_process_group()
+'''
+
+
+@pytest.mark.parametrize("bf16", [False, True])
+def test_syncbn_with_unequal_pixel_counts_per_rank(tmp_path, bf16):
+    """nn.SyncBatchNorm (mix_label.py:76) exchanges per-rank counts; here the counts ride behind the (sum, sum of squares) payload
+    of the one all-reduce.  Ranks with 6 and 2 images == one process with 8 (outputs, running statistics incl. the unbiased
+    variance factor, input and parameter gradients) - both statistics paths (bn_stats pass / conv-epilogue slab rows)."""
+    import json
+    out = str(tmp_path / "u.json")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583")
+        if bf16:
+            env["CSS_TEST_BF16"] = "1"
+        procs.append(subprocess.Popen([sys.executable, "-c", UNEQUAL_WORKER % ROOT, out], env=env))
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    tol = 2e-2 if bf16 else 1e-4
+    for r in range(2):
+        res = json.load(open(out + str(r)))
+        print(r, res)
+        assert res["a"] < tol and res["dx"] < 5 * tol and res["dgamma"] < 5 * tol and res["dbeta"] < 5 * tol
+        assert res["rm"] < (1e-2 if bf16 else 1e-5) and res["rv"] < (1e-2 if bf16 else 1e-5)
+
+
+def test_bench_self_launcher_two_ranks_on_this_gpu():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset: the launcher starts two fresh ranks before anything touches the GPU; here they
+    share cuda:0 and exchange through gloo (CSS_BENCH_SHARE_GPU=1; a one-GPU box cannot host two RCCL ranks), tiny crops."""
+    import json
+    env = dict(os.environ, CSS_BENCH_SHARE_GPU="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--size", "65", "--batch", "2",
+                        "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8 and d["value"] > 0 and d["scaling"] == "weak"
+    assert all(v == v for v in d["losses"].values())

@@ -54,6 +54,15 @@ def test_confusion_matrix_edge_cases():
     m2 = ConfMatrix(K)
     m2.update_from_logits(pred, torch.zeros(1, 2, 2, dtype=torch.int64, device=dev()))
     assert int(m2.mat[0, 0]) == 4
+    # h == K (and w == K): the layout is taken from the argument, never guessed from the shape
+    pred = torch.randn(1, K, K, K, device=dev())
+    lab = pred.argmax(1)
+    m3, m4 = ConfMatrix(K), ConfMatrix(K)
+    m3.update_from_logits(pred, lab)
+    m4.update_from_logits(pred.permute(0, 2, 3, 1).contiguous(), lab, channels_last=True)
+    assert int(m3.mat.diag().sum()) == K * K and torch.equal(m3.mat, m4.mat)
+    with pytest.raises(ValueError):
+        ConfMatrix(K).update_from_logits(torch.zeros(1, 3, 3, K + 1, device=dev()), torch.zeros(1, 3, 3, dtype=torch.int64, device=dev()))
     with pytest.raises(Exception):
         ConfMatrix(K).update(torch.zeros(3, dtype=torch.int64), torch.zeros(3, dtype=torch.int64))   # CPU tensors: no CPU path
 

@@ -267,3 +267,46 @@ def test_collectives_switch(tmp_path):
     for force in ("0", "1"):
         env = dict(os.environ, CSS_FORCE_COLLECTIVES=force)
         assert subprocess.run([sys.executable, "-c", code], env=env, timeout=300).returncode == 0
+
+
+def test_device_aug_defaults_to_the_reference_pipeline_and_pair_shapes_are_checked():
+    """the reference's YAML has no ``device_aug`` key - with the key absent the step wrappers must augment like the
+    reference (the 'pil' restatement), and unequal labeled / unlabeled batches must not silently share batch-norm groups."""
+    import contextlib
+    import io
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_mix
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = Model_mix(resnet.resnet101_tv(), num_classes=21, config={"Dataset": {"crop_size": (65, 65)}}, temp=0.5)
+        m2 = Model_mix(resnet.resnet101_tv(), num_classes=21, config={"Dataset": {"device_aug": "identity"}}, temp=0.5)
+    assert m._device_aug() == "pil" and m2._device_aug() == "identity"
+    with pytest.raises(ValueError):
+        m._check_pair(torch.zeros(2, 3, 9, 9), torch.zeros(4, 3, 9, 9))
+    m._check_pair(torch.zeros(2, 3, 9, 9), torch.zeros(2, 3, 9, 9))
+
+
+def _run_bench(args, env_extra, timeout=120):
+    env = dict(os.environ, **env_extra)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_self_launcher_starts_ranks_and_relays_one_line():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts 2 fresh ranks itself (mix_label.py:265 spawns its own workers too):
+    rendezvous on 127.0.0.1, one collective, ONE JSON line from rank 0, rc 0; a failing rank makes the launcher exit non-zero."""
+    import json
+    r = _run_bench(["--gpus", "2"], {"CSS_BENCH_LAUNCH_TEST": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip() and not ln.startswith("[Gloo]")]   # (gloo's own connection banner)
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"launch_test": True, "n_gpus": 2, "sum": 3.0}
+    r = _run_bench(["--gpus", "2"], {"CSS_BENCH_LAUNCH_TEST": "fail1"})
+    assert r.returncode != 0 and not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_bench_refuses_a_world_size_mismatch():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(os.environ, WORLD_SIZE="4", RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr

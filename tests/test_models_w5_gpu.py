@@ -17,7 +17,7 @@ K, S, B = 21, 65, 2
 def _setup(cls, **kw):
     from css_amd.networks import resnet
     from oracle import css_oracle as O
-    cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "none"}}
+    cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "none", "device_aug": "identity"}}
     m = cls(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, **kw)
     sd = O.init_state("tv", K, 256, 31, 0.25)          # well-conditioned random weights (bn3 gains x0.25), as the damped fixtures
     m.model.load_state_dict(sd)

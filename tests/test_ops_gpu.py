@@ -292,12 +292,13 @@ def test_conv_epilogue_bn_statistics(case):
     with ops.bn_groups(groups):
         y = ops.conv2d(x, wt, None, 1, pad, dil, bn_stats=True)
     part, mg, g_, c_ = y._css_bnstats
-    sums = torch.empty(groups * 2 * cout, dtype=torch.float64, device=dev())
+    sums = torch.empty(groups * 2 * cout + groups, dtype=torch.float64, device=dev())   # [G][2][C] sums + [G] row counts
     d, st = dev_stream(y)
     call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
          sums, cout, d, st)
     want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1).reshape(-1)
-    assert rel_err(sums.cpu(), want) < 1e-6
+    assert rel_err(sums.cpu()[:groups * 2 * cout], want) < 1e-6
+    assert sums.cpu()[groups * 2 * cout:].tolist() == [float(mg)] * groups        # this rank's rows per group ride behind the sums
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -23,7 +23,7 @@ def make(seed, K=21, S=65, gain=1.0):
     from css_amd.networks import resnet
     from css_amd.networks.ddp_model import Model_mix
     from oracle import css_oracle as O
-    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}}
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}}
     m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.5)
     sd = O.init_state("tv", K, 256, seed, gain)
     m.model.load_state_dict(sd, strict=True)

@@ -54,7 +54,7 @@ def test_entry_script_train_body_vs_reference_trace(golden, kind):
     from oracle import css_oracle as O
     g = golden(f"train_trace_{kind}")
     seed, gain, weak = int(g["seed"]), float(g["residual_gain"]), float(g["weak"])
-    config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Loss": {"weak_threshold": weak}}
+    config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}, "Loss": {"weak_threshold": weak}}
     if kind == "cross":
         model = Model_cross(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=config, temp=0.5)
     else:
@@ -134,7 +134,7 @@ def _build(kind, g):
     from css_amd.networks.ddp_model import Model_cross, Model_ori_pseudo
     from oracle import css_oracle as O
     seed, gain, weak = int(g["seed"]), float(g["residual_gain"]), float(g["weak"])
-    config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}, "Loss": {"weak_threshold": weak}}
+    config = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}, "Loss": {"weak_threshold": weak}}
     if kind == "cross":
         model = Model_cross(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=config, temp=0.5)
     else:
@@ -207,7 +207,7 @@ def test_cityscapes_shaped_step_vs_reference_trace(golden):
     from oracle import css_oracle as O
     g = golden("train_trace_city")
     seed, gain, Kc = int(g["seed"]), float(g["residual_gain"]), 19
-    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none"}}
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}}
     m = Model_mix(resnet.resnet101(), num_classes=Kc, output_dim=256, config=cfg, temp=0.5)
     sd = O.init_state("stem", Kc, 256, seed, gain)
     m.model.load_state_dict(sd, strict=True)
