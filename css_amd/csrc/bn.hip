@@ -74,8 +74,10 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
 #define S2_CH_V 8
 #endif
 constexpr int S2_CH = S2_CH_V, S2_NP = 1024 / S2_CH_V;
-template <typename PT, typename Rows, typename Emit>
-__device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, int C, int G, Rows rows, Emit emit) {
+struct NoTail { __device__ __forceinline__ void operator()(int, int, int, int, double&, double&) const {} };
+// tail(g, c, pl, P, t0, t1): optional extra contribution of partition pl (of P) to the sums of (group g, channel c)
+template <typename PT, typename Rows, typename Emit, typename Tail = NoTail>
+__device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, int C, int G, Rows rows, Emit emit, Tail tail = Tail()) {
   __shared__ double red[2][S2_NP][S2_CH];
   const int cl = threadIdx.x & (S2_CH - 1), part = threadIdx.x / S2_CH;
   const int c = blockIdx.x * S2_CH + cl;
@@ -109,6 +111,7 @@ __device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, in
         a0[7] += (double)partial[(size_t)extra * 2 * C + c];
         a1[7] += (double)partial[(size_t)extra * 2 * C + C + c];
       }
+      tail(g, c, pl, P, a0[6], a1[6]);
     }
     red[0][part][cl] = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
     red[1][part][cl] = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
@@ -176,16 +179,17 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
       });
 }
 
-// Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile): partial is fp32
-// [nslab + G][2][C]: one row per 128-row slab of the [G*Mg][C] tensor plus one spill row per group (rows of a slab that
-// lie in the NEXT group than the slab's first row).  Group g = slabs ceil(g*Mg/128) .. ceil((g+1)*Mg/128)-1, plus spill
-// row nslab+g when g*Mg is not a multiple of 128.
-// sums_out != null: write [G][2][C] sums only (SyncBN: all-reduced before bn_finalize); else finalize in place.
+// Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile, conv_pp.hip): partial is fp32
+// [nslab][2][C], one row per 128-row slab of the [G*Mg][C] tensor y, holding the sums of those rows of the slab that belong to the
+// statistics group of the slab's FIRST row.  Group g = slabs ceil(g*Mg/128) .. ceil((g+1)*Mg/128)-1 plus - when g*Mg is not a
+// multiple of 128 - the rows g*Mg .. (next multiple of 128) of y itself (< 128 rows, summed here from the bf16 tensor: the head
+// of the group sits in a slab that started in the previous group).
+// sums_out != null: write [G][2][C] sums (+ [G] row counts) only (SyncBN: all-reduced before bn_finalize); else finalize in place.
 __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* running_mean, float* running_var, float momentum, float eps,
                                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
-                                                               double* sums_out, int C) {
+                                                               double* sums_out, int C, const bf16_t* __restrict__ y, int ldy) {
   if (sums_out && blockIdx.x == 0 && threadIdx.x < G) sums_out[(size_t)G * 2 * C + threadIdx.x] = (double)Mg;   // local count, see bn_reduce_kernel
   stage2_reduce(
       partial, C, G,
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
         lo = (int)((b + 127) >> 7);
         hi = (int)((e + 127) >> 7);
         if (hi > nslab) hi = nslab;
-        extra = (g > 0 && (b & 127)) ? nslab + g : -1;
+        extra = -1;
       },
       [&](int g, double a0, double a1, int c) {
         if (sums_out) {
@@ -203,6 +207,17 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
         } else {
           bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
                           scale_out + g * C, shift_out + g * C, c);
+        }
+      },
+      [&](int g, int c, int pl, int P, double& t0, double& t1) {
+        const long b = (long)g * Mg;
+        if (!(b & 127)) return;
+        long e = (b + 127) & ~127L;
+        if (e > b + Mg) e = b + Mg;
+        for (long r = b + pl; r < e; r += P) {
+          const float v = (float)y[(size_t)r * ldy + c];
+          t0 += (double)v;
+          t1 += (double)v * (double)v;
         }
       });
 }
@@ -451,10 +466,10 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
 }
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                               float* shift, double* sums_out, int C, hipStream_t st) {
-  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M) return CSS_ERR_ARG;
+                               float* shift, double* sums_out, int C, const void* y, int ldy, hipStream_t st) {
+  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C) return CSS_ERR_ARG;
   hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, cdiv(M, 128), Mg, G, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C);
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

@@ -77,9 +77,9 @@ __device__ __forceinline__ float lanes_sum(float v) {
 //  * a.stats   - batch-norm statistics of exactly the values stored (the bf16-rounded ones bn_stats would read back):
 //                per-channel (sum, sum of squares) of every 128-row SLAB of the output, written to
 //                stats[slab][2][Cd] (fp32, plain stores - one workgroup owns a slab).  Statistics groups (forward passes
-//                batched along M, stat_Mg rows each) need not be slab-aligned: the rows of a slab that lie past the end of
-//                the group its first row belongs to are summed separately and land in the spill row stats[nslab + g + 1].
-//                css_bn_reduce_finalize_slabs (bn.hip) adds slabs and spill rows per group in fp64.
+//                batched along M, stat_Mg rows each) need not be slab-aligned: a slab's row holds only the rows of the group
+//                its FIRST row belongs to; the (< 128) rows past a group boundary are summed from the stored tensor by
+//                css_bn_reduce_finalize_slabs (bn.hip), which adds everything per group in fp64.
 // sstat: LDS area of this wave's (slab, wave column) pair: an arrival counter (zeroed at kernel start) and one slot
 // [2 parts][2 stats][WTN] per wave row (part 1 = rows of the next group).  wml: which of the slab's two wave rows this is.
 // --------------------------------------------------------------------------
@@ -214,15 +214,12 @@ __device__ __forceinline__ void store_wave_tile(const ConvArgs& a, const T* Cw, 
       if (second && (mrow0 & ~127) < a.M) {
         const float* other = mine + (wml ? 0 : 4 * WTN);
         const int row0 = mrow0 & ~127;
-        const int g0 = row0 / a.stat_Mg;
-        const bool spill = bnd < row0 + 128 && bnd < a.M;
         for (int i = lane; i < 4 * WTN; i += 64) {
           const int col = i % WTN, stat = (i / WTN) & 1, part = i / (2 * WTN);
           const int nn = n0w + col;
           if (nn >= a.Cd) continue;
-          const float v = slot[i] + other[i];
-          if (part == 0) a.stats[((size_t)(row0 >> 7) * 2 + stat) * a.Cd + nn] = v;
-          else if (spill) a.stats[((size_t)(a.stat_nslab + g0 + 1) * 2 + stat) * a.Cd + nn] = v;
+          // part 0 only: the rows of a slab past a statistics-group boundary are summed from the stored tensor by stage 2
+          if (part == 0) a.stats[((size_t)(row0 >> 7) * 2 + stat) * a.Cd + nn] = slot[i] + other[i];
         }
       }
     }
@@ -1329,6 +1326,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
   if (a.stats && (dtype != CSS_BF16 || a.stat_Mg < 128 || a.addend)) return CSS_ERR_ARG;   // slab statistics: bf16 forward only
   a.stat_nslab = cdiv(a.M, 128);
+  a.stat_G = a.stats ? a.M / a.stat_Mg : 0;
   {
     const size_t esz = dtype == CSS_BF16 ? 2 : 4;
     const size_t sb = (size_t)a.N * a.Hs * a.Ws * a.lds * esz, wb = (size_t)a.Cd * a.Ktot * esz;
@@ -1350,7 +1348,14 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
         P0(true, (double)(b.M - b.m_begin) / a.M);
-        hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+        if (css_conv_pp_supported(b) && (size_t)b.M * b.ldd * 2 < 0x7FFFFFF0ull) {
+          // second-generation kernel (conv_pp.hip): persistent, one workgroup per CU walking full_mt * nt_n tiles
+          b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
+          const int tiles = full_mt * nt_n;
+          css_launch_conv_pp(b, tiles < n_cu ? tiles : n_cu, st);
+        } else {
+          hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+        }
         P1();
       }
       if (full_mt < mt) {

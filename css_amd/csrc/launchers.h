@@ -18,8 +18,14 @@ struct ConvArgs {
   // fused epilogue extras (all optional):
   float* stats;                   // batch-norm partial statistics [stat_nslab + G][2][Cd] (see conv.hip: store_wave_tile), or null
   int stat_Mg, stat_nslab;        // rows per statistics group; ceil(total M / 128), filled by the launcher
+  int stat_G;                     // number of statistics groups (total M / stat_Mg), filled by the launcher
   const void* addend;             // [M][ld_add] tensor added to the result before it is stored (residual gradient), or null
   int ld_add;
+  // conv_igemm_pp_kernel (conv_pp.hip), filled by the launcher:
+  unsigned dst_bytes;             // bytes of dst the launch may write (buffer descriptor: rows >= M are dropped by the range check)
+  FastDiv fd_hw, fd_w;            // division by Hd*Wd and Wd
+  unsigned stat_bytes, add_bytes; // sizes of the stats / addend buffers (buffer descriptors)
+  int korder;                     // order of the K steps (conv_pp.hip: issue())
 };
 
 struct WgradArgs {
@@ -44,6 +50,8 @@ struct LaunchProf {
 };
 int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
+bool css_conv_pp_supported(const ConvArgs& a);
+void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st);
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
 
 int css_bn_nrb_(int Mg, int G, int C, int dtype);
@@ -55,7 +63,7 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
                                   float* shift, int C, hipStream_t st);
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                               float* shift, double* sums_out, int C, hipStream_t st);
+                               float* shift, double* sums_out, int C, const void* y, int ldy, hipStream_t st);
 int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                            float* shift, int C, hipStream_t st);

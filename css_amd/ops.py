@@ -193,7 +193,7 @@ class _Conv2d(torch.autograd.Function):
                 and cout % 8 == 0):
             # batch-norm statistics of the output from the convolution's own epilogue (no bn_stats pass)
             mg = m // stat_groups
-            stats = torch.empty(((m + 127) // 128 + stat_groups, 2, cout), dtype=torch.float32, device=x.device)
+            stats = torch.empty(((m + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
             call("css_conv2d_forward_bnstats", x, wf, y, stats, mg, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
                  flops, dtype_code(dt), dev, st)
             _conv_stats_out = (stats, mg, stat_groups, cout)
@@ -330,14 +330,14 @@ class _BNAct(torch.autograd.Function):
             if sync and collectives_on():
                 stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)     # [G][2][C] sums + [G] local row counts
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
-                     None, stats, c, dev, st)
+                     None, stats, c, y, c, dev, st)
                 dist.all_reduce(stats)          # SyncBN: (sum, sum of squares, count) of every rank - counts may differ per rank
                 count_t = stats[g * 2 * c:]
                 call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
-                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, dev, st)
+                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, dev, st)
         elif training:
             nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
             partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)

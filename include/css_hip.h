@@ -49,7 +49,8 @@ CSS_API int css_conv2d_forward(const void* x, const void* w, const float* bias, 
 /* css_conv2d_forward (bias-free, bf16) that also emits the batch-norm statistics of its output, saving bn_stats' pass over
  * the tensor (every convolution of the reference's backbone/ASPP/decoder is followed by BatchNorm: resnet.py:119-137,
  * aspp.py:21-62, deeplabv3.py:115-133).  The output holds G = M/Mg statistics groups of Mg >= 128 rows.
- * stats: fp32 [ceil(M/128) + G][2][Cout], consumed by css_bn_reduce_finalize_slabs. */
+ * stats: fp32 [ceil(M/128)][2][Cout], one row per 128-row slab holding the sums of the slab's rows that lie in the statistics group
+ * of its first row; consumed by css_bn_reduce_finalize_slabs (which sums the < 128 rows past each group boundary from y itself). */
 CSS_API int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho,
                                        int Wo, int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                        int device, css_stream_t stream);
@@ -96,12 +97,14 @@ CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* 
 CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                    float* shift, int C, int device, css_stream_t stream);
-/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [ceil(M/128) + G][2][C] -> per-group sums (fp64).  sums_out == NULL:
+/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [ceil(M/128)][2][C] + the bf16 tensor y [M][ldy] the statistics are of
+ * -> per-group sums (fp64).  sums_out == NULL:
  * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] + [G] local counts (SyncBN all-reduces them, then
  * css_bn_finalize) */
 CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                         float* scale, float* shift, double* sums_out, int C, int device, css_stream_t stream);
+                                         float* scale, float* shift, double* sums_out, int C, const void* y, int ldy, int device,
+                                         css_stream_t stream);
 CSS_API int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                             float* shift, int C, int device, css_stream_t stream);

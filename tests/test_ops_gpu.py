@@ -295,7 +295,7 @@ def test_conv_epilogue_bn_statistics(case):
     sums = torch.empty(groups * 2 * cout + groups, dtype=torch.float64, device=dev())   # [G][2][C] sums + [G] row counts
     d, st = dev_stream(y)
     call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
-         sums, cout, d, st)
+         sums, cout, y, cout, d, st)
     want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1).reshape(-1)
     assert rel_err(sums.cpu()[:groups * 2 * cout], want) < 1e-6
     assert sums.cpu()[groups * 2 * cout:].tolist() == [float(mg)] * groups        # this rank's rows per group ride behind the sums
