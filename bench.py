@@ -193,7 +193,7 @@ def timed_run(tr, batch, steps, warmup, world, dev, profile=True):
 
 
 def pmc_traffic(workload):
-    """HBM bytes per conv_igemm_dma256_kernel launch, REPLAYED from the committed rocprofv3 PMC passes of this workload (separate
+    """HBM bytes per launch of the dominant convolution kernels, REPLAYED from the committed rocprofv3 PMC passes of this workload (separate
     FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md) -
     PMC counters cannot be collected from inside the run that prints the line.  (None, None) when no pass exists for the workload."""
     import csv
@@ -205,7 +205,7 @@ def pmc_traffic(workload):
         return None, None
     rd = wr = n = 0.0
     for r in csv.DictReader(open(files[-1])):
-        if "conv_igemm_dma256" in r["kernel"]:
+        if "conv_igemm_dma256" in r["kernel"] or "conv_igemm_pp" in r["kernel"]:
             k = float(r["launches"])
             rd += float(r["read_MB_per_launch_corrected_x2"]) * k
             wr += float(r["write_MB_per_launch"]) * k
@@ -222,11 +222,12 @@ def rooflines(prof, dtype, workload):
     ig_ms, ig_n, ig_fl = tot("igemm256_fwd", "igemm256_dgrad")
     ach = ig_fl / (ig_ms * 1e-3) if ig_ms > 0 else 0.0
     traffic, src = pmc_traffic(workload)
-    roof = {"bound": "mfma", "kernel": "conv_igemm_dma256_kernel (forward + dgrad launches of the last timed step)",
+    roof = {"bound": "mfma", "kernel": "conv_igemm_pp64_kernel / conv_igemm_pp_kernel: the 256x256-tile implicit-GEMM convolution, forward + dgrad "
+                                       "launches of the last timed step (every launch of these kernels, HBM-bound short-K 1x1 shapes included)",
             "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src, "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
             "alg_flops_per_launch": ig_fl / max(ig_n, 1)}
-    mfma_groups = {"conv_igemm_dma256_kernel": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_dma256_kernel": prof["wgrad256"],
+    mfma_groups = {"conv_igemm_pp_kernels": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_dma256_kernel": prof["wgrad256"],
                    "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
                    "conv_wgrad_all_kernels": tot("conv_wgrad_other", "wgrad256")}
     hbm_groups = {k: prof[k] for k in ("bn_apply", "bn_bwd_apply", "bn_bwd_reduce", "sgd_ema", "conv1x1_short_k_fwd", "contrast_gather", "similarity")}

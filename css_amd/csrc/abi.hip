@@ -145,6 +145,18 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   cp.hbm_bytes = short_k_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
+int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
+                                         int ldy, int R, int Sk, int stride, int pad, int dil, int dtype, int device) {
+  ConvArgs a = {};
+  a.src = x; a.wt = w; a.dst = y; a.bias = nullptr;
+  a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.lds = ldx;
+  a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldd = ldy;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 0;
+  a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
+  alignas(16) static float dummy[4];
+  a.stats = dummy; a.stat_Mg = a.M;                  // (only the fact that statistics are requested matters to the plan)
+  return css_conv_tile_rows_(a, dtype, cu_count(device));
+}
 int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
   set_dev(device);
@@ -171,10 +183,15 @@ int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* 
   ConvProf cp(1, 6, alg_flops, S(stream));
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
-int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy, int R,
-                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+size_t css_conv2d_wgrad_ws_bytes(int M, int Ktot, int Cout, int dtype, int device) {
+  return css_wgrad_ws_bytes_(M, Ktot, Cout, dtype, cu_count(device));
+}
+int css_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
+                     int Cout, int lddy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device,
+                     css_stream_t stream) {
   set_dev(device);
   WgradArgs a;
+  a.ws = ws; a.ws_bytes = ws ? ws_bytes : 0;
   a.x = x; a.dy = dy; a.dw = dw;
   a.N = N; a.Hs = H; a.Ws = W; a.Cs = Cin; a.ldx = ldx;
   a.Hd = Ho; a.Wd = Wo; a.Cd = Cout; a.ldy = lddy;
@@ -219,10 +236,10 @@ int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, 
 }
 int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                                 float* shift, double* sums_out, int C, const void* y, int ldy, int device, css_stream_t stream) {
+                                 float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_bn_reduce_slabs(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
-                                    sums_out, C, y, ldy, S(stream));
+                                    sums_out, C, y, ldy, tile_rows, S(stream));
 }
 int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device,

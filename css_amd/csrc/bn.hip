@@ -180,23 +180,30 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
 }
 
 // Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile, conv_pp.hip): partial is fp32
-// [nslab][2][C], one row per 128-row slab of the [G*Mg][C] tensor y, holding the sums of those rows of the slab that belong to the
-// statistics group of the slab's FIRST row.  Group g = slabs ceil(g*Mg/128) .. ceil((g+1)*Mg/128)-1 plus - when g*Mg is not a
-// multiple of 128 - the rows g*Mg .. (next multiple of 128) of y itself (< 128 rows, summed here from the bf16 tensor: the head
-// of the group sits in a slab that started in the previous group).
+// [nslab][2][C], two rows ("slabs") per convolution tile of BM rows of the [G*Mg][C] tensor y: slab p covers rows
+// (p >> 1) * BM + (p & 1) * (BM - 128) ... of the tile's first (BM - 128 rows) or second (128 rows) pixel half and holds the sums of
+// those of its rows that belong to the statistics group of its FIRST row.  BM = 256 (128-row slabs, every kernel of conv.hip) or
+// 272 (conv_pp.hip's 272-row tiling).  Group g = the slabs that START inside it plus - when g*Mg is not a slab start - the rows
+// g*Mg .. (next slab start) of y itself (< 144 rows, summed here from the bf16 tensor: the head of the group sits in a slab that
+// started in the previous group).
 // sums_out != null: write [G][2][C] sums (+ [G] row counts) only (SyncBN: all-reduced before bn_finalize); else finalize in place.
+__device__ __forceinline__ long slab_start(long p, int BM) { return (p >> 1) * BM + (p & 1) * (BM - 128); }
+__device__ __forceinline__ long first_slab_from(long row, int BM) {       // first slab whose start is >= row
+  const long t = row / BM, rem = row - t * BM;
+  return 2 * t + (rem == 0 ? 0 : (rem <= BM - 128 ? 1 : 2));
+}
 __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
                                                                const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                float* running_mean, float* running_var, float momentum, float eps,
                                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
-                                                               double* sums_out, int C, const bf16_t* __restrict__ y, int ldy) {
+                                                               double* sums_out, int C, const bf16_t* __restrict__ y, int ldy, int BM) {
   if (sums_out && blockIdx.x == 0 && threadIdx.x < G) sums_out[(size_t)G * 2 * C + threadIdx.x] = (double)Mg;   // local count, see bn_reduce_kernel
   stage2_reduce(
       partial, C, G,
       [&](int g, int& lo, int& hi, int& extra) {
         const long b = (long)g * Mg, e = b + Mg;
-        lo = (int)((b + 127) >> 7);
-        hi = (int)((e + 127) >> 7);
+        lo = (int)first_slab_from(b, BM);
+        hi = (int)first_slab_from(e, BM);
         if (hi > nslab) hi = nslab;
         extra = -1;
       },
@@ -211,8 +218,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
       },
       [&](int g, int c, int pl, int P, double& t0, double& t1) {
         const long b = (long)g * Mg;
-        if (!(b & 127)) return;
-        long e = (b + 127) & ~127L;
+        long e = slab_start(first_slab_from(b, BM), BM);     // == b when the group starts on a slab boundary
         if (e > b + Mg) e = b + Mg;
         for (long r = b + pl; r < e; r += P) {
           const float v = (float)y[(size_t)r * ldy + c];
@@ -466,10 +472,10 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
 }
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                               float* shift, double* sums_out, int C, const void* y, int ldy, hipStream_t st) {
-  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C) return CSS_ERR_ARG;
-  hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, cdiv(M, 128), Mg, G, count, gamma, beta,
-                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy);
+                               float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, hipStream_t st) {
+  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C || (tile_rows != 256 && tile_rows != 272)) return CSS_ERR_ARG;
+  hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, 2 * cdiv(M, tile_rows), Mg, G, count, gamma, beta,
+                     running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy, tile_rows);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

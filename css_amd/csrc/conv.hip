@@ -1282,6 +1282,24 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must have landed before the workgroup's LDS is released
   // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
   const int l31 = lane & 31, lh = lane >> 5;
+  if (a.ws) {
+    // partial tile of this pixel slice -> its own 256 x 256 fp32 slab of the workspace with PLAIN stores (wgrad_slab_reduce_kernel
+    // adds the slices up in a fixed order): fp32 atomics run at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) - 504 workgroups x
+    // 256 KiB took longer than the MFMAs of a layer-3 weight gradient - plain stores of the same shape at ~6 TB/s
+    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int kl = wk * WTK + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[nl * 256 + kl] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -1294,6 +1312,37 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
         if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
       }
     }
+}
+
+// dw[n][k] += sum over the pixel slices of ws[tile][slice][n - n0][k - k0] (fixed order: the weight gradient is bit-reproducible).
+// grid = (64, tiles): block (bx, t) owns rows 4 bx .. 4 bx + 3 of tile t; thread = 4 consecutive k columns.
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
+                                                                int Cd, int Ktot) {
+  const int t = blockIdx.y;
+  const int k0 = (t % tiles_k) * 256, n0 = (t / tiles_k) * 256;
+  const int nl = blockIdx.x * 4 + (threadIdx.x >> 6), kl = (threadIdx.x & 63) * 4;
+  const int n = n0 + nl, k = k0 + kl;
+  if (n >= Cd || k >= Ktot) return;
+  const float4* p = reinterpret_cast<const float4*>(ws + (size_t)t * splits * (256 * 256) + nl * 256 + kl);
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  int z = 0;
+  for (; z + 3 < splits; z += 4) {        // four slabs in flight
+    const float4 v0 = p[(size_t)(z + 0) * (256 * 256 / 4)], v1 = p[(size_t)(z + 1) * (256 * 256 / 4)];
+    const float4 v2 = p[(size_t)(z + 2) * (256 * 256 / 4)], v3 = p[(size_t)(z + 3) * (256 * 256 / 4)];
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+    s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+    s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+  }
+  for (; z < splits; ++z) {
+    const float4 v0 = p[(size_t)z * (256 * 256 / 4)];
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+  }
+  const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+  float* o = dw + (size_t)n * Ktot + k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (k + e < Ktot) o[e] += r[e];
 }
 
 // --------------------------------------------------------------------------
@@ -1318,6 +1367,13 @@ static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
   }
 }
 
+// rows per statistics slab pair of a forward launch (see css_conv2d_forward_bnstats): 272 when the 272-row persistent tiling is used
+int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) {
+  static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
+  if (dtype == CSS_BF16 && a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) return 272;
+  return 256;
+}
+
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   auto P0 = [&](bool big, double share) { if (prof) prof->begin(big, share); };
   auto P1 = [&]() { if (prof) prof->end(); };
@@ -1338,7 +1394,15 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
-    if (a.Cd >= 256 && !no_dma && !no_256) {
+    if (a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) {
+      // 272-row tiles of the persistent kernel cover every row in whole rounds of the chip: one launch
+      ConvArgs b = a;
+      b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
+      const int tiles = cdiv(a.M, 272) * cdiv(a.Cd, 256);
+      P0(true, 1.0);
+      css_launch_conv_pp(b, 272, tiles < n_cu ? tiles : n_cu, st);
+      P1();
+    } else if (a.Cd >= 256 && !no_dma && !no_256) {
       // 256x256 tiles: whole rounds of the chip on the big kernel, leftover rows on the 128x128 kernel
       const int nt_n = cdiv(a.Cd, 256), mt = cdiv(a.M, 256);
       int full_mt = mt;
@@ -1348,11 +1412,12 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
         P0(true, (double)(b.M - b.m_begin) / a.M);
-        if (css_conv_pp_supported(b) && (size_t)b.M * b.ldd * 2 < 0x7FFFFFF0ull) {
+        if (css_conv_pp_plan(b, n_cu) != 0) {
           // second-generation kernel (conv_pp.hip): persistent, one workgroup per CU walking full_mt * nt_n tiles
           b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
           const int tiles = full_mt * nt_n;
-          css_launch_conv_pp(b, tiles < n_cu ? tiles : n_cu, st);
+          if (css_conv_pp64_supported(b)) css_launch_conv_pp64(b, tiles < n_cu ? tiles : n_cu, st);   // 128-byte rows (conv_pp64.hip)
+          else css_launch_conv_pp(b, 256, tiles < n_cu ? tiles : n_cu, st);
         } else {
           hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
         }
@@ -1447,6 +1512,16 @@ void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_o
   *mps_out = mps;
 }
 
+// bytes of workspace that let css_launch_wgrad replace its fp32 atomics by plain partial-tile stores + an ordered reduction (0: the
+// shape takes a kernel that has no such path)
+size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
+  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr, no_ws = getenv("CSS_WGRAD_ATOMICS") != nullptr;
+  if (!(dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256) || no_ws || M <= 0) return 0;
+  int splits, mps;
+  css_wgrad_plan_(M, Ktot, Cd, dtype, n_cu, &splits, &mps);
+  return (size_t)cdiv(Ktot, 256) * cdiv(Cd, 256) * splits * (256 * 256 * sizeof(float));
+}
+
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   if (a.M <= 0) return CSS_OK;
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
@@ -1479,9 +1554,12 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.tiles_n = cdiv(a.Cd, bn);
   dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
   if (prof) prof->begin(big, 1.0);
-  if (big)
+  if (!big || (size_t)a.tiles_k * a.tiles_n * a.splits * (256 * 256 * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path
+  if (big) {
     hipLaunchKernelGGL(conv_wgrad_dma256_kernel, g, dim3(512), 0, st, a);
-  else if (dtype == CSS_BF16)
+    if (a.ws)
+      hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
+  } else if (dtype == CSS_BF16)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
   else
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);

@@ -22,6 +22,7 @@
 #include "common.h"
 #include "launchers.h"
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 typedef __attribute__((address_space(3))) void pp_lds_void;
@@ -60,19 +61,25 @@ __device__ __forceinline__ float pp_lo(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float pp_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
-// NST: LDS stages of 32 KiB (4 or 5 = all 160 KiB of the CU; NST-1 K steps in flight).  STATS: batch-norm statistics of the output
-// (forward).  ADD: + a.addend before the store (data gradient with a residual branch).
-template <int NST, bool STATS, bool ADD>
+// TI0: 16-pixel tiles of the FIRST pixel half (8 or 9; the second half always has 8): tile height BM = 256 or 272 rows.  The
+// launcher picks the height that fills whole rounds of the chip (135200 rows = 32 images of 65x65: 498 tiles of 272 rows = two
+// rounds of 256 CUs; 529 tiles of 256 rows would leave 17 tiles for a third round or a latency-bound leftover launch - r01: 9.7 ms
+// per step).  NST: LDS stages (5 x 32 KiB = all 160 KiB of the CU at BM = 256, 4 x 33 KiB at 272; NST-1 K steps in flight).
+// STATS: batch-norm statistics of the output (forward).  ADD: + a.addend before the store (data gradient with a residual branch).
+template <int TI0, bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
-  constexpr int BM = 256, BN = 256, BK = 32;
-  constexpr int A_BYTES = BM * 64, ST_BYTES = 2 * A_BYTES;      // 64-byte LDS rows (32 bf16), 16 KiB per operand tile
-  constexpr int WAIT_STEADY = 4 * (NST - 2);                    // DMA instructions that may stay in flight behind the stage needed next
+  constexpr int S0 = 16 * TI0, BM = S0 + 128, BN = 256, BK = 32, NST = TI0 == 8 ? 5 : 4;
+  constexpr int A_BYTES = BM * 64, ST_BYTES = A_BYTES + BN * 64;   // 64-byte LDS rows (32 bf16)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;                       // pixel half (= ping-pong group), channel quarter
   const int l15 = lane & 15, lg = lane >> 4;
+  // LDS-DMA instructions of this wave per K step: 2 + 2 (16 rows of each operand tile per instruction); at BM = 272 the 17th
+  // 16-row piece of the pixel tile goes round the waves, one K step each (a fixed owner would have 25 % more to issue in every
+  // LOAD segment, and the slowest wave sets the pace: measured -15 %).  The counted waits below assume 4 per step: with the odd
+  // fifth among the youngest they wait for one more instruction than necessary, never for one less.
 
   // ---- tile schedule: this workgroup's position inside a round of gridDim.x tiles; XCD x owns a contiguous run of logical tiles
   const int G = gridDim.x, q8 = G >> 3, r8 = G & 7;
@@ -121,11 +128,12 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   };
 
   // ---- issue side (LDS-DMA producer state, NST-1 K steps ahead of the MFMAs) --------------------------------------------------
-  // thread -> rows wm*128 + wn*32 + 16 i + (lane >> 2) of BOTH operand tiles (i = 0, 1), 16-byte position lane & 3 of the row;
+  // thread -> rows wave*32 + 16 i + (lane >> 2) of BOTH operand tiles (i = 0, 1; wave 0 also row 256 + (lane >> 2) of a 272-row
+  // pixel tile), 16-byte position lane & 3 of the row;
   // the chunk stored at position p of row r is source chunk p ^ f((r >> 2) & 3), f = {2,0,1,3}: with 64-byte rows the 16 lanes of
   // every ds_read_b128 group of the 16x16x32 operand reads (rows r..r+15 at chunks c, c, c+1, c+1 per quad) then hit 16 distinct
   // 16-byte slots of the 256-byte bank row
-  const int prow = wm * 128 + wn * 32 + (lane >> 2);
+  const int prow = wave * 32 + (lane >> 2);       // (which wave loads a row is independent of which half consumes it)
   const int cch = (lane & 3) ^ ((0xD2 >> (2 * ((lane >> 4) & 3))) & 3);
   int it_ti = 0, it_cs = 0, it_tr = 0, it_ts = 0;
   Tile itile = {0, 0, 0, 0};
@@ -135,23 +143,25 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   //   boff  : byte offset of my weight rows (+ my chunk), or OOB
   // "cur" feeds the DMAs; "nxt" is the tile after it, prepared by the consumer side at the end of an epilogue (when the 128
   // accumulator registers are free) so that the LOAD segments never pay for a tile change
-  int rowoff[2], nrowoff[2];
-  unsigned rmask[2], nrmask[2];
+  constexpr int AR = TI0 == 9 ? 3 : 2;    // A rows per thread (the third: row 256 + (lane >> 2) of a 272-row tile, every 8th K step)
+  int rowoff[AR], nrowoff[AR];
+  unsigned rmask[AR], nrmask[AR];
   unsigned boff[2], nboff[2];
   bool it_live = false, it_need = true;
-  auto lane_setup = [&](int ti, int (&ro)[2], unsigned (&rm)[2], unsigned (&bo)[2]) {
+  int it_step = 0;        // K steps issued so far (all tiles)
+  auto lane_setup = [&](int ti, int (&ro)[AR], unsigned (&rm)[AR], unsigned (&bo)[2]) {
     if (ti >= nmy) {
-      rm[0] = rm[1] = 0;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) { rm[i] = 0; ro[i] = 0; }
       bo[0] = bo[1] = PP_OOB;
-      ro[0] = ro[1] = 0;
       return;
     }
     const int lt = ti * G + pos;
     const int mt = nt_n == 1 ? lt : lt / nt_n;
     const int m0 = a.m_begin + mt * BM, n0 = (lt - mt * nt_n) * BN;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int m = m0 + prow + 16 * i;
+    for (int i = 0; i < AR; ++i) {
+      const int m = i < 2 ? m0 + prow + 16 * i : m0 + 256 + (lane >> 2);
       unsigned msk = 0;
       int off = 0;
       if (m < a.M) {
@@ -186,15 +196,19 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       }
       ro[i] = off;
       rm[i] = msk;
-      const int n = n0 + prow + 16 * i;
-      bo[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)cch * 16u : PP_OOB;
+      if (i < 2) {
+        const int n = n0 + prow + 16 * i;
+        bo[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)cch * 16u : PP_OOB;
+      }
     }
   };
   // the issue side moves on to tile it_ti: take over the prepared lane state, reset the K position
   auto issue_tile_switch = [&]() {
     it_live = it_ti < nmy;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { rowoff[i] = nrowoff[i]; rmask[i] = nrmask[i]; boff[i] = nboff[i]; }
+    for (int i = 0; i < AR; ++i) { rowoff[i] = nrowoff[i]; rmask[i] = nrmask[i]; }
+    boff[0] = nboff[0];
+    boff[1] = nboff[1];
     if (!it_live) return;
     itile = tile_info(it_ti);
     it_cs = 0;
@@ -219,7 +233,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       it_need = false;
       issue_tile_switch();
     }
-    unsigned char* sa = smem + stage * ST_BYTES + (wm * 128 + wn * 32) * 64;
+    unsigned char* sa = smem + stage * ST_BYTES + wave * (32 * 64);
     const int tap = it_tr * a.S + it_ts;
     const bool cok = it_cs * BK + cch * 8 < a.Cs;                                  // ragged last channel slice
     const int da = (it_tr * a.Ws + it_ts) * tapstep + it_cs * (BK * 2);
@@ -229,6 +243,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       const bool ok = cok && ((rmask[i] >> tap) & 1);
       pp_dma16(rs_a, sa + i * 1024, ok ? (unsigned)(rowoff[i] + da) : PP_OOB);
     }
+    if (TI0 == 9 && (it_step & 7) == wave) {
+      const bool ok = cok && ((rmask[AR - 1] >> tap) & 1);
+      pp_dma16(rs_a, smem + stage * ST_BYTES + 256 * 64, ok ? (unsigned)(rowoff[AR - 1] + da) : PP_OOB);
+    }
+    ++it_step;
 #pragma unroll
     for (int i = 0; i < 2; ++i) pp_dma16(rs_b, sa + A_BYTES + i * 1024, (cok && boff[i] != PP_OOB) ? boff[i] + kb : PP_OOB);
     if (!it_live) return;
@@ -260,9 +279,10 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   };
 
   // ---- consumer state ---------------------------------------------------------------------------------------------------
-  f32x4 acc[8][4];        // [pixel tile i: pixels 16 i + (lane & 15)][channel tile j: channels 16 j + 4 (lane >> 4) + reg]
+  f32x4 acc[TI0][4];      // [pixel tile i: pixels 16 i + (lane & 15) of my half][channel tile j: channels 16 j + 4 (lane >> 4) + reg]
+  const int ti_n = wm ? 8 : TI0;                       // pixel tiles of my half
   const int koff = ((lg ^ ((0xD2 >> (2 * ((lane >> 2) & 3))) & 3)) << 4);
-  const int a_addr = (wm * 128 + l15) * 64 + koff, b_addr = A_BYTES + (wn * 64 + l15) * 64 + koff;
+  const int a_addr = (wm * S0 + l15) * 64 + koff, b_addr = A_BYTES + (wn * 64 + l15) * 64 + koff;
 
   lane_setup(0, nrowoff, nrmask, nboff);
   issue_tile_switch();                                 // tile 0 becomes current
@@ -270,7 +290,17 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   lane_setup(1, nrowoff, nrmask, nboff);
 #pragma unroll 1
   for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY) : "memory");
+  // all but the youngest NST-2 K steps of my LDS-DMAs (4 or 5 instructions each) have landed
+  auto wait_dma = [&](bool stores_behind) {
+    if (!stores_behind) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2)) : "memory");
+    } else {
+      // + the previous tile's stores, issued behind the DMAs of the first NST-2 K steps of this tile: at least 16 per wave, + 8
+      // statistics stores
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NST - 2) + (STATS ? 24 : 16)) : "memory");
+    }
+  };
+  wait_dma(false);
   __builtin_amdgcn_s_barrier();                        // every wave's share of K step 0 has landed
   if (wm == 1) __builtin_amdgcn_s_barrier();           // half a K step behind: LOAD of one half runs beside MFMA of the other
   asm volatile("" ::: "memory");
@@ -282,33 +312,30 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     for (int kt = 0; kt < ct.nk; ++kt) {
       // ---------------- LOAD segment ----------------
       const unsigned char* sb = smem + st_c * ST_BYTES;
-      bf16x8 fa[8], fw[4];
+      bf16x8 fa[TI0], fw[4];
 #ifdef PP_ABL_NOCOMPUTE       // ablation: LDS-DMA stream only (no fragment reads, one MFMA per step keeps the accumulators alive)
 #pragma unroll
       for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(smem + b_addr + j * 1024);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) fa[i] = fw[i & 3];
+      for (int i = 0; i < TI0; ++i) fa[i] = fw[i & 3];
       if (kt > 1000000) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sb + a_addr + i * 1024);
+        for (int i = 0; i < TI0; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sb + a_addr + i * 1024);
       }
 #else
 #pragma unroll
       for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sb + b_addr + j * 1024);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sb + a_addr + i * 1024);
+      if (TI0 == 9 && wm == 0) fa[TI0 - 1] = *reinterpret_cast<const bf16x8*>(sb + a_addr + 8 * 1024);
 #endif
       issue(st_i);                                     // K step + NST-1 (past the last tile: all-OOB = zeros into a free stage)
       st_c = st_c == NST - 1 ? 0 : st_c + 1;
       st_i = st_i == NST - 1 ? 0 : st_i + 1;
       // my share of the NEXT K step has landed.  The previous tile's stores (16 per wave, + 8 statistics stores) were issued
       // behind the DMAs of the first NST-2 K steps of this tile: while one of those is the step waited for they may stay in flight
-      if (st_pending == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY) : "memory");
-      else {
-        if (STATS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY + 24) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WAIT_STEADY + 16) : "memory");
-        --st_pending;
-      }
+      wait_dma(st_pending > 0);
+      if (st_pending > 0) --st_pending;
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // my fragment reads are done: the stage may be refilled after the barrier
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
@@ -320,7 +347,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       if (kt == 0) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < TI0; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = z;
       }
@@ -332,11 +359,19 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], z, 0, 0, 0);
+        if (TI0 == 9 && wm == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[TI0 - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[TI0 - 1], z, 0, 0, 0);
+        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+        if (TI0 == 9 && wm == 0) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[TI0 - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[TI0 - 1], acc[TI0 - 1][j], 0, 0, 0);
+        }
       }
 #endif
       __builtin_amdgcn_s_setprio(0);
@@ -347,28 +382,29 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     }
 
     // ---------------- epilogue of tile ti (no LDS, no barrier, no load but the optional addend) ----------------
-    const int mrow0 = ct.m0 + wm * 128, n0w = ct.n0 + wn * 64;
-    // a slab's row of a.stats holds the sums of the rows that belong to the statistics group of the slab's FIRST row; rows of a
-    // slab past a group boundary (< 128 per boundary) are summed from the stored tensor by stage 2 (bn_reduce_slabs_kernel)
+    const int mrow0 = ct.m0 + wm * S0, n0w = ct.n0 + wn * 64;
+    // a wave's rows (128 or 16 TI0 of them) are one "slab" of a.stats: its row holds the sums of the rows that belong to the
+    // statistics group of the slab's FIRST row; rows of a slab past a group boundary (< 144 per boundary) are summed from the
+    // stored tensor by stage 2 (bn_reduce_slabs_kernel)
     const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;
     // lane -> 8 consecutive channels of one pixel after the swaps below:
     //   lane group g = 0: tile j ch 0-7 | g = 1: tile j+1 ch 0-7 | g = 2: tile j ch 8-15 | g = 3: tile j+1 ch 8-15   (j = 0, 2)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
-    pp_u32x4 radd[ADD ? 8 : 1][2];
+    pp_u32x4 radd[ADD ? TI0 : 1][2];
     if (ADD) {
       // all 16 addend vectors of the wave tile are requested before the first one is used: ONE drain of the vector-memory queue per
       // tile (the compiler waits for an ordinary load with everything older, i.e. with the LDS-DMA of the next tile's first K steps)
       const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
+      for (int i = 0; i < TI0; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mrow0 + 16 * i + l15, n = nl + 32 * h;
-          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a.M && n < a.Cd) ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)n) * 2u : PP_OOB), 0, 0);
+          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((i < ti_n && m < a.M && n < a.Cd) ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)n) * 2u : PP_OOB), 0, 0);
         }
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    auto store_pixel_tile = [&](auto ic) {
+      constexpr int i = decltype(ic)::value;           // (static accumulator indices: a run-time index sends acc to scratch memory)
       const int m = mrow0 + 16 * i + l15;
       unsigned lo[4], hi[4];
 #pragma unroll
@@ -386,31 +422,42 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         const bool ok = m < a.M && n < a.Cd;
         if (ADD) {
           // dgrad: + the residual branch's gradient (bf16 + bf16 in fp32, rounded once: what autograd's add would give)
-          const pp_u32x4 r = radd[i][jp >> 1];
+          const pp_u32x4 r = radd[ADD ? i : 0][jp >> 1];
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = pp_pack2(pp_lo(v[e]) + pp_lo(r[e]), pp_hi(v[e]) + pp_hi(r[e]));
         }
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(ok ? rowb + (unsigned)n * 2u : PP_OOB), 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);              // one pixel tile at a time: short live ranges next to the 128 accumulators
-    }
+    };
+    store_pixel_tile(std::integral_constant<int, 0>());
+    store_pixel_tile(std::integral_constant<int, 1>());
+    store_pixel_tile(std::integral_constant<int, 2>());
+    store_pixel_tile(std::integral_constant<int, 3>());
+    store_pixel_tile(std::integral_constant<int, 4>());
+    store_pixel_tile(std::integral_constant<int, 5>());
+    store_pixel_tile(std::integral_constant<int, 6>());
+    store_pixel_tile(std::integral_constant<int, 7>());
+    if (TI0 == 9 && wm == 0) store_pixel_tile(std::integral_constant<int, TI0 - 1>());   // (uniform: the second half has 8 pixel tiles)
     if (STATS) {
       // Batch-norm statistics of exactly the bf16 values stored (what bn_apply reads back; rows >= M are exact zeros), one channel
       // tile at a time (8 live sums next to the 128 accumulators): per lane its 8 pixels, then the 16 pixels of a lane row by DPP;
       // lane 0 of each row stores 4 consecutive channels into the slab's row of a.stats.  Always 8 store instructions
       // (out-of-range offsets are dropped): the vmcnt arithmetic of the LOAD segments counts on them.
       const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
-      const unsigned base = (unsigned)(mrow0 >> 7) * 2u * (unsigned)a.Cd * 4u;
+      const unsigned base = (unsigned)(2 * ((ct.m0 - a.m_begin) / BM + a.m_begin / 256) + wm) * 2u * (unsigned)a.Cd * 4u;   // slab index: 2 per tile
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < TI0; ++i) {
           f32x4 t = acc[i][j];
           asm volatile("" : "+v"(t));       // opaque: otherwise the packed values of the store loop stay alive (CSE) across the epilogue
           const unsigned lo = pp_pack2(t[0], t[1]), hi = pp_pack2(t[2], t[3]);
-          const float keep = (mrow0 + 16 * i + l15 < bnd) ? 1.f : 0.f;
-          const float v0 = keep * pp_lo(lo), v1 = keep * pp_hi(lo), v2 = keep * pp_lo(hi), v3 = keep * pp_hi(hi);
+          // rows of the next statistics group are left to stage 2; the ninth tile of the second half does not exist (its registers
+          // hold garbage: select, do not multiply)
+          const bool keep = mrow0 + 16 * i + l15 < bnd && i < ti_n;
+          const float v0 = keep ? pp_lo(lo) : 0.f, v1 = keep ? pp_hi(lo) : 0.f, v2 = keep ? pp_lo(hi) : 0.f, v3 = keep ? pp_hi(hi) : 0.f;
           ss[0] += v0; ss[1] += v1; ss[2] += v2; ss[3] += v3;
           qq[0] += v0 * v0; qq[1] += v1 * v1; qq[2] += v2 * v2; qq[3] += v3 * v3;
         }
@@ -448,23 +495,38 @@ bool css_conv_pp_supported(const ConvArgs& a) {
   return true;
 }
 
-void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st) {
+// Tile height for a launch of M rows x Cd channels on n_cu compute units: 272 when 256-row tiles would leave a partial round that the
+// 272-row tiling absorbs (then this kernel covers every row: no leftover launch), else 256 (whole rounds here, leftover rows on the
+// 128-row kernels of conv.hip); 0: not a shape for this kernel.
+int css_conv_pp_plan(const ConvArgs& a, int n_cu) {
+  if (!css_conv_pp_supported(a) || (size_t)a.M * a.ldd * 2 >= 0x7FFFFFF0ull) return 0;
+  // 272-row tiling: correct (tests/test_conv_bench_scale_gpu.py runs it) but measured SLOWER than 256-row tiles + leftover launch
+  // (l3 3x3: 222 vs 210 us; the 272-row variant runs ~15 % slower per row), so it is opt-in: CSS_PP_272=1
+  const bool no272 = !(getenv("CSS_PP_272") && atoi(getenv("CSS_PP_272")) == 1);
+  const int nt_n = cdiv(a.Cd, 256);
+  const long t256 = (long)cdiv(a.M, 256) * nt_n, t272 = (long)cdiv(a.M, 272) * nt_n;
+  const double rounds = (double)t256 / n_cu;
+  const long k = (long)rounds;
+  if (!no272 && k >= 1 && rounds - k > 1e-9 && rounds - k < 0.6 && t272 <= k * n_cu) return 272;
+  return 256;
+}
+
+void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st) {
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
   a.fd_w = make_fastdiv((uint32_t)a.Wd);
-  // K order (see the kernel.s issue()): channel slice outer / tap inner for kernels with more than one tap
+  // K order (see the kernel's issue()): channel slice outer / tap inner for kernels with more than one tap
   static const int korder_env = getenv("CSS_PP_KORDER") ? atoi(getenv("CSS_PP_KORDER")) : -1;
   a.korder = korder_env >= 0 ? korder_env : (a.R * a.S > 1 ? 1 : 0);   // (measured on the harness: 1 beats 0 by 3-5 % on the 3x3 shapes, 2 loses)
-  if (a.stats) a.stat_bytes = (unsigned)((size_t)a.stat_nslab * 2 * a.Cd * 4);
+  if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, tile_rows) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
-  static const int nst = getenv("CSS_PP_NST") ? atoi(getenv("CSS_PP_NST")) : 5;
   const dim3 g(grid), b(512);
-  if (nst == 4) {
-    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<4, true, false>), g, b, 0, st, a);
-    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<4, false, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_pp_kernel<4, false, false>), g, b, 0, st, a);
+  if (tile_rows == 272) {
+    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<9, true, false>), g, b, 0, st, a);
+    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<9, false, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_pp_kernel<9, false, false>), g, b, 0, st, a);
   } else {
-    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<5, true, false>), g, b, 0, st, a);
-    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<5, false, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_pp_kernel<5, false, false>), g, b, 0, st, a);
+    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, true, false>), g, b, 0, st, a);
+    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, true>), g, b, 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, false>), g, b, 0, st, a);
   }
 }

@@ -39,6 +39,8 @@ struct WgradArgs {
   FastDiv fd_hw, fd_w;
   unsigned x_bytes, dy_bytes;   // filled by the launcher (buffer descriptors)
   int splits, tiles_k, tiles_n;
+  float* ws;         // optional workspace for per-slice partial tiles (plain stores + ordered reduction instead of fp32 atomics), or null
+  size_t ws_bytes;
 };
 
 
@@ -51,8 +53,13 @@ struct LaunchProf {
 int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 bool css_conv_pp_supported(const ConvArgs& a);
-void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st);
+int css_conv_pp_plan(const ConvArgs& a, int n_cu);
+void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st);
+int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu);
+bool css_conv_pp64_supported(const ConvArgs& a);
+void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st);
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
+size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu);
 
 int css_bn_nrb_(int Mg, int G, int C, int dtype);
 int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st);
@@ -63,7 +70,7 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
                                   float* shift, int C, hipStream_t st);
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                               float* shift, double* sums_out, int C, const void* y, int ldy, hipStream_t st);
+                               float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, hipStream_t st);
 int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                            float* shift, int C, hipStream_t st);

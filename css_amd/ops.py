@@ -193,10 +193,13 @@ class _Conv2d(torch.autograd.Function):
                 and cout % 8 == 0):
             # batch-norm statistics of the output from the convolution's own epilogue (no bn_stats pass)
             mg = m // stat_groups
-            stats = torch.empty(((m + 127) // 128, 2, cout), dtype=torch.float32, device=x.device)
+            stats = torch.empty((2 * ((m + 255) // 256), 2, cout), dtype=torch.float32, device=x.device)
             call("css_conv2d_forward_bnstats", x, wf, y, stats, mg, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
                  flops, dtype_code(dt), dev, st)
-            _conv_stats_out = (stats, mg, stat_groups, cout)
+            # rows per convolution tile (= two statistics slabs): 256, or 272 when the launcher tiles the rows that way
+            bm = _lib.query("css_conv2d_forward_bnstats_tile_rows", x, wf, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
+                            dtype_code(dt), dev)
+            _conv_stats_out = (stats, mg, stat_groups, cout, bm)
         else:
             call("css_conv2d_forward", x, wf, bias, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
                  dtype_code(dt), dev, st)
@@ -239,13 +242,17 @@ class _Conv2d(torch.autograd.Function):
             dx = dtap
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(weight, (cout, r, s, cin)) if (cout_pad == cout and cp == cin) else None
-            if sink is not None:      # the wgrad kernel accumulates atomically: add straight into param.grad
-                call("css_conv2d_wgrad", x, dyp, sink, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
+            # workspace for the per-slice partial tiles (plain stores + ordered reduction instead of fp32 atomics); 0 bytes: the
+            # shape takes a kernel without that path
+            wsb = _lib.query("css_conv2d_wgrad_ws_bytes", n * ho * wo, r * s * cp, cout_pad, dc, dev)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
+            if sink is not None:      # the wgrad kernels ADD into dw: straight into param.grad
+                call("css_conv2d_wgrad", x, dyp, sink, ws, wsb, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
                      dc, dev, st)
                 _grad_ready(weight)
             else:
                 dwp = torch.zeros((cout_pad, r, s, cp), dtype=torch.float32, device=dy.device)
-                call("css_conv2d_wgrad", x, dyp, dwp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil,
+                call("css_conv2d_wgrad", x, dyp, dwp, ws, wsb, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil,
                      flops, dc, dev, st)
                 dw = dwp[:cout, :, :, :cin].permute(0, 3, 1, 2)
         if has_bias and ctx.needs_input_grad[2]:
@@ -324,20 +331,20 @@ class _BNAct(torch.autograd.Function):
         mean = invstd = None
         count = float(mg)
         count_t = None       # SyncBN: per-group global pixel counts on the device (all-reduced together with the sums)
-        if training and fused is not None and fused[1:] == (mg, g, c):
+        if training and fused is not None and fused[1:4] == (mg, g, c):
             # statistics came out of the producing convolution's epilogue (fp32 rows per 128-row slab)
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
             if sync and collectives_on():
                 stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)     # [G][2][C] sums + [G] local row counts
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
-                     None, stats, c, y, c, dev, st)
+                     None, stats, c, y, c, fused[4], dev, st)
                 dist.all_reduce(stats)          # SyncBN: (sum, sum of squares, count) of every rank - counts may differ per rank
                 count_t = stats[g * 2 * c:]
                 call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
-                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, dev, st)
+                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, fused[4], dev, st)
         elif training:
             nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
             partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)

@@ -49,11 +49,15 @@ CSS_API int css_conv2d_forward(const void* x, const void* w, const float* bias, 
 /* css_conv2d_forward (bias-free, bf16) that also emits the batch-norm statistics of its output, saving bn_stats' pass over
  * the tensor (every convolution of the reference's backbone/ASPP/decoder is followed by BatchNorm: resnet.py:119-137,
  * aspp.py:21-62, deeplabv3.py:115-133).  The output holds G = M/Mg statistics groups of Mg >= 128 rows.
- * stats: fp32 [ceil(M/128)][2][Cout], one row per 128-row slab holding the sums of the slab's rows that lie in the statistics group
- * of its first row; consumed by css_bn_reduce_finalize_slabs (which sums the < 128 rows past each group boundary from y itself). */
+ * stats: fp32 [2 * ceil(M/256)][2][Cout] (room for either tiling): two rows ("slabs") per convolution tile of BM rows - the tile's
+ * first BM-128 and last 128 rows - each holding the sums of the slab's rows that lie in the statistics group of its first row;
+ * BM = css_conv2d_forward_bnstats_tile_rows(same arguments) = 256 or 272 (the launcher tiles M in 272-row tiles when that fills whole
+ * rounds of the chip).  Consumed by css_bn_reduce_finalize_slabs, which sums the (< 144) rows past each group boundary from y itself. */
 CSS_API int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho,
                                        int Wo, int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                        int device, css_stream_t stream);
+CSS_API int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
+                                                 int Cout, int ldy, int R, int S, int stride, int pad, int dil, int dtype, int device);
 /* w_t: weights re-laid out as [Cin][R][S][Cout] (css_weight_layout dgrad=1); stride 1 or 2 */
 CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
@@ -62,9 +66,14 @@ CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, i
 CSS_API int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx,
                                  int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                  int device, css_stream_t stream);
-/* dw: fp32 [Cout][R][S][Cin], ACCUMULATED (atomic adds): zero it first unless accumulating on purpose */
-CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout, int lddy,
-                             int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);
+/* dw: fp32 [Cout][R][S][Cin], ACCUMULATED: zero it first unless accumulating on purpose.  The pixels are reduced in slices (one
+ * workgroup per weight tile and slice).  ws (optional, caller-owned, ws_bytes >= css_conv2d_wgrad_ws_bytes(N*Ho*Wo, R*S*Cin, Cout, ..)):
+ * the slices' partial tiles are written there with plain stores and summed into dw in a fixed order by a second kernel - faster than
+ * fp32 atomics (1.3 TB/s chip-wide on MI355X) and bit-reproducible; ws == NULL or too small: fp32 atomic adds into dw. */
+CSS_API size_t css_conv2d_wgrad_ws_bytes(int M, int Ktot, int Cout, int dtype, int device);
+CSS_API int css_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t ws_bytes, int N, int H, int W, int Cin, int ldx, int Ho,
+                             int Wo, int Cout, int lddy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device,
+                             css_stream_t stream);
 /* host-side query (no launch): the number of pixel slices css_conv2d_wgrad cuts M = N*Ho*Wo rows into on a device with n_cu compute
  * units (one accumulation pass of fp32 atomics per slice); tests use it to check that bench-size layers take the split path */
 CSS_API int css_wgrad_splits(int M, int Ktot, int Cout, int dtype, int n_cu);
@@ -97,14 +106,14 @@ CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* 
 CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                    float* shift, int C, int device, css_stream_t stream);
-/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [ceil(M/128)][2][C] + the bf16 tensor y [M][ldy] the statistics are of
- * -> per-group sums (fp64).  sums_out == NULL:
+/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [2 * ceil(M/tile_rows)][2][C] (tile_rows = 256 or 272, see there) + the bf16
+ * tensor y [M][ldy] the statistics are of -> per-group sums (fp64).  sums_out == NULL:
  * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] + [G] local counts (SyncBN all-reduces them, then
  * css_bn_finalize) */
 CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
-                                         float* scale, float* shift, double* sums_out, int C, const void* y, int ldy, int device,
-                                         css_stream_t stream);
+                                         float* scale, float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows,
+                                         int device, css_stream_t stream);
 CSS_API int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                             float* shift, int C, int device, css_stream_t stream);

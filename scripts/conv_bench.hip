@@ -1,6 +1,7 @@
 // Standalone timing harness for the conv kernels (ablations via -DCSS_ABLATE_*): hipcc -O3 --offload-arch=gfx950
 #include "../css_amd/csrc/conv.hip"
 #include "../css_amd/csrc/conv_pp.hip"
+#include "../css_amd/csrc/conv_pp64.hip"
 #include <cstdio>
 #include <vector>
 #include <cstdlib>

@@ -83,11 +83,11 @@ def test_conv_bf16_bench_shapes_vs_cpu(case):
 
     # fused statistics against an fp64 reduction of the CPU output (two groups = the two batched forward passes)
     from css_amd._lib import call, dev_stream
-    part, mg, groups, c_ = y._css_bnstats
+    part, mg, groups, c_, bm = y._css_bnstats
     sums = torch.empty(groups * 2 * cout + groups, dtype=torch.float64, device=dev())   # [G][2][C] sums + [G] row counts
     d, st = dev_stream(y)
     call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
-         sums, cout, y, cout, d, st)
+         sums, cout, y, cout, bm, d, st)
     yy = y_ref.double().reshape(groups, -1, cout)
     want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1)                   # [G][2][C]
     got = sums.cpu()[:groups * 2 * cout].reshape(groups, 2, cout)

@@ -291,11 +291,11 @@ def test_conv_epilogue_bn_statistics(case):
     from css_amd._lib import call, dev_stream
     with ops.bn_groups(groups):
         y = ops.conv2d(x, wt, None, 1, pad, dil, bn_stats=True)
-    part, mg, g_, c_ = y._css_bnstats
+    part, mg, g_, c_, bm = y._css_bnstats
     sums = torch.empty(groups * 2 * cout + groups, dtype=torch.float64, device=dev())   # [G][2][C] sums + [G] row counts
     d, st = dev_stream(y)
     call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
-         sums, cout, y, cout, d, st)
+         sums, cout, y, cout, bm, d, st)
     want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1).reshape(-1)
     assert rel_err(sums.cpu()[:groups * 2 * cout], want) < 1e-6
     assert sums.cpu()[groups * 2 * cout:].tolist() == [float(mg)] * groups        # this rank's rows per group ride behind the sums
