@@ -187,9 +187,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
 // g*Mg .. (next slab start) of y itself (< 144 rows, summed here from the bf16 tensor: the head of the group sits in a slab that
 // started in the previous group).
 // sums_out != null: write [G][2][C] sums (+ [G] row counts) only (SyncBN: all-reduced before bn_finalize); else finalize in place.
-__device__ __forceinline__ long slab_start(long p, int BM) { return (p >> 1) * BM + (p & 1) * (BM - 128); }
-__device__ __forceinline__ long first_slab_from(long row, int BM) {       // first slab whose start is >= row
-  const long t = row / BM, rem = row - t * BM;
+__device__ __forceinline__ int slab_start(int p, int BM) { return (p >> 1) * BM + (p & 1) * (BM - 128); }
+__device__ __forceinline__ int first_slab_from(int row, int BM) {         // first slab whose start is >= row (rows < 2^31)
+  const int t = BM == 256 ? row >> 8 : row / BM, rem = row - t * BM;
   return 2 * t + (rem == 0 ? 0 : (rem <= BM - 128 ? 1 : 2));
 }
 __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
@@ -201,9 +201,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
   stage2_reduce(
       partial, C, G,
       [&](int g, int& lo, int& hi, int& extra) {
-        const long b = (long)g * Mg, e = b + Mg;
-        lo = (int)first_slab_from(b, BM);
-        hi = (int)first_slab_from(e, BM);
+        const int b = g * Mg, e = b + Mg;
+        lo = first_slab_from(b, BM);
+        hi = first_slab_from(e, BM);
         if (hi > nslab) hi = nslab;
         extra = -1;
       },
@@ -217,10 +217,10 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
         }
       },
       [&](int g, int c, int pl, int P, double& t0, double& t1) {
-        const long b = (long)g * Mg;
-        long e = slab_start(first_slab_from(b, BM), BM);     // == b when the group starts on a slab boundary
+        const int b = g * Mg;
+        int e = slab_start(first_slab_from(b, BM), BM);      // == b when the group starts on a slab boundary
         if (e > b + Mg) e = b + Mg;
-        for (long r = b + pl; r < e; r += P) {
+        for (int r = b + pl; r < e; r += P) {
           const float v = (float)y[(size_t)r * ldy + c];
           t0 += (double)v;
           t1 += (double)v * (double)v;

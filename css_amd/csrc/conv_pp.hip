@@ -302,7 +302,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   };
   wait_dma(false);
   __builtin_amdgcn_s_barrier();                        // every wave's share of K step 0 has landed
+#ifndef PP_ABL_NOSTAGGER      // ablation: both pixel halves in phase (the schedule of round 1's kernel)
   if (wm == 1) __builtin_amdgcn_s_barrier();           // half a K step behind: LOAD of one half runs beside MFMA of the other
+#endif
   asm volatile("" ::: "memory");
   int st_c = 0, st_i = NST - 1;                        // stage read by the next LOAD segment / filled by its issue
   int st_pending = 0;                                  // K steps during which the epilogue's stores may still be in flight
@@ -477,7 +479,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     lane_setup(ti + 2, nrowoff, nrmask, nboff);
     __builtin_amdgcn_sched_barrier(0);
   }
+#ifndef PP_ABL_NOSTAGGER
   if (wm == 0) __builtin_amdgcn_s_barrier();           // the barrier the other half ran at the start
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ghost DMAs must have landed before the workgroup's LDS is released
 }
 

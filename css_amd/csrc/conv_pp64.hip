@@ -110,8 +110,12 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
   // (r >> 1) & 7 = (4 i + (lane >> 4)) & 7: rows i = 1, 3 take the chunk of rows i = 0, 2 with bit 2 flipped.
   const int prow = wave * 32 + (lane >> 3);
   const int cch0 = (lane & 7) ^ ((lane >> 4) & 3);
-  struct KPos { int ti, cs, tr, ts; unsigned trm; bool live, need; };
-  KPos pa = {0, 0, 0, 0, 0, false, true}, pb = {0, 0, 0, 0, 0, false, true};
+  // Position of a stream inside its tile: channel slice cs and index it into the tile's list of taps (a.tab_*: one list per set of
+  // valid kernel rows, built by the launcher).  The bookkeeping of a K step is a handful of scalar instructions: in the first
+  // version the (kernel row, column, slice) iteration with its valid-row bit tricks cost ~280 SALU instructions per LOAD segment
+  // - more than the 32 MFMAs of the other pixel half take.
+  struct KPos { int ti, cs, it, nt, vb; bool live, need; };
+  KPos pa = {0, 0, 0, 1, 0, false, true}, pb = {0, 0, 0, 1, 0, false, true};
   int rowoff[4], nrowoff[4];      // byte offset of the tap-(0,0) source pixel of my rows (+ my chunk), may be out of range: see rmask
   unsigned rmask[4], nrmask[4];   // bit (tr*S + ts): that tap of the row lies inside the source image
   unsigned boff[4], nboff[4];     // byte offset of my weight rows (+ my chunk), or OOB
@@ -172,41 +176,31 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
     p.live = p.ti < nmy;
     if (!p.live) return;
     const Tile t = tile_info(p.ti);
-    p.trm = t.trm;
     p.cs = 0;
-    p.ts = 0;
-    p.tr = __builtin_ctz(t.trm);
+    p.it = 0;
+    p.nt = __builtin_popcount(t.trm) * a.S;
+    p.vb = ((int)t.trm - 1) * 9;
   };
   // next K step of a stream: channel slice outer, tap inner (korder 1) or the reverse (korder 0)
   auto kpos_next = [&](KPos& p) {
     if (!p.live) return;
-    auto next_tap = [&]() -> bool {
-      if (++p.ts < a.S) return false;
-      p.ts = 0;
-      const unsigned rest = p.trm >> (p.tr + 1);
-      if (rest) {
-        p.tr += 1 + __builtin_ctz(rest);
-        return false;
-      }
-      p.tr = __builtin_ctz(p.trm);
-      return true;
-    };
-    bool done;
+    bool done = false;
     if (a.korder == 0) {
-      done = false;
       if (++p.cs == ncs) {
         p.cs = 0;
-        done = next_tap();
+        done = ++p.it == p.nt;
       }
     } else {
-      done = next_tap() && ++p.cs == ncs;
+      if (++p.it == p.nt) {
+        p.it = 0;
+        done = ++p.cs == ncs;
+      }
     }
     if (done) {
       ++p.ti;
       p.need = true;
     }
   };
-  const int tapstep = (a.mode == 0 ? a.dil : -a.dil) * a.lds * 2;     // bytes per kernel column; a kernel row is tapstep * Ws
   auto issue_a = [&](int buf) {
     if (pa.need) {
       kpos_switch(pa);
@@ -214,8 +208,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
       for (int i = 0; i < 4; ++i) { rowoff[i] = nrowoff[i]; rmask[i] = nrmask[i]; }
     }
     unsigned char* sa = smem + buf * BUF + wave * (32 * 128);
-    const int tap = pa.tr * a.S + pa.ts;
-    const int da = (pa.tr * a.Ws + pa.ts) * tapstep + pa.cs * (BK * 2);
+    const int ix = pa.vb + pa.it;
+    const int tap = a.tab_tap[ix];
+    const int da = a.tab_da[ix] + pa.cs * (BK * 2);
     const bool cok0 = pa.cs * BK + cch0 * 8 < a.Cs, cok1 = pa.cs * BK + (cch0 ^ 4) * 8 < a.Cs;      // ragged last channel slice
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -231,8 +226,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
       for (int i = 0; i < 4; ++i) boff[i] = nboff[i];
     }
     unsigned char* sb = smem_b + buf * BUF + wave * (32 * 128);
-    const int tap = pb.tr * a.S + pb.ts;
-    const unsigned kb = (unsigned)(tap * a.Cs + pb.cs * BK) * 2u;
+    const unsigned kb = (unsigned)(a.tab_kb[pb.vb + pb.it] + pb.cs * (BK * 2));
     const bool cok0 = pb.cs * BK + cch0 * 8 < a.Cs, cok1 = pb.cs * BK + (cch0 ^ 4) * 8 < a.Cs;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -397,7 +391,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
 // Supported: what conv_pp.hip supports, with at least three 64-channel K steps per tile and a whole number of 16-byte chunks.
 bool css_conv_pp64_supported(const ConvArgs& a) {
   static const bool off = getenv("CSS_NO_PP64_CONV") != nullptr;
-  if (off || !css_conv_pp_supported(a)) return false;
+  if (off || !css_conv_pp_supported(a) || a.R > 3 || a.S > 3) return false;     // (tap tables: 7 sets of valid kernel rows x 9 taps)
   const int ncs = (a.Cs + 63) / 64;
   return ncs * a.S >= 3;
 }
@@ -409,6 +403,22 @@ void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st) {
   a.korder = korder_env >= 0 ? (korder_env != 0) : (a.R * a.S > 1 ? 1 : 0);
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  // tap lists: for every non-empty set v of valid kernel rows (bit r of v: row r reads something but padding for the tile), the taps
+  // (r, s) in order with the byte offset of the source pixel relative to tap (0,0), the byte offset inside a weight row, and the bit
+  // index of the tap in the per-pixel validity masks
+  const int tapstep = (a.mode == 0 ? a.dil : -a.dil) * a.lds * 2;
+  for (int v = 1; v < (1 << a.R); ++v) {
+    int n = 0;
+    for (int r = 0; r < a.R; ++r) {
+      if (!((v >> r) & 1)) continue;
+      for (int sx = 0; sx < a.S; ++sx, ++n) {
+        const int ix = (v - 1) * 9 + n;
+        a.tab_da[ix] = (r * a.Ws + sx) * tapstep;
+        a.tab_kb[ix] = (r * a.S + sx) * a.Cs * 2;
+        a.tab_tap[ix] = r * a.S + sx;
+      }
+    }
+  }
   const dim3 g(grid), b(512);
   if (a.stats) hipLaunchKernelGGL((conv_igemm_pp64_kernel<true, false>), g, b, 0, st, a);
   else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp64_kernel<false, true>), g, b, 0, st, a);

@@ -26,6 +26,7 @@ struct ConvArgs {
   FastDiv fd_hw, fd_w;            // division by Hd*Wd and Wd
   unsigned stat_bytes, add_bytes; // sizes of the stats / addend buffers (buffer descriptors)
   int korder;                     // order of the K steps (conv_pp.hip: issue())
+  int tab_da[63], tab_kb[63], tab_tap[63];   // conv_pp64.hip: tap lists per set of valid kernel rows (7 x 9)
 };
 
 struct WgradArgs {

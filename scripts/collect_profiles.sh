@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round profiles of the default bench workload on the GPU box (each counter group is its own rocprofv3 run, every run bounded by
+# `timeout`; FETCH_SIZE and WRITE_SIZE never share a pass; no trace domains next to --pmc).  Usage: scripts/collect_profiles.sh r02
+set -u
+TAG=${1:-r02}
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out
+cd /tmp && export TMPDIR=/tmp
+B="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra"
+run() {   # name, counters...
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 420 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o p -- $B > /tmp/prof_$name.log 2>&1 || echo "$name: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt
+}
+run sq SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE
+DB=$(find /tmp/prof_sq -name "*.db" | head -1); [ -n "$DB" ] && python3 $ROOT/scripts/pmc_sq_summary.py $DB 20 > $OUT/${TAG}_pmc_sq_mfma_busy.csv
+run lds SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES
+DB=$(find /tmp/prof_lds -name "*.db" | head -1); [ -n "$DB" ] && python3 $ROOT/scripts/pmc_sq_summary.py $DB 20 > $OUT/${TAG}_pmc_sq_lds.csv
+run fetch FETCH_SIZE
+run write WRITE_SIZE
+F=$(find /tmp/prof_fetch -name "*.db" | head -1); W=$(find /tmp/prof_write -name "*.db" | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python3 $ROOT/scripts/pmc_summary.py $F $W > $OUT/${TAG}_pmc_hbm_traffic_c2.csv
+ls -la $OUT/${TAG}_* 2>/dev/null
