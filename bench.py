@@ -313,6 +313,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         sys.exit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}")
+    # stdout carries ONE JSON line.  Libraries write there too (RCCL prints its version banner to stdout when a communicator is
+    # created): keep the real stdout aside and point file descriptor 1 at stderr for the duration of the run.
+    sys.stdout.flush()
+    real_stdout = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # launcher self-test (tests/test_host_cpu.py): rendezvous + one collective over gloo on CPU, no GPU, no model
     if os.environ.get("CSS_BENCH_LAUNCH_TEST"):
         if os.environ["CSS_BENCH_LAUNCH_TEST"] == f"fail{rank}":
@@ -321,7 +326,7 @@ def main():
         t = torch.tensor([float(rank + 1)])
         dist.all_reduce(t)
         if rank == 0:
-            print(json.dumps({"launch_test": True, "n_gpus": world, "sum": float(t)}))
+            print(json.dumps({"launch_test": True, "n_gpus": world, "sum": float(t)}), file=real_stdout, flush=True)
         dist.destroy_process_group()
         return
     # CSS_BENCH_SHARE_GPU=1: every rank on cuda:0 with gloo collectives - the N > 1 code path on a one-GPU box (tests only)
@@ -385,7 +390,7 @@ def main():
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.cpu_budget)
-        print(json.dumps(res))
+        print(json.dumps(res), file=real_stdout, flush=True)
     if world > 1 or forced:
         dist.destroy_process_group()
 
