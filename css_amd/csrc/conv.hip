@@ -1163,6 +1163,10 @@ __device__ __forceinline__ void dma16_asm(u32x4 rsrc, void* lds_wave_base, unsig
   const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)lds_wave_base);
   asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(off), "s"(rsrc) : "memory");
 }
+// (the LDS byte address as a wave-uniform integer: no generic -> LDS pointer conversion, with its null check, per instruction)
+__device__ __forceinline__ void dma16_lds(u32x4 rsrc, unsigned lds_off, unsigned off) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(off), "s"(rsrc) : "memory");
+}
 __device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
   const unsigned long long b = reinterpret_cast<unsigned long long>(base);
   u32x4 r = {(unsigned)b, (unsigned)(b >> 32), bytes, 0x00020000u};
@@ -1186,7 +1190,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
   constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 2, wk = wave & 3;
   // XCD-aware order as in conv_wgrad_kernel: all tiles of one pixel slice run on one XCD
   const int per_z = a.tiles_k * a.tiles_n;
@@ -1211,28 +1215,60 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
   const bool n_ok = ncol < a.Cd;
 
   const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
-  // pixel block starting at mb -> stage (rows >= m_end, padding taps and tail columns land as zeros)
-  auto issue = [&](int stage, int mb) {
-    unsigned char* sy = smem + stage * ST_BYTES + wave * 1024;
-    unsigned char* sx = sy + T_BYTES;
+  // Issue side.  Every thread walks two pixel rows (prow, prow + 16) through the slice in steps of BP = 32 pixels; the step is a
+  // mixed-radix addition on (image, hd, wd) with one carry per digit, and the byte offsets into x and dy move by constants picked
+  // by the carries - a handful of full-rate VALU instructions per row where the first version re-derived (image, hd, wd) with two
+  // magic divisions, 64-bit multiply-adds and three 32-bit multiplies per row and step (~110 instructions per step and wave next to
+  // 16 MFMAs).  Rows >= m_end, padding taps and tail columns land as zeros (out-of-range offset).
+  const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;            // BP = (d_n * Hd + d_h) * Wd + d_w
+  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
+  const int xrow = a.ldx * 2;                                                       // bytes per source pixel
+  const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
+  const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;                               // no carry
+  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;                        // extra when wd / hd wrap
+  const int ystep = BP * a.ldy * 2;
+  int r_m[2], r_hs[2], r_ws[2];          // row, source coordinates of my tap (may be outside the image: padding)
+  unsigned r_xo[2], r_yo[2];             // byte offsets of my 16-byte chunk in x and dy
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_begin + prow + i * 16;
+    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
+    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
+    const uint32_t hd = fdiv(rem, a.fd_w);
+    const uint32_t wd = rem - hd * a.fd_w.d;
+    r_m[i] = m;
+    r_hs[i] = (int)hd * a.stride + dh;
+    r_ws[i] = (int)wd * a.stride + dw_;
+    r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
+    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
+  }
+  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;   // source coordinate of the last output row / column
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
+  auto issue = [&](int stage) {          // the next pixel block of the slice -> stage; advances the walk
+    const unsigned sy = lds0 + (unsigned)stage * ST_BYTES, sx = sy + T_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) dma16_lds(rs_y, sy + i * 8192, (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB);
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = mb + prow + i * 16;
-      const unsigned off = (unsigned)(m * a.ldy + ncol) * 2u;
-      dma16_asm(rs_y, sy + i * 8192, (n_ok && m < m_end) ? off : OOB);
+      const bool ok = k_ok && r_m[i] < m_end && (unsigned)r_hs[i] < (unsigned)a.Hs && (unsigned)r_ws[i] < (unsigned)a.Ws;
+      dma16_lds(rs_x, sx + i * 8192, ok ? r_xo[i] : OOB);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int m = mb + prow + i * 16;
-      const uint32_t mm = (uint32_t)min(m, a.M - 1);
-      const uint32_t n_img = fdiv(mm, a.fd_hw);
-      const uint32_t rem = mm - n_img * a.fd_hw.d;
-      const uint32_t hd = fdiv(rem, a.fd_w);
-      const uint32_t wd = rem - hd * a.fd_w.d;
-      const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
-      const bool ok = k_ok && m < m_end && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
-      const unsigned off = (unsigned)(((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc) * 2u;
-      dma16_asm(rs_x, sx + i * 8192, ok ? off : OOB);
+      r_m[i] += BP;
+      r_yo[i] += (unsigned)ystep;
+      int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
+      int dx = D0;
+      const bool cw = ws > ws_hi;
+      ws -= cw ? a.Wd * a.stride : 0;
+      hs += cw ? a.stride : 0;
+      dx += cw ? Dw : 0;
+      const bool ch = hs > hs_hi;
+      hs -= ch ? a.Hd * a.stride : 0;
+      dx += ch ? Dh : 0;
+      r_ws[i] = ws;
+      r_hs[i] = hs;
+      r_xo[i] += (unsigned)dx;
     }
   };
 
@@ -1266,15 +1302,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
     }
   };
 
-  int mb = m_begin;
-  issue(0, mb); mb += BP;
-  issue(1, mb); mb += BP;
-  issue(2, mb); mb += BP;
+  issue(0);
+  issue(1);
+  issue(2);
   int st_c = 0, st_i = 3;
   for (int it = 0; it < nit; ++it) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    issue(st_i, mb); mb += BP;          // step it+3 (past m_end: all-OOB = zeros into a free stage)
+    issue(st_i);                        // step it+3 (past m_end: all-OOB = zeros into a free stage)
     compute(st_c);
     st_c = (st_c + 1) & 3;
     st_i = (st_i + 1) & 3;

@@ -47,6 +47,12 @@ __device__ __forceinline__ float p6_lo(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float p6_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
+#ifndef P6_SPLIT
+#define P6_SPLIT 0      // 1: a K step's scalar bookkeeping inside the previous MFMA segment, only its LDS-DMA pieces in the LOAD segment
+#endif
+#ifndef P6_DMA_FIRST
+#define P6_DMA_FIRST 0  // (split only) the pieces ahead of the segment's fragment reads (1) or behind them (0)
+#endif
 template <bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) {
   constexpr int BM = 256, BN = 256, BK = 64, NA = 3, NB = 2;
@@ -69,8 +75,13 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
   const int ncs = (a.Cs + BK - 1) / BK;                         // 64-channel slices (the last one may be ragged: Cs = 304)
   const int hw = a.Hd * a.Wd;
 
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, (int)a.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (int)a.wt_bytes, 0x00020000);
+  // (opaque copies: under SGPR pressure the compiler otherwise re-loads these kernel arguments from memory inside every LOAD
+  // segment - an s_load and an lgkmcnt(0) wait ahead of the LDS-DMA issue; a spilled SGPR costs one v_readlane instead)
+  unsigned long long src_p = (unsigned long long)a.src, wt_p = (unsigned long long)a.wt;
+  int src_n = (int)a.src_bytes, wt_n = (int)a.wt_bytes;
+  asm volatile("" : "+s"(src_p), "+s"(wt_p), "+s"(src_n), "+s"(wt_n));
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_p, 0, src_n, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wt_p, 0, wt_n, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, (int)a.dst_bytes, 0x00020000);
 
   struct Tile { int m0, n0; unsigned trm; int nk; };
@@ -114,6 +125,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
   // valid kernel rows, built by the launcher).  The bookkeeping of a K step is a handful of scalar instructions: in the first
   // version the (kernel row, column, slice) iteration with its valid-row bit tricks cost ~280 SALU instructions per LOAD segment
   // - more than the 32 MFMAs of the other pixel half take.
+  // The launcher's tap tables (63 entries each) live in three VGPRs, entry e in lane e: a lookup is one v_readlane, where indexing
+  // the kernel-argument copy costs an s_load and an lgkmcnt(0) wait (which also waits for every fragment read in flight).
+  const int tabv_da = a.tab_da[lane < 63 ? lane : 62], tabv_kb = a.tab_kb[lane < 63 ? lane : 62], tabv_tap = a.tab_tap[lane < 63 ? lane : 62];
   struct KPos { int ti, cs, it, nt, vb; bool live, need; };
   KPos pa = {0, 0, 0, 1, 0, false, true}, pb = {0, 0, 0, 1, 0, false, true};
   int rowoff[4], nrowoff[4];      // byte offset of the tap-(0,0) source pixel of my rows (+ my chunk), may be out of range: see rmask
@@ -201,39 +215,54 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
       p.need = true;
     }
   };
-  auto issue_a = [&](int buf) {
+  // An operand tile is issued as four 1-KiB pieces per wave: *_begin = the K step's scalars (and the tile switch), *_piece(i) = one
+  // LDS-DMA instruction.  In the K loop they are issued INSIDE the MFMA segments (see there); the prologue issues whole tiles.
+  unsigned char* sa_cur = smem;
+  int tap_cur = 0, da_cur = 0, a_lim = 0;
+  auto a_begin = [&](int buf) {
     if (pa.need) {
       kpos_switch(pa);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { rowoff[i] = nrowoff[i]; rmask[i] = nrmask[i]; }
     }
-    unsigned char* sa = smem + buf * BUF + wave * (32 * 128);
+    sa_cur = smem + buf * BUF + wave * (32 * 128);
     const int ix = pa.vb + pa.it;
-    const int tap = a.tab_tap[ix];
-    const int da = a.tab_da[ix] + pa.cs * (BK * 2);
-    const bool cok0 = pa.cs * BK + cch0 * 8 < a.Cs, cok1 = pa.cs * BK + (cch0 ^ 4) * 8 < a.Cs;      // ragged last channel slice
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = ((i & 1) ? cok1 : cok0) && ((rmask[i] >> tap) & 1);
-      p6_dma16(rs_a, sa + i * 1024, ok ? (unsigned)(rowoff[i] + da) : P6_OOB);
-    }
+    tap_cur = __builtin_amdgcn_readlane(tabv_tap, ix);
+    da_cur = __builtin_amdgcn_readlane(tabv_da, ix) + pa.cs * (BK * 2);
+    a_lim = a.Cs - pa.cs * BK;                               // channels left in this slice (ragged last slice)
     kpos_next(pa);
   };
-  auto issue_b = [&](int buf) {
+  auto a_piece = [&](int i) {
+    const bool ok = (cch0 ^ ((i & 1) << 2)) * 8 < a_lim && ((rmask[i] >> tap_cur) & 1);
+    p6_dma16(rs_a, sa_cur + i * 1024, ok ? (unsigned)(rowoff[i] + da_cur) : P6_OOB);
+  };
+  unsigned char* sb_cur = smem;
+  unsigned kb_cur = 0;
+  int b_lim = 0;
+  auto b_begin = [&](int buf) {
     if (pb.need) {
       kpos_switch(pb);
 #pragma unroll
       for (int i = 0; i < 4; ++i) boff[i] = nboff[i];
     }
-    unsigned char* sb = smem_b + buf * BUF + wave * (32 * 128);
-    const unsigned kb = (unsigned)(a.tab_kb[pb.vb + pb.it] + pb.cs * (BK * 2));
-    const bool cok0 = pb.cs * BK + cch0 * 8 < a.Cs, cok1 = pb.cs * BK + (cch0 ^ 4) * 8 < a.Cs;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ok = ((i & 1) ? cok1 : cok0) && boff[i] != P6_OOB && pb.live;
-      p6_dma16(rs_b, sb + i * 1024, ok ? boff[i] + kb : P6_OOB);
-    }
+    sb_cur = smem_b + buf * BUF + wave * (32 * 128);
+    kb_cur = (unsigned)(__builtin_amdgcn_readlane(tabv_kb, pb.vb + pb.it) + pb.cs * (BK * 2));
+    b_lim = pb.live ? a.Cs - pb.cs * BK : 0;
     kpos_next(pb);
+  };
+  auto b_piece = [&](int i) {
+    const bool ok = (cch0 ^ ((i & 1) << 2)) * 8 < b_lim && boff[i] != P6_OOB;
+    p6_dma16(rs_b, sb_cur + i * 1024, ok ? boff[i] + kb_cur : P6_OOB);
+  };
+  auto issue_a = [&](int buf) {
+    a_begin(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) a_piece(i);
+  };
+  auto issue_b = [&](int buf) {
+    b_begin(buf);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b_piece(i);
   };
 
   // ---- consumer state ----
@@ -248,12 +277,15 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
   issue_b(0);                        // B(0)
   lane_setup(1, nrowoff, nrmask, nboff);
   issue_a(1);                        // A(1)
+#if P6_SPLIT
+  b_begin(1);                        // scalars of B(1): its pieces are the first thing the K loop issues
+#endif
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // A(0), B(0) landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();           // half a sub-step behind: LOAD of one half runs beside MFMA of the other
   asm volatile("" ::: "memory");
   int ca = 0, cb = 0;                // buffers read by the current K step
-  int ia = 2, ib = 1;                // buffers filled next (A two steps ahead, B one)
+  int ia = 2, ib = P6_SPLIT ? 0 : 1; // buffers of the next *_begin (A two steps ahead, B one; split: B(1)'s scalars are ready)
 
   for (int ti = 0; ti < nmy; ++ti) {
     const Tile ct = tile_info(ti);
@@ -265,18 +297,36 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         // ---------------- LOAD segment of K half h ----------------
         const int ko = h ? koff1 : koff0;
         bf16x8 fa[8], fw[4];
+        // The LOAD segment is the critical path of the ping-pong (the other half's 32 MFMAs take 512 cycles), so it holds nothing but
+        // the four LDS-DMA pieces of this K half - B(s+1) in half 0 (its buffer was last read one K step ago), A(s+2) in half 1 - and
+        // the fragment reads; the step's scalar bookkeeping (tile switch, tap tables: s_load + lgkmcnt waits that would also wait for
+        // the fragment reads) was done inside the previous MFMA segment (b_begin / a_begin below).
+#if P6_SPLIT && P6_DMA_FIRST
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { if (h == 0) b_piece(p); else a_piece(p); }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
         for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(bb + j * 2048 + ko);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + ko);
-        if (h == 0) {
-          issue_b(ib);                                   // weights of the NEXT K step (its buffer was last read one K step ago)
-          ib ^= 1;
-        } else {
-          issue_a(ia);                                   // pixels of the K step after the next
-          ia = ia == NA - 1 ? 0 : ia + 1;
-          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my share of the next K step (A and B) has landed; A(+2) keeps flying
-        }
+#if !P6_SPLIT
+        if (h == 0) { b_begin(ib); ib ^= 1; }
+        else { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
+#endif
+#if !(P6_SPLIT && P6_DMA_FIRST)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) { if (h == 0) b_piece(p); else a_piece(p); }
+#endif
+#if P6_SPLIT == 2
+        // scalars of the NEXT LOAD segment's pieces, behind this segment's issue: they run while the reads and the DMAs are in flight
+        __builtin_amdgcn_sched_barrier(0);
+        if (h == 0) { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
+        else { b_begin(ib); ib ^= 1; }
+        __builtin_amdgcn_sched_barrier(0);
+#endif
+        if (h == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my share of the next K step (A and B) has landed; A(+2) keeps flying
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads are done (buffers may be refilled after the barrier)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -284,17 +334,28 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA segment ----------------
         __builtin_amdgcn_s_setprio(1);
+        auto dma_slot = [&](int i) {       // scalars of the NEXT segment's pieces, behind the first row of MFMAs
+          if (i != 0 || P6_SPLIT != 1) return;
+          __builtin_amdgcn_sched_barrier(0);
+          if (h == 0) { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
+          else { b_begin(ib); ib ^= 1; }
+          __builtin_amdgcn_sched_barrier(0);
+        };
         if (kt == 0 && h == 0) {
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], z, 0, 0, 0);
+            dma_slot(i);
+          }
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i)
+          for (int i = 0; i < 8; ++i) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
+            dma_slot(i);
+          }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);

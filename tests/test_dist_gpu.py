@@ -175,9 +175,11 @@ def _trainer_pair(tmp_path, bucket_mb, steps="3"):
 def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
     """The gradient all-reduce overlapped with backward in buckets (train_step.MixTrainer._backward_and_reduce; DDP's buckets at
     mix_label.py:77) against ONE all-reduce after backward (CSS_GRAD_BUCKET_MB=0): two steps (the first records the readiness order,
-    the second runs bucketed), replicas bit-identical in both modes, and the two modes equal up to the order of the fp32 atomic adds
-    (a random-init network amplifies that noise step by step - 2e-2 after three steps - hence two steps here; a bucket that missed a
-    range or reduced one twice would break the replica equality or show up as O(1))."""
+    the second runs bucketed), replicas bit-identical in both modes, and the two modes equal up to run-to-run noise (the order of
+    the remaining fp32 atomic adds - class sums, loss footprints - which a random-init bf16 network amplifies step by step: 3e-3 to
+    8e-3 after two steps on different boxes, 2e-2 after three - hence two steps and a 3e-2 bound here; a bucket that missed a range
+    or reduced one twice breaks the replica equality (the gradient of that range is then no longer the same sum on both ranks) or
+    shows up as O(1))."""
     import torch
     a8, b8 = _trainer_pair(tmp_path, "8", "2")
     a0, b0 = _trainer_pair(tmp_path, "0", "2")
@@ -189,7 +191,7 @@ def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
     p8, p0 = torch.tensor(a8["p"]), torch.tensor(a0["p"])
     err = ((p8 - p0).norm() / p0.norm()).item()
     print("bucketed vs single all-reduce after 2 steps: rel-L2 of the parameters", err, a8["losses"], a0["losses"])
-    assert err < 5e-3
+    assert err < 3e-2
 
 
 def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
