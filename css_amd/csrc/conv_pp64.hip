@@ -47,12 +47,6 @@ __device__ __forceinline__ float p6_lo(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float p6_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
-#ifndef P6_SPLIT
-#define P6_SPLIT 0      // 1: a K step's scalar bookkeeping inside the previous MFMA segment, only its LDS-DMA pieces in the LOAD segment
-#endif
-#ifndef P6_DMA_FIRST
-#define P6_DMA_FIRST 0  // (split only) the pieces ahead of the segment's fragment reads (1) or behind them (0)
-#endif
 template <bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) {
   constexpr int BM = 256, BN = 256, BK = 64, NA = 3, NB = 2;
@@ -277,15 +271,12 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
   issue_b(0);                        // B(0)
   lane_setup(1, nrowoff, nrmask, nboff);
   issue_a(1);                        // A(1)
-#if P6_SPLIT
-  b_begin(1);                        // scalars of B(1): its pieces are the first thing the K loop issues
-#endif
   asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // A(0), B(0) landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();           // half a sub-step behind: LOAD of one half runs beside MFMA of the other
   asm volatile("" ::: "memory");
   int ca = 0, cb = 0;                // buffers read by the current K step
-  int ia = 2, ib = P6_SPLIT ? 0 : 1; // buffers of the next *_begin (A two steps ahead, B one; split: B(1)'s scalars are ready)
+  int ia = 2, ib = 1;                // buffers filled next (A two steps ahead, B one)
 
   for (int ti = 0; ti < nmy; ++ti) {
     const Tile ct = tile_info(ti);
@@ -297,36 +288,25 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         // ---------------- LOAD segment of K half h ----------------
         const int ko = h ? koff1 : koff0;
         bf16x8 fa[8], fw[4];
-        // The LOAD segment is the critical path of the ping-pong (the other half's 32 MFMAs take 512 cycles), so it holds nothing but
-        // the four LDS-DMA pieces of this K half - B(s+1) in half 0 (its buffer was last read one K step ago), A(s+2) in half 1 - and
-        // the fragment reads; the step's scalar bookkeeping (tile switch, tap tables: s_load + lgkmcnt waits that would also wait for
-        // the fragment reads) was done inside the previous MFMA segment (b_begin / a_begin below).
-#if P6_SPLIT && P6_DMA_FIRST
-#pragma unroll
-        for (int p = 0; p < 4; ++p) { if (h == 0) b_piece(p); else a_piece(p); }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
+        // Both segments of the ping-pong are critical (a phase lasts max(LOAD of one half, MFMA of the other), and they are about
+        // equal), so the LOAD segment holds: the 12 fragment reads, the step's scalars (~35 SALU, no memory access: the tap tables
+        // sit in VGPR lanes - they run while the reads are in flight), the four LDS-DMA pieces of this K half - B(s+1) in half 0 (its
+        // buffer was last read one K step ago), A(s+2) in half 1 - and the waits.  Measured alternatives (profiles/
+        // r02_conv_ablation.txt section 6): pieces or scalars inside the MFMA segment +10..15 % time (they stall MFMA issue),
+        // pieces ahead of the reads or directly behind them +3..5 % (an LDS-DMA issued into a queue of ds_reads is slow).
 #pragma unroll
         for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(bb + j * 2048 + ko);
 #pragma unroll
         for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + ko);
-#if !P6_SPLIT
         if (h == 0) { b_begin(ib); ib ^= 1; }
         else { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
-#endif
-#if !(P6_SPLIT && P6_DMA_FIRST)
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int p = 0; p < 4; ++p) { if (h == 0) b_piece(p); else a_piece(p); }
-#endif
-#if P6_SPLIT == 2
-        // scalars of the NEXT LOAD segment's pieces, behind this segment's issue: they run while the reads and the DMAs are in flight
-        __builtin_amdgcn_sched_barrier(0);
-        if (h == 0) { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
-        else { b_begin(ib); ib ^= 1; }
-        __builtin_amdgcn_sched_barrier(0);
-#endif
-        if (h == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // my share of the next K step (A and B) has landed; A(+2) keeps flying
+        // my share of the next K step (A and B) has landed; A(+2) keeps flying.  (vmcnt is in order and counts stores: in the first K
+        // step of a tile this also waits for the previous epilogue's stores; issuing B(1), A(2) ahead of those stores was tried - the
+        // K loop with the extra first-step case ran 12-15 % slower on every shape, profiles/r02_conv_ablation.txt section 6)
+        if (h == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // my fragment reads are done (buffers may be refilled after the barrier)
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
@@ -334,28 +314,17 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA segment ----------------
         __builtin_amdgcn_s_setprio(1);
-        auto dma_slot = [&](int i) {       // scalars of the NEXT segment's pieces, behind the first row of MFMAs
-          if (i != 0 || P6_SPLIT != 1) return;
-          __builtin_amdgcn_sched_barrier(0);
-          if (h == 0) { a_begin(ia); ia = ia == NA - 1 ? 0 : ia + 1; }
-          else { b_begin(ib); ib ^= 1; }
-          __builtin_amdgcn_sched_barrier(0);
-        };
         if (kt == 0 && h == 0) {
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], z, 0, 0, 0);
-            dma_slot(i);
-          }
         } else {
 #pragma unroll
-          for (int i = 0; i < 8; ++i) {
+          for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-            dma_slot(i);
-          }
         }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
