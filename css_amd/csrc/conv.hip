@@ -1280,26 +1280,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int stage) {
+  bf16x8 fy[2][TN], fx[2][TK];          // fragments of the two 16-pixel halves of a stage
+  auto read_frags = [&](int stage, int ks) {
     const unsigned char* Yb = smem + stage * ST_BYTES;
     const unsigned char* Xb = Yb + T_BYTES;
-    bf16x8 fy[2][TN], fx[2][TK];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int i = 0; i < TN; ++i) fy[ks][i] = wg_frag_sw(Yb, ks * 16, wn * WTN + i * 32, lane);
 #pragma unroll
-      for (int i = 0; i < TN; ++i) fy[ks][i] = wg_frag_sw(Yb, ks * 16, wn * WTN + i * 32, lane);
+    for (int j = 0; j < TK; ++j) fx[ks][j] = wg_frag_sw(Xb, ks * 16, wk * WTK + j * 32, lane);
+  };
+  auto mma = [&](int ks) {
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-      for (int j = 0; j < TK; ++j) fx[ks][j] = wg_frag_sw(Xb, ks * 16, wk * WTK + j * 32, lane);
-    }
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
+      for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   issue(0);
@@ -1309,8 +1305,16 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
   for (int it = 0; it < nit; ++it) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    // fragment reads first, then the LDS-DMA issue and the walk's ALU work while the reads are in flight, then the MFMAs (issue ahead
+    // of the reads: +2 % time; a software pipeline inside the wave - reads of one 16-pixel half under the MFMAs of the other, with the
+    // barrier between them - +4 %: the two waves of a SIMD already cover each other, profiles/r02_conv_ablation.txt section 6)
+    read_frags(st_c, 0);
+    read_frags(st_c, 1);
+    __builtin_amdgcn_sched_barrier(0);
     issue(st_i);                        // step it+3 (past m_end: all-OOB = zeros into a free stage)
-    compute(st_c);
+    __builtin_amdgcn_sched_barrier(0);
+    mma(0);
+    mma(1);
     st_c = (st_c + 1) & 3;
     st_i = (st_i + 1) & 3;
   }

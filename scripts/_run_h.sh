@@ -1,9 +1,6 @@
 cd $GRAFT_REPO_ROOT
-export CB_NOWGRAD=1
 for rep in 1 2; do
-for b in cb_base cb_cur cb_pre1; do
-  echo "== $b plain rep$rep"; timeout 120 ./build/$b | grep fwd
-  echo "== $b stats rep$rep"; CB_STATS=1 timeout 120 ./build/$b | grep fwd
+for b in cb_base cb_wr1 cb_wp; do
+  echo "== $b plain rep$rep"; timeout 200 ./build/$b | sed 's/wgrad/fwd  /' | awk 'NR%2==0'
 done
 done
-for b in cb_base cb_cur cb_pre1; do echo "== $b add"; CB_ADD=1 timeout 120 ./build/$b | grep fwd; done
