@@ -20,4 +20,8 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 F=$(find /tmp/prof_fetch -name "*.db" | head -1); W=$(find /tmp/prof_write -name "*.db" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 $ROOT/scripts/pmc_summary.py $F $W > $OUT/${TAG}_pmc_hbm_traffic_c2.csv
+# per-kernel time: --kernel-trace --stats only (never next to --pmc), three steps
+rm -rf /tmp/prof_stats
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /tmp/prof_stats.log 2>&1 || echo "stats: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt
+S=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_bench_kernel_stats.csv
 ls -la $OUT/${TAG}_* 2>/dev/null
