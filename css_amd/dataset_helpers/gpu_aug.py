@@ -12,11 +12,17 @@ is absent (the reference's YAML files do not have it, and the drop-in path must 
     random crop, ColorJitter (PIL blends + 8-bit HSV hue shift, random order), GaussianBlur (PIL's three box passes per axis),
     horizontal flip, to_tensor, ImageNet normalisation.  The random draws are made on the host with the reference's laws
     (``draw_params``) - a few numbers per image.
-Mixing (both modes): ``none`` | ``cutmix`` | ``cutout`` with the reference's box law (VOC.py:518-534) and partner
-``(i+1) % B`` (VOC.py:428), boxes drawn on the host with numpy like the reference and applied by torch indexing on the device
-classmix (VOC.py:505-510,430-437) with torch ops on the device.
+Mixing (both modes): ``none`` | ``cutmix`` | ``cutout`` with the reference's box law (VOC.py:518-534), boxes drawn on the host
+with numpy like the reference and applied by torch indexing on the device; classmix (VOC.py:505-510,430-437) with torch ops on the
+device.  The partner of image i is ``gathered[(i+1) % B]`` (VOC.py:396-399,428): the reference all-gathers the four tensors and then
+indexes the gathered batch with the LOCAL batch size, so on every rank the partner comes from RANK 0's batch, and every rank draws
+one mask per gathered image and uses the block of its own rank.  ``_mix`` reproduces exactly that with one broadcast of rank 0's
+tensors (and, for classmix only, an all-gather of the label maps the masks are drawn from) instead of four all-gathers;
+``CSS_CUTMIX_LOCAL=1`` mixes inside the local batch instead (no collective, not the reference's law for world size > 1).
 """
 from __future__ import annotations
+
+import os
 
 import numpy as np
 import torch
@@ -94,6 +100,14 @@ def class_mask(pseudo_labels: torch.Tensor, generator=None) -> torch.Tensor:
     return (pseudo_labels.unsqueeze(-1) == select).any(dim=-1)
 
 
+def _ranks():
+    """(rank, world size) the mixing has to reproduce (VOC.py:396-402), (0, 1) without a process group."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and os.environ.get("CSS_CUTMIX_LOCAL") != "1":
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def _mix(tensors, mode, rng):
     image = tensors[0]
     b, _, h, w = image.shape
@@ -101,19 +115,36 @@ def _mix(tensors, mode, rng):
         return tensors
     if mode not in ("cutmix", "cutout", "classmix"):
         raise ValueError("mode must be in none, cutout, cutmix, or classmix")
+    rank, world = _ranks()
+    partners = tensors                       # gathered[(i + 1) % B] = rank 0's batch
+    labels_all = None
+    if world > 1:
+        import torch.distributed as dist
+        if mode != "cutout":
+            partners = [t.clone() for t in tensors]
+            for t in partners:
+                dist.broadcast(t, src=0)
+        if mode == "classmix":               # one mask per gathered image, drawn from that image's label map (VOC.py:412,424)
+            labels_all = [torch.empty_like(tensors[1]) for _ in range(world)]
+            dist.all_gather(labels_all, tensors[1].contiguous())
     outs = [t.clone() for t in tensors]
-    for i in range(b):
-        j = (i + 1) % b
+    # every rank draws for ALL gathered images in order and keeps the block of its own rank (VOC.py:411-437)
+    for gi in range(world * b):
+        mine = rank * b <= gi < (rank + 1) * b
+        i, j = gi - rank * b, (gi + 1) % b
         if mode == "classmix":
             # image i where the mask is 1, partner elsewhere (VOC.py:430-437); tensors[1] is the (first) label map
-            keep = class_mask(tensors[1][i])
-            for t, o in zip(tensors, outs):
-                o[i] = torch.where(keep if t.dim() == 3 else keep.unsqueeze(0), t[i], t[j])
+            keep = class_mask(tensors[1][i] if world == 1 else labels_all[gi // b][gi % b])
+            if mine:
+                for t, o, pt in zip(tensors, outs, partners):
+                    o[i] = torch.where(keep if t.dim() == 3 else keep.unsqueeze(0), t[i], pt[j])
             continue
         y0, y1, x0, x1 = cutout_box(h, w, 2, rng)
-        for t, o in zip(tensors, outs):
+        if not mine:
+            continue
+        for t, o, pt in zip(tensors, outs, partners):
             if mode == "cutmix":
-                o[i, ..., y0:y1, x0:x1] = t[j, ..., y0:y1, x0:x1]
+                o[i, ..., y0:y1, x0:x1] = pt[j, ..., y0:y1, x0:x1]
             else:
                 is_label = t.dtype == torch.int64
                 o[i, ..., y0:y1, x0:x1] = -1 if is_label else 0

@@ -134,3 +134,51 @@ def batch_transform_2(images, labels, logits_1, logits_2, params: Sequence[AugPa
         for o, r in zip(outs, res):
             o.append(r.unsqueeze(0))
     return tuple(torch.cat(o) for o in outs)
+
+
+# ---- generate_cut_gather* across ranks (VOC.py:354-477) -----------------------------------------------------------------
+def cutout_mask(h, w, ratio, rng):
+    """generate_cutout_mask (VOC.py:518-534): 1 outside the box, 0 inside; three numpy draws."""
+    area = h * w / ratio
+    bw = rng.randint(w / ratio + 1, w)
+    bh = np.round(area / bw)
+    x0 = rng.randint(0, w - bw + 1)
+    y0 = rng.randint(0, h - bh + 1)
+    m = torch.ones(h, w)
+    m[int(y0): int(y0 + bh), int(x0): int(x0 + bw)] = 0
+    return m
+
+
+def cut_gather_ranks(per_rank, mode, rngs):
+    """What each of W ranks returns from generate_cut_gather_2/3 (VOC.py:393-434 / 436-477), restated for a list of per-rank tensor
+    tuples (image [B,3,H,W], label maps int64 [B,H,W] ..., confidence maps [B,H,W] ...): the tensors are all-gathered, EVERY rank
+    walks all W*B gathered images drawing one mask each from its own numpy stream (``rngs[r]``), the partner of gathered image i is
+    ``gathered[(i + 1) % B]`` with B the LOCAL batch size - i.e. always an image of rank 0 - and rank r keeps block r.
+    cutmix / cutout only (classmix draws from torch's global stream)."""
+    world, b = len(per_rank), per_rank[0][0].shape[0]
+    h, w = per_rank[0][0].shape[-2:]
+    gathered = [torch.cat([per_rank[r][k] for r in range(world)]) for k in range(len(per_rank[0]))]
+    outs = []
+    for r in range(world):
+        if mode == "none":
+            outs.append(tuple(t[r * b:(r + 1) * b].clone() for t in gathered))
+            continue
+        new = [[] for _ in gathered]
+        for i in range(world * b):
+            if mode == "cutout":
+                m = cutout_mask(h, w, 2, rngs[r])
+                for k, t in enumerate(gathered):
+                    if t.dtype == torch.int64:
+                        v = t[i].clone()
+                        v[(1 - m).bool()] = -1
+                    else:
+                        v = t[i] * m
+                    new[k].append(v.unsqueeze(0))
+                continue
+            m = cutout_mask(h, w, 2, rngs[r])
+            j = (i + 1) % b
+            for k, t in enumerate(gathered):
+                v = t[i] * m + t[j] * (1 - m)
+                new[k].append((v.long() if t.dtype == torch.int64 else v).unsqueeze(0))
+        outs.append(tuple(torch.cat(n)[r * b:(r + 1) * b] for n in new))
+    return outs

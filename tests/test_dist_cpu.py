@@ -180,3 +180,64 @@ def test_world2_bucketed_gradient_all_reduce_equals_one_all_reduce():
         # backward visits the layers in reverse: every bucket is one contiguous run of the flat buffer
         assert all(len(r) == 1 for r in runs), runs
     assert res[0][3] == res[1][3]                                    # same plan on both ranks
+
+
+def _mix_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import numpy as np
+    from css_amd.dataset_helpers import gpu_aug
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cut_gather_w2.npz"))
+    ins = lambda: [torch.from_numpy(z[f"in_r{rank}_{k}"]).clone() for k in range(4)]
+    res = {}
+    for mode in ("none", "cutmix", "cutout"):
+        res[mode] = [o.numpy() for o in gpu_aug.generate_cut_gather_2(*ins(), mode=mode, rng=np.random.RandomState(50 + rank))]
+    img, lab, l1, l2 = ins()
+    res["cutmix3"] = [o.numpy() for o in gpu_aug.generate_cut_gather_3(img, lab, lab + 1, l1, l2, mode="cutmix", rng=np.random.RandomState(50 + rank))]
+    q.put((rank, res))
+    dist.destroy_process_group()
+
+
+def test_world2_cut_gather_partner_and_draws_follow_the_reference():
+    """generate_cut_gather_2/3 under two ranks against vectors captured from the reference run by two gloo processes
+    (tests/golden/make_cut_gather_w2.py; VOC.py:393-477): the partner of every image is RANK 0's image (i+1) % B (the reference
+    indexes the all-gathered batch with the local batch size) and every rank draws one box per GATHERED image and uses its own
+    block.  The oracle's restatement (oracle/aug_oracle.py: cut_gather_ranks) is pinned on the same vectors."""
+    import numpy as np
+    os.environ["CSS_FORCE_COLLECTIVES"] = "0"
+    os.environ.pop("CSS_CUTMIX_LOCAL", None)
+    z = np.load(os.path.join(ROOT, "tests", "golden", "cut_gather_w2.npz"))
+    modes = ("none", "cutmix", "cutout", "cutmix3")
+    n_out = {"none": 4, "cutmix": 4, "cutout": 4, "cutmix3": 5}
+    # (1) the oracle against the reference's vectors
+    sys.path.insert(0, ROOT)
+    from oracle import aug_oracle as A
+    ins = [[torch.from_numpy(z[f"in_r{r}_{k}"]) for k in range(4)] for r in range(2)]
+    for mode in modes:
+        per_rank = [tuple(i) for i in ins] if mode != "cutmix3" else [(i[0], i[1], i[1] + 1, i[2], i[3]) for i in ins]
+        want = A.cut_gather_ranks(per_rank, mode.rstrip("3"), [np.random.RandomState(50 + r) for r in range(2)])
+        for r in range(2):
+            for k in range(n_out[mode]):
+                assert np.array_equal(want[r][k].numpy(), z[f"out_{mode}_r{r}_{k}"]), ("oracle", mode, r, k)
+    # (2) css_amd under two gloo ranks against the same vectors
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_mix_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for mode in modes:
+        for r in range(2):
+            for k in range(n_out[mode]):
+                assert np.array_equal(res[r][mode][k], z[f"out_{mode}_r{r}_{k}"]), ("css_amd", mode, r, k)
+    # rank 1's cutmix result contains rank 0's pixels: it differs from mixing inside its own batch
+    from css_amd.dataset_helpers import gpu_aug
+    local = gpu_aug.generate_cut_gather_2(*[t.clone() for t in ins[1]], mode="cutmix", rng=np.random.RandomState(51))
+    assert not np.array_equal(local[0].numpy(), z["out_cutmix_r1_0"])
