@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Throughput of the CSS mix_label training step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W          (defaults: N = 1, W = 20 - SURVEY 8(d) - and K = 20: ~6 s of steps)
 
 N > 1 with WORLD_SIZE unset: this process starts N fresh children of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
 environment, one per GPU) BEFORE it touches the GPU, relays rank 0's line and exits non-zero if any child fails - the counterpart of
@@ -288,8 +288,8 @@ def cpu_baseline(budget_s=150.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=20, help="SURVEY 8(d): 20 steps before timing (prototype EMA branch active)")
     ap.add_argument("--batch", type=int, default=None, help="crops per GPU of each kind (default: the workload's)")
     ap.add_argument("--size", type=int, default=None, help="crop size (default: the workload's)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
