@@ -1,0 +1,67 @@
+"""Every environment switch the launchers read (css_amd/csrc/conv.hip, conv_pp.hip, conv_pp64.hip: kernel selection for A/B timing)
+is a shipped configuration: each one runs a bench-shape convolution (32 images of 65x65, 256 -> 256, 3x3 dilation 2: whole rounds of
+the chip + leftover rows + the fused statistics) forward, data gradient and weight gradient against torch-CPU fp32, in a process of its
+own (the switches are read once).  Shapes as in tests/test_conv_bench_scale_gpu.py; reference: generalframeworks/networks/resnet.py:119-139."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+sys.path.insert(0, %r)
+import torch, torch.nn.functional as F
+from css_amd import ops
+from gpu_util import bf16_round, dev, rel_err
+n, h, w, cin, cout, k, pad, dil = 32, 65, 65, 256, 256, 3, 2, 2
+g = torch.Generator().manual_seed(77)
+x = bf16_round(torch.randn(n, h, w, cin, generator=g) + 0.25)
+wt = bf16_round(torch.randn(cout, k, k, cin, generator=g) / (cin * k * k) ** 0.5)
+gy = bf16_round(torch.randn(n, h, w, cout, generator=g))
+xr = x.permute(0, 3, 1, 2).requires_grad_(True)
+wr = wt.permute(0, 3, 1, 2).requires_grad_(True)
+yr = F.conv2d(xr, wr, None, 1, pad, dil)
+yr.backward(gy.permute(0, 3, 1, 2))
+xg = x.to(dev(), torch.bfloat16).requires_grad_(True)
+wg = wt.permute(0, 3, 1, 2).to(dev()).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+with ops.bn_groups(2):
+    y = ops.conv2d(xg, wg, None, 1, pad, dil, bn_stats=True)
+y.backward(gy.to(dev(), torch.bfloat16))
+torch.cuda.synchronize()
+e = (rel_err(y.detach().float().cpu(), yr.detach().permute(0, 2, 3, 1)), rel_err(xg.grad.float().cpu(), xr.grad.permute(0, 2, 3, 1)),
+     rel_err(wg.grad.cpu(), wr.grad))
+# fused statistics (when this configuration emits them) against an fp64 reduction of the CPU output
+if hasattr(y, "_css_bnstats"):
+    from css_amd._lib import call, dev_stream
+    part, mg, groups, c_, bm = y._css_bnstats
+    sums = torch.empty(groups * 2 * cout + groups, dtype=torch.float64, device=dev())
+    d, st = dev_stream(y)
+    call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None, None,
+         sums, cout, y, cout, bm, d, st)
+    yy = yr.detach().permute(0, 2, 3, 1).double().reshape(groups, -1, cout)
+    got = sums.cpu()[:groups * 2 * cout].reshape(groups, 2, cout)
+    es = rel_err(got[:, 1], (yy * yy).sum(1))
+else:
+    es = 0.0
+print("ERRS", *e, es)
+assert max(e) < 2e-2 and es < 2e-3, (e, es)
+'''
+
+SWITCHES = [{}, {"CSS_NO_PP64_CONV": "1"}, {"CSS_NO_PP64_CONV": "1", "CSS_NO_PP_CONV": "1"}, {"CSS_NO_PP64_CONV": "1", "CSS_PP_272": "1"},
+            {"CSS_PP_KORDER": "0"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"}, {"CSS_WGRAD_ATOMICS": "1"},
+            {"CSS_NO_DMA256_WGRAD": "1"}, {"CSS_REM_N64": "1"}, {"CSS_BN_RED_BLOCKS": "256"}]
+
+
+@pytest.mark.parametrize("env", SWITCHES, ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()) or "default")
+def test_conv_parity_under_every_launcher_switch(env):
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, os.path.join(ROOT, "tests"))], env=e, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-400:], r.stderr[-800:])
+    assert r.returncode == 0, (env, r.stderr[-800:])
