@@ -4,6 +4,7 @@
 #include "../../include/css_hip.h"
 #include "launchers.h"
 
+#include <cstdlib>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -199,6 +200,20 @@ int css_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin; a.m_per_split = a.M;
   ConvProf cp(2, 7, alg_flops, S(stream));
   return css_launch_wgrad(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
+}
+int css_conv_ws_applies(int M, int K, int ld_src, int N, int ld_dst, int R, int Sk, int stride, int pad, int has_stats, int has_addend, int ld_add,
+                        int has_bias, int dtype, int n_cu) {
+  static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
+  if (dtype != CSS_BF16 || no_dma || no_256) return 0;
+  alignas(16) static float dummy[4];
+  ConvArgs a = {};
+  a.N = 1; a.Hs = a.Hd = 1; a.Ws = a.Wd = M; a.M = M;
+  a.Cs = K; a.lds = ld_src; a.Cd = N; a.ldd = ld_dst; a.Ktot = R * Sk * K;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = 1;
+  a.stats = has_stats ? dummy : nullptr;
+  a.addend = has_addend ? dummy : nullptr; a.ld_add = ld_add;
+  a.bias = has_bias ? dummy : nullptr;
+  return css_conv_ws_supported(a, n_cu > 0 ? n_cu : 256) ? 1 : 0;
 }
 int css_wgrad_splits(int M, int Ktot, int Cout, int dtype, int n_cu) {
   int splits = 0, mps = 0;

@@ -1409,6 +1409,7 @@ static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
 // rows per statistics slab pair of a forward launch (see css_conv2d_forward_bnstats): 272 when the 272-row persistent tiling is used
 int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) {
   static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
+  if (dtype == CSS_BF16 && !no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) return 256;   // conv_ws.hip: 128-row slabs, as the 256-row tiles
   if (dtype == CSS_BF16 && a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) return 272;
   return 256;
 }
@@ -1433,7 +1434,12 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
-    if (a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) {
+    if (!no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) {
+      // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
+      P0(true, 1.0);
+      css_launch_conv_ws(a, n_cu, st);
+      P1();
+    } else if (a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) {
       // 272-row tiles of the persistent kernel cover every row in whole rounds of the chip: one launch
       ConvArgs b = a;
       b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);

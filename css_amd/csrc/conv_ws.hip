@@ -1,0 +1,388 @@
+// conv_ws_kernel: weight-STATIONARY 1x1 convolution for the short-K class (K = Cin in {64, 128, 256}, Cout a multiple of 256):
+// conv3 of a Bottleneck (generalframeworks/networks/resnet.py:131-133: planes -> 4 x planes) in the forward pass and conv1 of a
+// Bottleneck (resnet.py:123-125: 4 x planes -> planes) in its data-gradient form, 23 + 22 of each in layer 3 alone.
+//
+// Why a kernel of its own (profiles/r02_conv_ablation.txt section 4): on these shapes the 256x256 persistent
+// kernels are bound by the global -> LDS fill path, not by MFMA, HBM or the stores: a 256x256 tile with K = 256 re-stages 128 KiB of
+// weights AND 128 KiB of pixels for 33.5 MFLOP (10 us per tile against 3.9 us of MFMA).  Here
+//   * a workgroup owns ONE 256-channel panel of the output for its whole life and keeps the panel's weights in REGISTERS as MFMA
+//     operands: wave w holds channels 32 w .. 32 w + 31 for all of K (K = 256: 16 fragments = 64 VGPRs), loaded once per launch;
+//   * the only LDS traffic from global memory is the pixel stream: tiles of 128 pixels, one 16 KiB stage per 64 channels, a ring of
+//     LA + 2 stages with LA = 2 tiles' worth in flight (K = 256: 10 stages = 160 KiB, 128 KiB in flight per CU) - half the bytes per
+//     FLOP of the 256x256 tiling, and none of them weights;
+//   * every wave reads the whole pixel stage (128 x 64) and multiplies it with its own 32 channels: 16 ds_read_b128 + 32
+//     v_mfma_f32_16x16x32_bf16 per stage and wave, ONE barrier per stage;
+//   * the 4 (Cout / 256) panels of a pixel tile are worked on at the same time by 4 CUs of one XCD (the tile is fetched from HBM once
+//     and hits that XCD's L2 three times); 128-row tiles quantise to the chip well enough (1057 tiles x 4 panels on 256 CUs = 16.5
+//     rounds) that there is no leftover launch;
+//   * the epilogue is conv_pp64's (registers -> bf16 -> v_permlane16_swap -> 16-byte stores, 64 contiguous bytes per pixel; BN
+//     statistics slabs of 128 rows, which a wave owns whole; the residual-gradient addend of css_conv2d_dgrad_add), with the addend
+//     requested at the START of the tile so that its wait does not drain the LDS-DMA queue.
+// vmcnt bookkeeping: loads, stores and LDS-DMA retire in order, so the wait for "my two pieces of stage s" is a COUNT of what the
+// wave has issued since: 2 (LA - 1) pieces + the epilogue stores (+ addend loads) of the two tiles in between - a constant because LA is a
+// whole number of tiles.
+#include "common.h"
+#include "launchers.h"
+#include <cstdlib>
+
+#ifndef WS_STORE_AUX
+#define WS_STORE_AUX 0      // cache policy of the output stores (timing ablation: 2 = nt)
+#endif
+namespace {
+typedef __attribute__((address_space(3))) void ws_lds_void;
+constexpr unsigned WS_OOB = 0x80000000u;
+typedef __attribute__((ext_vector_type(4))) unsigned int ws_u32x4;
+typedef __attribute__((ext_vector_type(4))) float ws_f32x4;
+typedef __attribute__((ext_vector_type(2))) float ws_f32x2;
+
+__device__ __forceinline__ void ws_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ws_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
+}
+__device__ __forceinline__ float ws_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+// (the builtin returns one register for both results in this toolchain: DESIGN.md 3)
+__device__ __forceinline__ void ws_swap16(unsigned& a, unsigned& b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ unsigned ws_pack2(float lo, float hi) {
+  union { bf16_t h[2]; unsigned u; } t;
+  t.h[0] = (bf16_t)lo;
+  t.h[1] = (bf16_t)hi;
+  return t.u;
+}
+__device__ __forceinline__ float ws_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float ws_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// vmcnt(BASE + c_st * NST + c_ld * NLD) for c_st in 0..2, c_ld in 1..2 (the counts fold to constants once the K loop is unrolled)
+template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_stage(int c_st, int c_ld) {
+  static_assert(BASE + 2 * NST + 2 * NLD <= 63, "vmcnt is a 6-bit counter");
+  if (c_ld <= 1) {
+    if (c_st == 0) ws_wait_vm<BASE + NLD>();
+    else if (c_st == 1) ws_wait_vm<BASE + NST + NLD>();
+    else ws_wait_vm<BASE + 2 * NST + NLD>();
+  } else {
+    if (c_st == 0) ws_wait_vm<BASE + 2 * NLD>();
+    else if (c_st == 1) ws_wait_vm<BASE + NST + 2 * NLD>();
+    else ws_wait_vm<BASE + 2 * NST + 2 * NLD>();
+  }
+}
+}  // namespace
+#ifndef WS_PP
+#define WS_PP 0
+#endif
+
+// KS = K / 64 (stages per pixel tile).  grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 256) == 0.
+template <int KS, bool STATS, bool ADD>
+__global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
+  constexpr int BM = 128, BN = 256, LA = 2 * KS, NS = LA + 2;
+  constexpr int STG = BM * 128;                                  // one stage: 128 pixels x 128 bytes (64 channels)
+#if defined(WS_ABL_NOSTORE)       // timing ablations (scripts/ws_bench.hip): results are garbage
+  constexpr bool ABL_NOSTORE = true, ABL_NOMFMA = false, ABL_NODMA = false;
+#elif defined(WS_ABL_NOMFMA)
+  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = true, ABL_NODMA = false;
+#elif defined(WS_ABL_NODMA)
+  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = true;
+#else
+  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = false;
+#endif
+  constexpr int NLD = ADD ? 8 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
+  constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
+  constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + NLD + NST, W2 = W1 + NST;   // vmcnt of the stage wait in tile 0, tile 1, later tiles
+  static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // ---- schedule: workgroup -> (panel, pixel-tile stream); the panels of a pixel tile sit on CUs of ONE XCD ----
+  const int G = gridDim.x, c8 = G >> 3;
+  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
+  const int np = a.Cd / BN;
+  const int spx = c8 / np;                                       // streams per XCD
+#if defined(WS_ABL_PANEL_XCD)      // timing ablation: the panels of a pixel tile on different XCDs
+  const int lin = xcd * c8 + idx8, nstreams = G / np;
+  const int panel = lin % np, stream = lin / np;
+#else
+  const int panel = idx8 % np, stream = xcd * spx + idx8 / np, nstreams = 8 * spx;
+#endif
+  const int mt_total = (a.M + BM - 1) / BM;
+  const int nmy = stream < mt_total ? (mt_total - stream + nstreams - 1) / nstreams : 0;
+  if (nmy == 0) return;
+  const int n0w = panel * BN + wave * 32;
+
+  unsigned long long src_p = (unsigned long long)a.src, wt_p = (unsigned long long)a.wt;
+  int src_n = (int)a.src_bytes, wt_n = (int)a.wt_bytes;
+  asm volatile("" : "+s"(src_p), "+s"(wt_p), "+s"(src_n), "+s"(wt_n));
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_p, 0, src_n, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wt_p, 0, wt_n, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, (int)a.dst_bytes, 0x00020000);
+
+  // ---- my weights: MFMA operand fragments for channels n0w + 16 j + (lane & 15), k = 32 q + 8 (lane >> 4) .. + 7 ----
+  bf16x8 fw[2 * KS][2];
+#pragma unroll
+  for (int q = 0; q < 2 * KS; ++q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned off = (unsigned)(n0w + 16 * j + l15) * (unsigned)a.Ktot * 2u + (unsigned)(32 * q + 8 * lg) * 2u;
+      fw[q][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs_b, (int)off, 0, 0));
+    }
+
+  // ---- issue side: stage (tile it_ti, slice it_k) = 16 pieces of 1 KiB, two per wave: rows 16 wave + 8 i + (lane >> 3), the
+  // 16-byte chunk stored at position lane & 7 of row r is source chunk (lane & 7) ^ ((r >> 1) & 7) (conflict-free fragment reads) ----
+  const int prow = wave * 16 + (lane >> 3);
+  const int cch0 = (lane & 7) ^ ((lane >> 4) & 3);
+  const unsigned lds2 = (unsigned)a.lds * 2u;
+  int it_ti = 0, it_k = 0, islot = 0;
+  unsigned rowoff[2];
+  auto issue_rows = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int m = (stream + it_ti * nstreams) * BM + prow + 8 * i;
+      rowoff[i] = (it_ti < nmy && m < a.M) ? (unsigned)m * lds2 + (unsigned)((cch0 ^ ((i & 1) << 2)) * 16) : WS_OOB;
+    }
+  };
+  auto issue_stage = [&]() {
+    unsigned char* const sa = smem + islot * STG + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) ws_dma16(rs_a, sa + i * 1024, rowoff[i] != WS_OOB ? rowoff[i] + (unsigned)(it_k * 128) : WS_OOB);
+    islot = islot == NS - 1 ? 0 : islot + 1;
+    if (++it_k == KS) {
+      it_k = 0;
+      ++it_ti;
+      issue_rows();
+    }
+  };
+  issue_rows();
+#pragma unroll
+  for (int s = 0; s < LA; ++s) issue_stage();
+  // the weights are needed from here on: one counted wait now (the pieces above stay in flight).  Without this the compiler's
+  // waitcnt pass carries the pending loads into the loop and waits for them, with ever smaller counts, in front of every MFMA group.
+#pragma unroll
+  for (int q = 0; q < 2 * KS; ++q)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) asm volatile("" : "+v"(fw[q][j]));
+
+  // ---- consumer ----
+  f32x4 acc[8][2];        // [pixel tile i: pixels 16 i + (lane & 15)][channel tile j: channels 16 j + 4 (lane >> 4) + reg]
+  const int sw = (l15 >> 1) & 7;
+  int cslot = 0;
+  const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);            // first of my 8 channels in a store (after the lane swap)
+
+  ws_u32x4 radd[ADD ? 8 : 1];
+  // ---------------- epilogue of a tile (rows m0e ..): no LDS, no barrier ----------------
+  auto epilogue = [&](int m0e) {
+    const int bnd = STATS ? (m0e / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int m = m0e + 16 * i + l15;
+      unsigned lo0 = ws_pack2(acc[i][0][0], acc[i][0][1]), hi0 = ws_pack2(acc[i][0][2], acc[i][0][3]);
+      unsigned lo1 = ws_pack2(acc[i][1][0], acc[i][1][1]), hi1 = ws_pack2(acc[i][1][2], acc[i][1][3]);
+      ws_swap16(lo0, lo1);
+      ws_swap16(hi0, hi1);
+      ws_u32x4 v = {lo0, hi0, lo1, hi1};
+      if (ADD) {
+        const ws_u32x4 r = radd[ADD ? i : 0];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(r[e]), ws_hi(v[e]) + ws_hi(r[e]));
+      }
+      if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+      else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)nl) * 2u : WS_OOB), 0, WS_STORE_AUX);
+    }
+    if (STATS) {
+      // sum and sum of squares of the bf16-ROUNDED outputs (what the batch norm will read), two values per instruction (v_pk_add_f32 /
+      // v_pk_fma_f32); the row test only in a tile that straddles a statistics-group boundary (one tile per group)
+      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
+      const unsigned base = (unsigned)(m0e >> 7) * 2u * (unsigned)a.Cd * 4u;
+      const bool whole = m0e + BM <= bnd;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        ws_f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        auto accum = [&](bool test) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            f32x4 t = acc[i][j];
+            asm volatile("" : "+v"(t));       // opaque: otherwise the packed values of the store loop stay alive (CSE) across the epilogue
+            const unsigned lo = ws_pack2(t[0], t[1]), hi = ws_pack2(t[2], t[3]);
+            ws_f32x2 v01 = {ws_lo(lo), ws_hi(lo)}, v23 = {ws_lo(hi), ws_hi(hi)};
+            if (test && !(m0e + 16 * i + l15 < bnd)) { v01 = ws_f32x2{0.f, 0.f}; v23 = ws_f32x2{0.f, 0.f}; }   // (rows >= M hold zeros already)
+            s01 += v01; s23 += v23;
+            q01 += v01 * v01; q23 += v23 * v23;
+          }
+        };
+        if (whole) accum(false);
+        else accum(true);
+        ws_f32x4 os = {ws_row16_sum(s01[0]), ws_row16_sum(s01[1]), ws_row16_sum(s23[0]), ws_row16_sum(s23[1])};
+        ws_f32x4 oq = {ws_row16_sum(q01[0]), ws_row16_sum(q01[1]), ws_row16_sum(q23[0]), ws_row16_sum(q23[1])};
+        const int n = n0w + 16 * j + 4 * lg;
+        const bool lane_ok = l15 == 0;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, os), rs_s, (int)(lane_ok ? base + (unsigned)n * 4u : WS_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, oq), rs_s, (int)(lane_ok ? base + (unsigned)(a.Cd + n) * 4u : WS_OOB), 0, 0);
+      }
+    }
+  };
+  auto load_addend = [&](int m0e) {
+    // requested a whole tile ahead of its use: by then everything older (LDS-DMA pieces of earlier stages) has landed anyway, so
+    // waiting for it costs nothing - an addend requested inside the epilogue drains the whole in-order queue once per tile
+    const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < (ADD ? 8 : 0); ++i) {
+      const int m = m0e + 16 * i + l15;
+      radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)nl) * 2u : WS_OOB), 0, 0);
+    }
+  };
+  auto mfma_half = [&](const bf16x8 (&fa)[8], int q, bool first) {
+    if (first) {
+      const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[q][j], fa[i], z, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[q][j], fa[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if constexpr (WS_PP != 0) {
+    // ---- ping-pong: waves 0-3 and waves 4-7 (one of each per SIMD) run half a stage apart - READ segment (last tile's epilogue,
+    // fragment reads, next LDS-DMA pieces, waits) of one group beside the MFMA segment of the other, two barriers per stage ----
+    const int grp = wave >> 2;
+    ws_wait_vm<NPC * (LA - 1)>();           // my pieces of stage 0 have landed
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    for (int ti = 0; ti < nmy; ++ti) {
+      const int m0 = (stream + ti * nstreams) * BM;
+#pragma unroll
+      for (int k = 0; k < KS; ++k) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (k == 0) {
+          if (ti > 0) epilogue(m0 - nstreams * BM);       // beside the other group's MFMAs
+          if (ADD) load_addend(m0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const unsigned char* ab = smem + cslot * STG + l15 * 128;
+        bf16x8 fa[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) fa[h][i] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + (((4 * h + lg) ^ sw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+        if (!ABL_NODMA) issue_stage();      // stage + LA into the slot read two stages ago
+        __builtin_amdgcn_sched_barrier(0);
+        // my pieces of the NEXT stage have landed: younger than them are 2 (LA - 1) pieces and the epilogues / addend requests at the
+        // starts of this tile and (for all but the last slice) of the previous one
+        ws_wait_stage<NPC * (LA - 1), NST, NLD>((ti >= 1 ? 1 : 0) + ((ti >= 2 && k <= KS - 2) ? 1 : 0), 1 + ((ti >= 1 && k <= KS - 2) ? 1 : 0));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        if (!ABL_NOMFMA) {
+          mfma_half(fa[0], 2 * k, k == 0);
+          mfma_half(fa[1], 2 * k + 1, false);
+        } else if (k == 0) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        cslot = cslot == NS - 1 ? 0 : cslot + 1;
+      }
+    }
+    epilogue((stream + (nmy - 1) * nstreams) * BM);
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+  } else {
+  for (int ti = 0; ti < nmy; ++ti) {
+    const int m0 = (stream + ti * nstreams) * BM;
+    if (ABL_NOMFMA) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (ADD) load_addend(m0);
+#pragma unroll
+    for (int k = 0; k < KS; ++k) {
+      __builtin_amdgcn_sched_barrier(0);
+      // my two pieces of this stage have landed (see the header for the counts)
+      if (ti >= 2) ws_wait_vm<W2>();
+      else if (ti == 1) ws_wait_vm<W1>();
+      else ws_wait_vm<W0>();
+      __builtin_amdgcn_s_barrier();       // everybody's pieces have landed; everybody is done reading the previous stages
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (!ABL_NODMA) issue_stage();      // stage + LA into the slot read two stages ago
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned char* ab = smem + cslot * STG + l15 * 128;
+      // all fragment reads of the stage first (16 x ds_read_b128, back to back), then its 32 MFMAs back to back: left to itself the
+      // compiler reads one fragment, waits for it, issues its two MFMAs, and so on - every LDS latency exposed.  (The addend variant
+      // holds 32 more registers: it reads and multiplies one 32-channel half of the stage at a time.)
+      constexpr int HB = ADD ? 1 : 2;                    // K halves per batch
+#pragma unroll
+      for (int hb = 0; hb < (ABL_NOMFMA ? 0 : 2); hb += HB) {
+        bf16x8 fa[HB][8];
+#pragma unroll
+        for (int h = 0; h < HB; ++h)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) fa[h][i] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + (((4 * (hb + h) + lg) ^ sw) << 4));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int h = 0; h < HB; ++h) mfma_half(fa[h], 2 * k + hb + h, k == 0 && hb + h == 0);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      cslot = cslot == NS - 1 ? 0 : cslot + 1;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    epilogue(m0);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ghost pieces (stages past my last tile) must have landed before the LDS is released
+}
+
+// Shapes this kernel takes (everything else stays on the 256x256 persistent kernels)
+static int g_ws_off = -1;      // -1: read CSS_NO_WS_CONV on first use
+void css_conv_ws_set_enabled(int on) { g_ws_off = on ? 0 : 1; }     // (A/B timing and the parity harness: scripts/conv_bench.hip)
+bool css_conv_ws_supported(const ConvArgs& a, int n_cu) {
+  if (g_ws_off < 0) g_ws_off = getenv("CSS_NO_WS_CONV") != nullptr;
+  const bool off = g_ws_off != 0;
+  if (off || a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
+  if (a.Ktot != a.Cs || (a.Cs != 64 && a.Cs != 128 && a.Cs != 256) || a.Cd < 256 || a.Cd % 256 || a.lds % 8 || a.ldd % 8) return false;
+  if (a.stats && a.addend) return false;
+  if (a.addend && a.ld_add % 8) return false;
+  const int np = a.Cd / 256;
+  if (n_cu < 8 || n_cu % 8 || (n_cu / 8) % np) return false;
+  if ((size_t)a.M * a.ldd * 2 >= 0x7FFFFFF0ull || (a.addend && (size_t)a.M * a.ld_add * 2 >= 0x7FFFFFF0ull)) return false;
+  return a.M > 0;
+}
+
+template <int KS>
+static void launch_ws(const ConvArgs& a, int grid, hipStream_t st) {
+  const dim3 g(grid), b(512);
+  if (a.stats) hipLaunchKernelGGL((conv_ws_kernel<KS, true, false>), g, b, 0, st, a);
+  else if (a.addend) hipLaunchKernelGGL((conv_ws_kernel<KS, false, true>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((conv_ws_kernel<KS, false, false>), g, b, 0, st, a);
+}
+void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st) {
+  a.dst_bytes = (unsigned)((size_t)a.M * a.ldd * 2);
+  if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
+  if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  if (a.Cs == 256) launch_ws<4>(a, n_cu, st);
+  else if (a.Cs == 128) launch_ws<2>(a, n_cu, st);
+  else launch_ws<1>(a, n_cu, st);
+}

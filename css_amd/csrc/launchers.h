@@ -59,6 +59,9 @@ void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st);
 int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu);
 bool css_conv_pp64_supported(const ConvArgs& a);
 void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st);
+bool css_conv_ws_supported(const ConvArgs& a, int n_cu);
+void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st);
+void css_conv_ws_set_enabled(int on);
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
 size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu);
 

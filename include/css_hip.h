@@ -58,6 +58,12 @@ CSS_API int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, fl
                                        int device, css_stream_t stream);
 CSS_API int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
                                                  int Cout, int ldy, int R, int S, int stride, int pad, int dil, int dtype, int device);
+/* host-side query (no launch): 1 when css_conv2d_forward[_bnstats] / css_conv2d_dgrad[_add] run this product on the weight-stationary
+ * short-K kernel (csrc/conv_ws.hip: 1x1, stride 1, no padding, bf16, K = channels of the gathered tensor in {64, 128, 256}, N = output
+ * channels a multiple of 256; conv3 of a Bottleneck forward - resnet.py:131-133 - and conv1 of a Bottleneck backward - resnet.py:123-125),
+ * 0 when it takes the 256x256-tile kernels.  M = output rows, ld_* = row pitches in elements, n_cu = css_device_cu_count(). */
+CSS_API int css_conv_ws_applies(int M, int K, int ld_src, int N, int ld_dst, int R, int S, int stride, int pad, int has_stats, int has_addend,
+                                int ld_add, int has_bias, int dtype, int n_cu);
 /* w_t: weights re-laid out as [Cin][R][S][Cout] (css_weight_layout dgrad=1); stride 1 or 2 */
 CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);

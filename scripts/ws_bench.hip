@@ -1,0 +1,127 @@
+// Standalone parity + timing harness for conv_ws_kernel (css_amd/csrc/conv_ws.hip) against the 256x256 persistent kernels it replaces on
+// the short-K 1x1 shapes.  Test / measurement infrastructure, not a product path.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics scripts/ws_bench.hip -o build/ws_bench && ./build/ws_bench
+// For every shape and every epilogue (plain, BN statistics, addend) it runs css_launch_conv twice - conv_ws switched off, then on -
+// compares the outputs (bf16 tensors element by element, statistics slabs row by row) and times 20 launches of each.
+#include "../css_amd/csrc/conv.hip"
+#include "../css_amd/csrc/conv_pp.hip"
+#include "../css_amd/csrc/conv_pp64.hip"
+#include "../css_amd/csrc/conv_ws.hip"
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+struct Shape { const char* name; int N, H, W, Cin, Cout, ldd; };   // ldd: row pitch of the output in elements (0: Cout)
+static float bf2f(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
+
+int main() {
+  std::vector<Shape> shapes = {
+      {"l3 conv3 256->1024", 32, 65, 65, 256, 1024},
+      {"l2 conv3 128->512", 32, 65, 65, 128, 512},
+      {"l1 conv3 64->256", 32, 129, 129, 64, 256},
+      {"l2.0 ds 256->512 (dgrad of l2 conv1 form)", 32, 65, 65, 256, 512},
+      {"c4 l3 256->1024 (16 x 97^2)", 16, 97, 97, 256, 1024},
+      {"tiny 256->1024 (2 x 9^2: ragged, few tiles)", 2, 9, 9, 256, 1024},
+      {"tiny 64->256 (3 x 21^2)", 3, 21, 21, 64, 256},
+      {"tiny 128->2048 (1 x 33^2)", 1, 33, 33, 128, 2048},
+      {"pitch test 256->256 into 256-wide rows", 32, 65, 65, 256, 256},
+      {"pitch test 256->256 into 1024-wide rows", 32, 65, 65, 256, 256, 1024},
+      {"pitch test 256->512 into 1024-wide rows", 32, 65, 65, 256, 512, 1024},
+  };
+  const int only = getenv("WB_ONLY") ? atoi(getenv("WB_ONLY")) : -1;
+  const int reps = getenv("WB_REPS") ? atoi(getenv("WB_REPS")) : 20;
+  int bad = 0;
+  for (auto& s : shapes) {
+    if (only >= 0 && &s - shapes.data() != only) continue;
+    const int M = s.N * s.H * s.W;
+    const int ldd = s.ldd ? s.ldd : s.Cout;
+    const size_t nx = (size_t)M * s.Cin, nw = (size_t)s.Cout * s.Cin, ny = (size_t)M * ldd;
+    std::vector<unsigned short> hx(nx), hw(nw), hadd(ny);
+    srand(1234);
+    for (auto& v : hx) v = 0x3C00 + (rand() & 0x3FF) - ((rand() & 1) << 15);
+    for (auto& v : hw) v = 0x3800 + (rand() & 0x3FF) - ((rand() & 1) << 15);
+    for (auto& v : hadd) v = 0x3E00 + (rand() & 0x3FF) - ((rand() & 1) << 15);
+    void *dx, *dw, *dy[2], *dadd;
+    float* dstat[2];
+    const size_t nslab = 2 * (size_t)((M + 255) / 256), nstat = nslab * 2 * s.Cout;
+    hipMalloc(&dx, nx * 2); hipMalloc(&dw, nw * 2); hipMalloc(&dadd, ny * 2);
+    for (int v = 0; v < 2; ++v) { hipMalloc(&dy[v], ny * 2); hipMalloc(&dstat[v], nstat * 4); }
+    hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice);
+    hipMemcpy(dadd, hadd.data(), ny * 2, hipMemcpyHostToDevice);
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    const double flops = 2.0 * M * s.Cout * s.Cin, bytes = 2.0 * (nx + (double)M * s.Cout + nw);
+    static const char* ep_name[3] = {"plain", "stats", "add  "};
+    for (int ep = 0; ep < 3; ++ep) {
+      float us[2] = {0, 0};
+      for (int v = 0; v < 2; ++v) {      // 0: reference path, 1: conv_ws
+        css_conv_ws_set_enabled(v);
+        ConvArgs a{};
+        a.src = dx; a.wt = dw; a.dst = dy[v]; a.bias = nullptr;
+        a.N = s.N; a.Hs = s.H; a.Ws = s.W; a.Cs = s.Cin; a.lds = s.Cin;
+        a.Hd = s.H; a.Wd = s.W; a.Cd = s.Cout; a.ldd = ldd;
+        a.R = 1; a.S = 1; a.stride = 1; a.pad = 0; a.dil = 1; a.mode = ep == 2 ? 1 : 0;
+        a.M = M; a.Ktot = s.Cin;
+        if (ep == 1) { a.stats = dstat[v]; a.stat_Mg = (M % 2 == 0 && M / 2 >= 128) ? M / 2 : M; }
+        if (ep == 2) { a.addend = dadd; a.ld_add = ldd; }
+        if (v == 1 && !css_conv_ws_supported(a, 256)) { printf("%-46s %s  NOT SUPPORTED by conv_ws\n", s.name, ep_name[ep]); ++bad; continue; }
+        hipMemset(dy[v], 0xFF, ny * 2);
+        hipMemset(dstat[v], 0, nstat * 4);
+        int rc = css_launch_conv(a, CSS_BF16, 256, 0);
+        if (rc != 0 || hipDeviceSynchronize() != hipSuccess) { printf("launch failed rc=%d\n", rc); return 2; }
+        for (int i = 0; i < 2; ++i) css_launch_conv(a, CSS_BF16, 256, 0);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        for (int i = 0; i < reps; ++i) css_launch_conv(a, CSS_BF16, 256, 0);
+        hipEventRecord(e1, 0);
+        hipEventSynchronize(e1);
+        float ms;
+        hipEventElapsedTime(&ms, e0, e1);
+        us[v] = ms / reps * 1e3f;
+      }
+      // compare
+      std::vector<unsigned short> y0(ny), y1(ny);
+      hipMemcpy(y0.data(), dy[0], ny * 2, hipMemcpyDeviceToHost);
+      hipMemcpy(y1.data(), dy[1], ny * 2, hipMemcpyDeviceToHost);
+      size_t ndiff = 0;
+      double maxd = 0, maxv = 0;
+      for (size_t i = 0; i < ny; ++i) {
+        if (y0[i] == 0xFFFF && y1[i] == 0xFFFF) continue;     // untouched (pitch tests: columns outside the output)
+        if (y0[i] != y1[i]) ++ndiff;
+        const double d = fabs((double)bf2f(y0[i]) - (double)bf2f(y1[i]));
+        if (!(d <= maxd)) maxd = d;     // (NaN-propagating)
+        if (fabs(bf2f(y0[i])) > maxv) maxv = fabs(bf2f(y0[i]));
+      }
+      double smax = 0, sref = 0;
+      if (ep == 1) {
+        std::vector<float> s0(nstat), s1(nstat);
+        hipMemcpy(s0.data(), dstat[0], nstat * 4, hipMemcpyDeviceToHost);
+        hipMemcpy(s1.data(), dstat[1], nstat * 4, hipMemcpyDeviceToHost);
+        // only the slabs that exist (cdiv(M, 128)) carry data
+        const size_t live = (size_t)((M + 127) / 128) * 2 * s.Cout;
+        for (size_t i = 0; i < live; ++i) {
+          const double d = fabs((double)s0[i] - (double)s1[i]);
+          if (!(d <= smax)) smax = d;
+          if (fabs(s0[i]) > sref) sref = fabs(s0[i]);
+        }
+      }
+      // bf16 outputs of the same MFMA instruction on the same K blocks: identical except where the reference used its 32x32x16
+      // leftover kernel (different summation tree): allow one bf16 ulp there
+      const bool ok = maxd <= maxv * 0.01 && (ep != 1 || smax <= 2e-3 * (sref + 1.0));
+      if (!ok) ++bad;
+      printf("%-46s %s  M=%-6d ref %7.1f us  ws %7.1f us (%5.2fx, %6.1f TFLOP/s, %5.2f TB/s)  diff elems %zu / %zu  max |d| %.4g (max |y| %.3g)", s.name,
+             ep_name[ep], M, us[0], us[1], us[0] / us[1], flops / (us[1] * 1e-6) / 1e12, (bytes + (ep == 2 ? 2.0 * M * s.Cout : 0)) / (us[1] * 1e-6) / 1e12, ndiff, ny,
+             maxd, maxv);
+      if (ep == 1) printf("  stats max |d| %.4g (max %.4g)", smax, sref);
+      printf("  %s\n", ok ? "OK" : "MISMATCH");
+      fflush(stdout);
+    }
+    hipFree(dx); hipFree(dw); hipFree(dadd);
+    for (int v = 0; v < 2; ++v) { hipFree(dy[v]); hipFree(dstat[v]); }
+  }
+  printf(bad ? "FAILED: %d case(s)\n" : "all cases OK\n", bad);
+  return bad ? 1 : 0;
+}

@@ -310,3 +310,41 @@ def test_bench_refuses_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=dict(os.environ, WORLD_SIZE="4", RANK="0"),
                        capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr
+
+
+def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
+    """conv_ws_kernel (csrc/conv_ws.hip) waits for its LDS-DMA pieces by COUNT (loads, stores and LDS-DMA retire in order): the K loop must
+    hold exactly the waits the source states and no compiler-inserted drain, no scratch, the whole 160 KiB ring in ONE LDS object; and the
+    host-side shape rule of the dispatch (no GPU needed: css_conv_ws_applies launches nothing)."""
+    import shutil
+    import subprocess
+    from css_amd import _lib
+    ap = lambda m, k, n, r=1, stride=1, stats=0, add=0, bias=0, dtype=1: _lib.query("css_conv_ws_applies", m, k, k, n, n, r, r, stride, 0, stats, add, n, bias, dtype, 256)
+    assert ap(135200, 256, 1024) == 1 and ap(135200, 128, 512, stats=1) == 1 and ap(532512, 64, 256, add=1) == 1 and ap(81, 256, 2048) == 1
+    assert ap(135200, 512, 2048) == 0 and ap(135200, 256, 304) == 0 and ap(135200, 192, 1024) == 0 and ap(135200, 256, 128) == 0
+    assert ap(135200, 256, 1024, r=3) == 0 and ap(135200, 256, 1024, stride=2) == 0 and ap(135200, 256, 1024, bias=1) == 0
+    assert ap(135200, 256, 1024, dtype=0) == 0 and ap(135200, 256, 1024, stats=1, add=1) == 0
+    assert ap(135200, 64, 256 * 64) == 0          # more panels than CUs per XCD
+
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv_ws.hip")
+    out = str(tmp_path / "conv_ws.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    lines = open(out).read().split("\n")
+    # (KS, STATS, ADD) -> the vmcnt values of the stage wait in tile 0 / tile 1 / later tiles (conv_ws.hip: W0, W1, W2)
+    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (22, 38, 46)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (10, 26, 34))):
+        sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELb{ad}EEv8ConvArgs:"
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
+        assert len(mfma) % (32 * ks) == 0 and mfma, (sym, len(mfma))
+        bar = [i for i, l in enumerate(body) if "s_barrier" in l]
+        assert not any("vmcnt(0)" in l for l in body[bar[0]:mfma[-1] + 1]), sym + " compiler drained the LDS-DMA pipeline inside the K loop"
+        for wv in waits:
+            assert any(f"s_waitcnt vmcnt({wv})" in l for l in body), (sym, wv)
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == (2 * ks + 2) * 16384, sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
