@@ -271,14 +271,27 @@ int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, in
                  int Mg, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   ProfScope ps(8, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (res ? 1 : 0)), S(stream));
-  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, dtype, S(stream));
+  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, nullptr, dtype, S(stream));
+}
+int css_bn_apply_mask(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
+                      int relu, int Mg, unsigned char* mask, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  ProfScope ps(8, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (res ? 1 : 0)) + (mask ? (double)M * C / 8 : 0), S(stream));
+  return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, mask, dtype, S(stream));
 }
 int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, int device,
                       css_stream_t stream) {
   set_dev(device);
   ProfScope ps(10, (double)Mg * G * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (a ? 1 : 0)), S(stream));
-  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, dtype, S(stream));
+  return css_launch_bn_bwd_reduce(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, nullptr, dtype, S(stream));
+}
+int css_bn_bwd_reduce_mask(const void* da, int ldda, const unsigned char* mask, const void* y, int ldy, const float* mean, const float* invstd,
+                           int Mg, int G, int C, double* partial, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  if (!mask) return CSS_ERR_ARG;
+  ProfScope ps(10, (double)Mg * G * C * (dtype == CSS_BF16 ? 2 : 4) * 2 + (double)Mg * G * C / 8, S(stream));
+  return css_launch_bn_bwd_reduce(da, ldda, nullptr, 0, y, ldy, mean, invstd, nullptr, nullptr, Mg, G, C, 1, partial, mask, dtype, S(stream));
 }
 int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                      const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
@@ -286,7 +299,16 @@ int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const voi
   set_dev(device);
   ProfScope ps(9, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (3 + (a ? 1 : 0) + (dres ? 1 : 0)), S(stream));
   return css_launch_bn_bwd_apply(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg,
-                                 dtype, S(stream));
+                                 nullptr, dtype, S(stream));
+}
+int css_bn_bwd_apply_mask(const void* da, int ldda, const unsigned char* mask, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
+                          const float* mean, const float* invstd, const float* gamma, const double* sums, double count, const double* count_dev,
+                          int M, int C, int Mg, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  if (!mask) return CSS_ERR_ARG;
+  ProfScope ps(9, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (3 + (dres ? 1 : 0)) + (double)M * C / 8, S(stream));
+  return css_launch_bn_bwd_apply(da, ldda, nullptr, 0, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, nullptr, nullptr, count, count_dev, M, C, 1,
+                                 Mg, mask, dtype, S(stream));
 }
 
 // ---- pooling / resize / concat ----

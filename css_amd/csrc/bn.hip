@@ -272,10 +272,11 @@ __global__ void bn_eval_coeff_kernel(const float* __restrict__ gamma, const floa
 // Elementwise BN kernels: thread t owns channel vector (blockIdx.y*TPC + t % TPC) for all of its rows, so the per-channel
 // coefficients are loaded ONCE into registers (they used to be re-loaded for every element and made these kernels
 // instruction-bound).  grid = (row blocks, channel blocks, groups).
-template <typename T>
+template <typename T, bool MASK, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
                                                        T* __restrict__ out, int ldo, const float* __restrict__ scale,
-                                                       const float* __restrict__ shift, int Mg, int C, int relu, int rows_per_block) {
+                                                       const float* __restrict__ shift, int Mg, int C, int rows_per_block,
+                                                       unsigned char* __restrict__ mask) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
       const int ru = r + u * RPB;
       if (ru < row1) {
         v[u].load(y + (size_t)ru * ldy + c);
-        if (res) rr[u].load(res + (size_t)ru * ldr + c);
+        if (RES) rr[u].load(res + (size_t)ru * ldr + c);
       }
     }
 #pragma unroll
@@ -308,22 +309,35 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float x = v[u].f(e) * sc[e] + sh[e];
-          if (res) x += rr[u].f(e);
-          if (relu) x = fmaxf(x, 0.f);
+          if (RES) x += rr[u].f(e);
+          if (RELU) x = fmaxf(x, 0.f);
           o.set(e, x);
         }
         o.store(out + (size_t)ru * ldo + c);
+        if (MASK) {      // ReLU mask for the backward passes: one byte per vector, of the STORED values (what reading `out` back would give)
+          unsigned bits = 0;
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) bits |= (o.f(e) > 0.f ? 1u : 0u) << e;
+          mask[(size_t)ru * CV + cv] = (unsigned char)bits;
+        }
       }
     }
   }
 }
 
-template <typename T>
+// Where the backward kernels take the ReLU mask from (a template parameter: these kernels sit close to instruction-bound, a run-time
+// choice per element cost 20-45 % of their time):
+enum { BN_NORELU = 0, BN_MASK_RECOMPUTE = 1, BN_MASK_ACT = 2, BN_MASK_BITS = 3 };
+//   RECOMPUTE  layers without a residual: y * scale + shift > 0, exactly as the forward computed it (no extra read)
+//   ACT        from the saved activation tensor `a`
+//   BITS       residual layers: one byte per 16-byte vector written by bn_apply (bit e = element e > 0)
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a,
                                                             int lda, const T* __restrict__ y, int ldy,
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
-                                                            int Mg, int C, int relu, int rows_per_block, double* partial) {
+                                                            int Mg, int C, int rows_per_block, double* partial,
+                                                            const unsigned char* __restrict__ mask) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256;
@@ -334,20 +348,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   for (int e = 0; e < VEC; ++e) {
     mu[e] = mean[g * C + c0 + e];
     is[e] = invstd[g * C + c0 + e];
-    sc[e] = (relu && !a) ? scale[g * C + c0 + e] : 0.f;
-    sh[e] = (relu && !a) ? shift[g * C + c0 + e] : 0.f;
+    sc[e] = MODE == BN_MASK_RECOMPUTE ? scale[g * C + c0 + e] : 0.f;
+    sh[e] = MODE == BN_MASK_RECOMPUTE ? shift[g * C + c0 + e] : 0.f;
   }
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> gv, av, yv;
     gv.load(da + (size_t)r * ldda + c);
     yv.load(y + (size_t)r * ldy + c);
-    if (relu && a) av.load(a + (size_t)r * lda + c);
+    if (MODE == BN_MASK_ACT) av.load(a + (size_t)r * lda + c);
+    unsigned bits = 0;
+    if (MODE == BN_MASK_BITS) bits = mask[(size_t)r * CV + cv];
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       float dz = gv.f(e);
-      // ReLU mask: from the saved activation, or (layers without a residual) recomputed exactly as the forward did
-      const float act = a ? av.f(e) : yv.f(e) * sc[e] + sh[e];
-      if (relu && !(act > 0.f)) dz = 0.f;
+      if (MODE == BN_MASK_RECOMPUTE) { if (!(yv.f(e) * sc[e] + sh[e] > 0.f)) dz = 0.f; }
+      else if (MODE == BN_MASK_ACT) { if (!(av.f(e) > 0.f)) dz = 0.f; }
+      else if (MODE == BN_MASK_BITS) { if (!((bits >> e) & 1u)) dz = 0.f; }
       const float xh = (yv.f(e) - mu[e]) * is[e];
       s0[e] += dz;
       s1[e] += dz * xh;
@@ -356,14 +372,14 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
 }
 
-template <typename T>
+template <typename T, int MODE>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ da, int ldda, const T* __restrict__ a, int lda,
                                                            const T* __restrict__ y, int ldy, T* __restrict__ dy, int lddy,
                                                            T* __restrict__ dres, int lddr, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, double count, const double* __restrict__ count_dev,
-                                                           int Mg, int C, int relu, int rows_per_block) {
+                                                           int Mg, int C, int rows_per_block, const unsigned char* __restrict__ mask) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
@@ -380,20 +396,23 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     gi[e] = gamma[c + e] * is[e];
     m1[e] = (float)sums[(size_t)g * 2 * C + c + e] * inv_n;          // sums are [G][2][C]
     m2[e] = (float)sums[(size_t)g * 2 * C + C + c + e] * inv_n;
-    sc[e] = (relu && !a) ? scale[g * C + c + e] : 0.f;
-    sh[e] = (relu && !a) ? shift[g * C + c + e] : 0.f;
+    sc[e] = MODE == BN_MASK_RECOMPUTE ? scale[g * C + c + e] : 0.f;
+    sh[e] = MODE == BN_MASK_RECOMPUTE ? shift[g * C + c + e] : 0.f;
   }
   const int gbase = g * Mg;
   const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
     Vec16<T> gv[EW_UNROLL], av[EW_UNROLL], yv[EW_UNROLL];
+    unsigned bits[EW_UNROLL];
 #pragma unroll
     for (int u = 0; u < EW_UNROLL; ++u) {
       const int ru = r + u * RPB;
+      bits[u] = 0;
       if (ru < row1) {
         gv[u].load(da + (size_t)ru * ldda + c);
         yv[u].load(y + (size_t)ru * ldy + c);
-        if (relu && a) av[u].load(a + (size_t)ru * lda + c);
+        if (MODE == BN_MASK_ACT) av[u].load(a + (size_t)ru * lda + c);
+        if (MODE == BN_MASK_BITS) bits[u] = mask[(size_t)ru * CV + cv];
       }
     }
 #pragma unroll
@@ -404,8 +423,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           float dz = gv[u].f(e);
-          const float act = a ? av[u].f(e) : yv[u].f(e) * sc[e] + sh[e];
-          if (relu && !(act > 0.f)) dz = 0.f;
+          if (MODE == BN_MASK_RECOMPUTE) { if (!(yv[u].f(e) * sc[e] + sh[e] > 0.f)) dz = 0.f; }
+          else if (MODE == BN_MASK_ACT) { if (!(av[u].f(e) > 0.f)) dz = 0.f; }
+          else if (MODE == BN_MASK_BITS) { if (!((bits[u] >> e) & 1u)) dz = 0.f; }
           const float xh = (yv[u].f(e) - mu[e]) * is[e];
           o.set(e, gi[e] * (dz - m1[e] - xh * m2[e]));
           dr.set(e, dz);
@@ -513,46 +533,66 @@ static inline int pick_rows_ew(int Mg, int G, int C, int vec, int min_rows = EW_
 
 template <typename T>
 static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
-                      const float* shift, int M, int C, int relu, int Mg, hipStream_t st) {
+                      const float* shift, int M, int C, int relu, int Mg, unsigned char* mask, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 2048;
   const int rpb = pick_rows_ew(Mg, G, C, VEC, EW_UNROLL, apply_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
-  hipLaunchKernelGGL(bn_apply_kernel<T>, g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, Mg, C,
-                     relu, rpb);
+#define CSS_BN_APPLY_LAUNCH(MASK, RES, RELU)                                                                                               \
+  hipLaunchKernelGGL((bn_apply_kernel<T, MASK, RES, RELU>), g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, \
+                     Mg, C, rpb, mask)
+  // (the elementwise kernels sit close to instruction-bound: mask / residual / ReLU are compile-time choices)
+  if (mask) {
+    if (!res || !relu) return CSS_ERR_ARG;                 // the bit mask exists for residual + ReLU layers
+    CSS_BN_APPLY_LAUNCH(true, true, true);
+  } else if (res) {
+    if (relu) CSS_BN_APPLY_LAUNCH(false, true, true);
+    else CSS_BN_APPLY_LAUNCH(false, true, false);
+  } else {
+    if (relu) CSS_BN_APPLY_LAUNCH(false, false, true);
+    else CSS_BN_APPLY_LAUNCH(false, false, false);
+  }
+#undef CSS_BN_APPLY_LAUNCH
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale,
-                        const float* shift, int M, int C, int relu, int Mg, int dtype, hipStream_t st) {
+                        const float* shift, int M, int C, int relu, int Mg, unsigned char* mask, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
   if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
-  return dtype == CSS_BF16 ? bn_apply_T<bf16_t>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, st)
-         : dtype == CSS_F32 ? bn_apply_T<float>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, st) : CSS_ERR_DTYPE;
+  return dtype == CSS_BF16 ? bn_apply_T<bf16_t>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, mask, st)
+         : dtype == CSS_F32 ? bn_apply_T<float>(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, mask, st) : CSS_ERR_DTYPE;
 }
 
 template <typename T>
 static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
                            const float* invstd, const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial,
-                           hipStream_t st) {
+                           const unsigned char* mask, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
-  if (C % VEC || ldda % VEC || ldy % VEC || (relu && a && lda % VEC) || (relu && !a && (!scale || !shift))) return CSS_ERR_ARG;
+  if (C % VEC || ldda % VEC || ldy % VEC || (relu && a && lda % VEC) || (relu && !a && !mask && (!scale || !shift)) || (a && mask)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256;
   const int rpb = pick_rows_per_block(Mg, G, C, VEC);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean,
-                     invstd, scale, shift, Mg, C, relu, rpb, partial);
+  const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
+#define CSS_BN_RED_LAUNCH(MODE)                                                                                                      \
+  hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean, invstd, \
+                     scale, shift, Mg, C, rpb, partial, mask)
+  if (mode == BN_NORELU) CSS_BN_RED_LAUNCH(BN_NORELU);
+  else if (mode == BN_MASK_RECOMPUTE) CSS_BN_RED_LAUNCH(BN_MASK_RECOMPUTE);
+  else if (mode == BN_MASK_ACT) CSS_BN_RED_LAUNCH(BN_MASK_ACT);
+  else CSS_BN_RED_LAUNCH(BN_MASK_BITS);
+#undef CSS_BN_RED_LAUNCH
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean,
                              const float* invstd, const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial,
-                             int dtype, hipStream_t st) {
+                             const unsigned char* mask, int dtype, hipStream_t st) {
   if (Mg <= 0 || G <= 0) return CSS_ERR_ARG;
-  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, st)
-         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, st)
+  return dtype == CSS_BF16 ? bn_bwd_reduce_T<bf16_t>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, mask, st)
+         : dtype == CSS_F32 ? bn_bwd_reduce_T<float>(da, ldda, a, lda, y, ldy, mean, invstd, scale, shift, Mg, G, C, relu, partial, mask, st)
                             : CSS_ERR_DTYPE;
 }
 
@@ -560,10 +600,10 @@ template <typename T>
 static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                           void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
                           const float* scale, const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg,
-                          hipStream_t st) {
+                          const unsigned char* mask, hipStream_t st) {
   constexpr int VEC = 16 / sizeof(T);
   if (C % VEC || ldda % VEC || ldy % VEC || lddy % VEC || (relu && a && lda % VEC) || (dres && lddr % VEC) ||
-      (relu && !a && (!scale || !shift)))
+      (relu && !a && !mask && (!scale || !shift)) || (a && mask))
     return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   // amortise the 7-coefficient prologue (measured: 44 -> 30 us at 135200x128), and ONE block per CU: with 3-5 streams per block the
@@ -571,20 +611,27 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
   static const long bwd_blocks = getenv("CSS_BN_BWD_EW_BLOCKS") ? atol(getenv("CSS_BN_BWD_EW_BLOCKS")) : 256;
   const int rpb = pick_rows_ew(Mg, G, C, VEC, 16, bwd_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel<T>, g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy,
-                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, relu, rpb);
+  const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
+#define CSS_BN_APP_LAUNCH(MODE)                                                                                                       \
+  hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, \
+                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, rpb, mask)
+  if (mode == BN_NORELU) CSS_BN_APP_LAUNCH(BN_NORELU);
+  else if (mode == BN_MASK_RECOMPUTE) CSS_BN_APP_LAUNCH(BN_MASK_RECOMPUTE);
+  else if (mode == BN_MASK_ACT) CSS_BN_APP_LAUNCH(BN_MASK_ACT);
+  else CSS_BN_APP_LAUNCH(BN_MASK_BITS);
+#undef CSS_BN_APP_LAUNCH
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy,
                             void* dres, int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums,
                             const float* scale, const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg,
-                            int dtype, hipStream_t st) {
+                            const unsigned char* mask, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
   if (Mg <= 0 || M % Mg) return CSS_ERR_ARG;
   return dtype == CSS_BF16
-             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<bf16_t>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, mask, st)
          : dtype == CSS_F32
-             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, st)
+             ? bn_bwd_apply_T<float>(da, ldda, a, lda, y, ldy, dy, lddy, dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, M, C, relu, Mg, mask, st)
              : CSS_ERR_DTYPE;
 }

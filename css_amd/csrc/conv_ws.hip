@@ -1,4 +1,4 @@
-// conv_ws_kernel: weight-STATIONARY 1x1 convolution for the short-K class (K = Cin in {64, 128, 256}, Cout a multiple of 256):
+// conv_ws_kernel: weight-STATIONARY 1x1 convolution for the short-K class (K = Cin in {64, 128, 256, 512}, Cout a multiple of 256):
 // conv3 of a Bottleneck (generalframeworks/networks/resnet.py:131-133: planes -> 4 x planes) in the forward pass and conv1 of a
 // Bottleneck (resnet.py:123-125: 4 x planes -> planes) in its data-gradient form, 23 + 22 of each in layer 3 alone.
 //
@@ -79,7 +79,8 @@ template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_st
 // KS = K / 64 (stages per pixel tile).  grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 256) == 0.
 template <int KS, bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
-  constexpr int BM = 128, BN = 256, LA = 2 * KS, NS = LA + 2;
+  constexpr int NT = KS <= 4 ? 2 : 1;                            // whole tiles of look-ahead (K = 512: one - the ring is 160 KiB either way)
+  constexpr int BM = 128, BN = 256, LA = NT * KS, NS = LA + 2;
   constexpr int STG = BM * 128;                                  // one stage: 128 pixels x 128 bytes (64 channels)
 #if defined(WS_ABL_NOSTORE)       // timing ablations (scripts/ws_bench.hip): results are garbage
   constexpr bool ABL_NOSTORE = true, ABL_NOMFMA = false, ABL_NODMA = false;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #endif
   constexpr int NLD = ADD ? 8 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
   constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
-  constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + NLD + NST, W2 = W1 + NST;   // vmcnt of the stage wait in tile 0, tile 1, later tiles
+  constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + (NT >= 2 ? NLD : 0) + NST, W2 = W1 + (NT >= 2 ? NST : 0);   // vmcnt of the stage wait in tile 0, tile 1, later tiles
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG];
 
@@ -252,6 +253,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   };
 
   if constexpr (WS_PP != 0) {
+    static_assert(NT == 2, "the ping-pong variant counts two tiles of look-ahead");
     // ---- ping-pong: waves 0-3 and waves 4-7 (one of each per SIMD) run half a stage apart - READ segment (last tile's epilogue,
     // fragment reads, next LDS-DMA pieces, waits) of one group beside the MFMA segment of the other, two barriers per stage ----
     const int grp = wave >> 2;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       // all fragment reads of the stage first (16 x ds_read_b128, back to back), then its 32 MFMAs back to back: left to itself the
       // compiler reads one fragment, waits for it, issues its two MFMAs, and so on - every LDS latency exposed.  (The addend variant
       // holds 32 more registers: it reads and multiplies one 32-channel half of the stage at a time.)
-      constexpr int HB = ADD ? 1 : 2;                    // K halves per batch
+      constexpr int HB = (ADD || KS > 4) ? 1 : 2;        // K halves per batch (K = 512: 128 registers of weights)
 #pragma unroll
       for (int hb = 0; hb < (ABL_NOMFMA ? 0 : 2); hb += HB) {
         bf16x8 fa[HB][8];
@@ -340,10 +342,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
         for (int h = 0; h < HB; ++h)
 #pragma unroll
           for (int i = 0; i < 8; ++i) fa[h][i] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + (((4 * (hb + h) + lg) ^ sw) << 4));
-        __builtin_amdgcn_sched_barrier(0);
+        if (KS <= 4) __builtin_amdgcn_sched_barrier(0);      // (K = 512: 128 registers of weights - the compiler interleaves reads and MFMAs itself)
 #pragma unroll
         for (int h = 0; h < HB; ++h) mfma_half(fa[h], 2 * k + hb + h, k == 0 && hb + h == 0);
-        __builtin_amdgcn_sched_barrier(0);
+        if (KS <= 4) __builtin_amdgcn_sched_barrier(0);
       }
       cslot = cslot == NS - 1 ? 0 : cslot + 1;
     }
@@ -362,7 +364,8 @@ bool css_conv_ws_supported(const ConvArgs& a, int n_cu) {
   if (g_ws_off < 0) g_ws_off = getenv("CSS_NO_WS_CONV") != nullptr;
   const bool off = g_ws_off != 0;
   if (off || a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
-  if (a.Ktot != a.Cs || (a.Cs != 64 && a.Cs != 128 && a.Cs != 256) || a.Cd < 256 || a.Cd % 256 || a.lds % 8 || a.ldd % 8) return false;
+  if (a.Ktot != a.Cs || (a.Cs != 64 && a.Cs != 128 && a.Cs != 256 && a.Cs != 512) || a.Cd < 256 || a.Cd % 256 || a.lds % 8 || a.ldd % 8) return false;
+  if (a.Cs == 512 && a.addend) return false;        // (128 registers of weights + 32 of addend + 64 accumulators + fragments: no room)
   if (a.stats && a.addend) return false;
   if (a.addend && a.ld_add % 8) return false;
   const int np = a.Cd / 256;
@@ -382,7 +385,10 @@ void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st) {
   a.dst_bytes = (unsigned)((size_t)a.M * a.ldd * 2);
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
-  if (a.Cs == 256) launch_ws<4>(a, n_cu, st);
+  if (a.Cs == 512) {
+    if (a.stats) hipLaunchKernelGGL((conv_ws_kernel<8, true, false>), dim3(n_cu), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((conv_ws_kernel<8, false, false>), dim3(n_cu), dim3(512), 0, st, a);
+  } else if (a.Cs == 256) launch_ws<4>(a, n_cu, st);
   else if (a.Cs == 128) launch_ws<2>(a, n_cu, st);
   else launch_ws<1>(a, n_cu, st);
 }

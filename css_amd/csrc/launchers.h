@@ -81,12 +81,14 @@ int css_launch_bn_finalize(const double* sums, int G, double count, const double
 int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float* rm, const float* rv, float eps, float* scale, float* shift, int C,
                              hipStream_t st);
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
-                        int relu, int Mg, int dtype, hipStream_t st);
+                        int relu, int Mg, unsigned char* mask, int dtype, hipStream_t st);
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
-                             const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, hipStream_t st);
+                             const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, const unsigned char* mask,
+                             int dtype, hipStream_t st);
 int css_launch_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, void* dy, int lddy, void* dres, int lddr,
                             const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale, const float* shift,
-                            double count, const double* count_dev, int M, int C, int relu, int Mg, int dtype, hipStream_t st);
+                            double count, const double* count_dev, int M, int C, int relu, int Mg, const unsigned char* mask, int dtype,
+                            hipStream_t st);
 
 int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,
                            int dtype, hipStream_t st);

@@ -328,7 +328,7 @@ class _BNAct(torch.autograd.Function):
         assert m % g == 0, (m, g)
         mg = m // g
         scale, shift = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
-        mean = invstd = None
+        mean = invstd = mask = None
         count = float(mg)
         count_t = None       # SyncBN: per-group global pixel counts on the device (all-reduced together with the sums)
         if training and fused is not None and fused[1:4] == (mg, g, c):
@@ -369,11 +369,17 @@ class _BNAct(torch.autograd.Function):
             call("css_bn_apply", y, c, res, c, buf.data_ptr() + off * buf.element_size(), ldo, scale, shift, m, c, int(relu), mg, dc, dev, st)
         else:
             out = torch.empty_like(y)
-            call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
+            if training and relu and res is not None and _bn_bit_mask:
+                # residual layer: the backward passes read the ReLU mask as one byte per 16-byte vector instead of `out` itself
+                mask = torch.empty((m, c // vec_of(dt)), dtype=torch.uint8, device=y.device)
+                call("css_bn_apply_mask", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, mask, dc, dev, st)
+            else:
+                call("css_bn_apply", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, dc, dev, st)
         if training:
-            # ReLU mask in backward: from `out` when a residual was added, else recomputed from y*scale+shift (one read less)
+            # ReLU mask in backward: the bit mask (or `out`, CSS_BN_NO_MASK=1) when a residual was added, else recomputed from
+            # y*scale+shift (no extra read at all)
             assert out_into is None or not (relu and res is not None)
-            ctx.save_for_backward(y, out if (relu and res is not None) else None, mean, invstd, gamma, scale, shift, count_t)
+            ctx.save_for_backward(y, out if (relu and res is not None and mask is None) else None, mean, invstd, gamma, scale, shift, count_t, mask)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         return out
@@ -383,7 +389,7 @@ class _BNAct(torch.autograd.Function):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
             raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
-        y, a, mean, invstd, gamma, scale, shift, count_t = ctx.saved_tensors
+        y, a, mean, invstd, gamma, scale, shift, count_t, mask = ctx.saved_tensors
         c = y.shape[-1]
         m = y.numel() // c
         mg = m // g
@@ -395,7 +401,10 @@ class _BNAct(torch.autograd.Function):
         dc = dtype_code(dt)
         nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
         partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
-        call("css_bn_bwd_reduce", da, ldda, a, c, y, c, mean, invstd, scale, shift, mg, g, c, int(relu), partial, dc, dev, st)
+        if mask is not None:
+            call("css_bn_bwd_reduce_mask", da, ldda, mask, y, c, mean, invstd, mg, g, c, partial, dc, dev, st)
+        else:
+            call("css_bn_bwd_reduce", da, ldda, a, c, y, c, mean, invstd, scale, shift, mg, g, c, int(relu), partial, dc, dev, st)
         sums = torch.empty(g * 2 * c, dtype=torch.float64, device=y.device)
         # parameter gradients are LOCAL sums over all groups (DDP / the trainer all-reduce them with the rest)
         sg, sb = _grad_sink(gamma, (c,)), _grad_sink(ctx.beta_ref, (c,))
@@ -411,13 +420,18 @@ class _BNAct(torch.autograd.Function):
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
         dres = torch.empty_like(y) if has_res else None
-        call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
-             int(relu), mg, dc, dev, st)
+        if mask is not None:
+            call("css_bn_bwd_apply_mask", da, ldda, mask, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, count_t, m, c, mg, dc, dev, st)
+        else:
+            call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
+                 int(relu), mg, dc, dev, st)
         return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
 _nbt_sink = None
+# CSS_BN_NO_MASK=1: residual layers re-read their activation tensor for the ReLU mask in backward (round-2 behaviour; A/B and parity tests)
+_bn_bit_mask = os.environ.get("CSS_BN_NO_MASK") != "1"
 
 
 class bn_groups:

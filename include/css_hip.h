@@ -136,6 +136,17 @@ CSS_API int css_bn_bwd_apply(const void* da, int ldda, const void* a, int lda, c
                              const float* mean, const float* invstd, const float* gamma, const double* sums, const float* scale,
                              const float* shift, double count, const double* count_dev, int M, int C, int relu, int Mg, int dtype, int device,
                              css_stream_t stream);
+/* Residual layers (bn3 + identity + ReLU of a Bottleneck, resnet.py:133-137): the ReLU mask travels as ONE BYTE per 16-byte vector of
+ * the output (bit e = element e of the vector is > 0 after the ReLU; mask is [M][C / (16 / sizeof(element))] bytes, contiguous) instead of
+ * the backward passes re-reading the activation tensor: css_bn_apply_mask = css_bn_apply that also writes the mask (mask may be NULL);
+ * css_bn_bwd_reduce_mask / css_bn_bwd_apply_mask = the ReLU forms of css_bn_bwd_reduce / css_bn_bwd_apply reading it. */
+CSS_API int css_bn_apply_mask(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M,
+                              int C, int relu, int Mg, unsigned char* mask, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_bwd_reduce_mask(const void* da, int ldda, const unsigned char* mask, const void* y, int ldy, const float* mean,
+                                   const float* invstd, int Mg, int G, int C, double* partial, int dtype, int device, css_stream_t stream);
+CSS_API int css_bn_bwd_apply_mask(const void* da, int ldda, const unsigned char* mask, const void* y, int ldy, void* dy, int lddy, void* dres,
+                                  int lddr, const float* mean, const float* invstd, const float* gamma, const double* sums, double count,
+                                  const double* count_dev, int M, int C, int Mg, int dtype, int device, css_stream_t stream);
 
 /* ---- pooling / resize / concat: deeplabv3.py:153,164-166; aspp.py:27-38,67-72; ddp_model.py:141,144 */
 CSS_API int css_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride, int pad,

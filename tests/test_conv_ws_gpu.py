@@ -3,7 +3,7 @@ pass (/root/reference/generalframeworks/networks/resnet.py:131-133, planes -> 4 
 data-gradient form (resnet.py:123-125; the residual gradient is added in the store: css_conv2d_dgrad_add) - against torch-CPU fp32
 ``F.conv2d`` on the same bf16-rounded inputs, through the C ABI, with the dispatch asserted (css_conv_ws_applies + launch counts).
 
-Covers K = 64 / 128 / 256, 1 / 2 / 4 / 8 output panels, ragged row counts (M % 128 != 0), streams of 0, 1, 3+ tiles (the counted vmcnt has
+Covers K = 64 / 128 / 256 / 512, 1 / 2 / 4 / 8 output panels, ragged row counts (M % 128 != 0), streams of 0, 1, 3+ tiles (the counted vmcnt has
 its steady state from the third tile on), the statistics slabs across a group boundary, the addend variant at bench scale, and the
 CSS_NO_WS_CONV switch."""
 import ctypes
@@ -97,6 +97,8 @@ FWD_CASES = [
     (8, 65, 65, 256, 1024),     # 265 tiles on 64 streams: 4-5 tiles per stream (steady-state vmcnt counts)
     (16, 129, 129, 64, 256),    # K = 64 at depth: 2081 tiles on 256 streams
     (1, 9, 9, 256, 512),        # fewer rows than one tile: most workgroups have nothing to do
+    (2, 33, 33, 512, 2048),     # K = 512 (layer4 conv3): eight stages per tile, one tile of look-ahead
+    (8, 65, 65, 512, 2048),     # ... with 8-9 tiles per stream
 ]
 
 
@@ -141,7 +143,9 @@ def test_ws_dgrad_and_addend_vs_cpu(case):
 def test_ws_shape_rules():
     """What the kernel does NOT take stays on the 256x256 kernels."""
     assert ws_applies(135200, 256, 1024) == 1
-    assert ws_applies(135200, 512, 2048) == 0        # K = 512: the weights of a panel do not fit the register file
+    assert ws_applies(135200, 512, 2048) == 1 and ws_applies(135200, 512, 2048, stats=1) == 1
+    assert ws_applies(135200, 512, 2048, addend=1) == 0        # K = 512: 128 registers of weights leave no room for the addend
+    assert ws_applies(135200, 1024, 2048) == 0
     assert ws_applies(135200, 256, 304) == 0         # not whole panels
     assert ws_applies(135200, 256, 128) == 0
     assert ws_applies(135200, 192, 1024) == 0

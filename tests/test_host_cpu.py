@@ -321,7 +321,8 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
     from css_amd import _lib
     ap = lambda m, k, n, r=1, stride=1, stats=0, add=0, bias=0, dtype=1: _lib.query("css_conv_ws_applies", m, k, k, n, n, r, r, stride, 0, stats, add, n, bias, dtype, 256)
     assert ap(135200, 256, 1024) == 1 and ap(135200, 128, 512, stats=1) == 1 and ap(532512, 64, 256, add=1) == 1 and ap(81, 256, 2048) == 1
-    assert ap(135200, 512, 2048) == 0 and ap(135200, 256, 304) == 0 and ap(135200, 192, 1024) == 0 and ap(135200, 256, 128) == 0
+    assert ap(135200, 512, 2048) == 1 and ap(135200, 512, 2048, stats=1) == 1 and ap(135200, 512, 2048, add=1) == 0      # K = 512: no addend form
+    assert ap(135200, 1024, 2048) == 0 and ap(135200, 256, 304) == 0 and ap(135200, 192, 1024) == 0 and ap(135200, 256, 128) == 0
     assert ap(135200, 256, 1024, r=3) == 0 and ap(135200, 256, 1024, stride=2) == 0 and ap(135200, 256, 1024, bias=1) == 0
     assert ap(135200, 256, 1024, dtype=0) == 0 and ap(135200, 256, 1024, stats=1, add=1) == 0
     assert ap(135200, 64, 256 * 64) == 0          # more panels than CUs per XCD
@@ -335,7 +336,8 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
                    check=True, capture_output=True, timeout=600)
     lines = open(out).read().split("\n")
     # (KS, STATS, ADD) -> the vmcnt values of the stage wait in tile 0 / tile 1 / later tiles (conv_ws.hip: W0, W1, W2)
-    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (22, 38, 46)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (10, 26, 34))):
+    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (22, 38, 46)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (10, 26, 34)),
+                              (8, 1, 0, (14, 26)), (8, 0, 0, (14, 22))):
         sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELb{ad}EEv8ConvArgs:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
@@ -346,5 +348,5 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
         assert not any("vmcnt(0)" in l for l in body[bar[0]:mfma[-1] + 1]), sym + " compiler drained the LDS-DMA pipeline inside the K loop"
         for wv in waits:
             assert any(f"s_waitcnt vmcnt({wv})" in l for l in body), (sym, wv)
-        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == (2 * ks + 2) * 16384, sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == ((2 if ks <= 4 else 1) * ks + 2) * 16384, sym
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym

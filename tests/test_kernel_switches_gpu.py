@@ -65,3 +65,14 @@ def test_conv_parity_under_every_launcher_switch(env):
     r = subprocess.run([sys.executable, "-c", WORKER % (ROOT, os.path.join(ROOT, "tests"))], env=e, capture_output=True, text=True, timeout=600)
     print(r.stdout[-400:], r.stderr[-800:])
     assert r.returncode == 0, (env, r.stderr[-800:])
+
+
+def test_bn_activation_mask_switch_is_a_shipped_configuration():
+    """CSS_BN_NO_MASK=1 (residual layers re-read their activation for the ReLU mask in backward, css_amd/ops.py): the batch-norm parity tests
+    against F.batch_norm under that switch, in a process of its own."""
+    e = dict(os.environ)
+    e["CSS_BN_NO_MASK"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ops_gpu.py"), "-q", "-x", "-k", "bn_act_train", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, r.stdout[-800:]

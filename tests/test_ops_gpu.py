@@ -115,6 +115,38 @@ def test_bn_act_train(shape, res, relu, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,groups", [((8, 65, 65, 1024), 2), ((3, 11, 7, 264), 1)])
+def test_bn_residual_bit_mask_equals_activation_mask(shape, groups, dtype):
+    """Residual layers (bn3 + identity + ReLU, /root/reference/generalframeworks/networks/resnet.py:133-137) hand the ReLU mask to their
+    backward passes as one byte per 16-byte vector (css_bn_apply_mask / css_bn_bwd_*_mask); the round-2 form (CSS_BN_NO_MASK=1) re-reads the
+    activation tensor.  Same arithmetic: bit-identical outputs and gradients, here at a bench-scale layer (8 x 65^2 x 1024, two statistics
+    groups) and at a ragged one (C = 264: 33 vectors per row)."""
+    from css_amd import ops
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(11 + c)
+    x = (torch.randn(n, h, w, c, generator=g) * 2 + 0.5).to(dev(), dtype)
+    r = torch.randn(n, h, w, c, generator=g).to(dev(), dtype)
+    go = torch.randn(n, h, w, c, generator=g).to(dev(), dtype)
+    gamma, beta = (torch.rand(c, generator=g) + 0.5).to(dev()), (torch.randn(c, generator=g) * 0.1).to(dev())
+    outs = []
+    prev = ops._bn_bit_mask
+    try:
+        for use_mask in (True, False):
+            ops._bn_bit_mask = use_mask
+            xg, rg = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+            gg, bg = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+            rm, rv = torch.zeros(c, device=dev()), torch.ones(c, device=dev())
+            o = ops.bn_act(xg, gg, bg, rm, rv, rg, True, True, 0.1, 1e-5, False, groups=groups)
+            o.backward(go)
+            outs.append((o.detach(), xg.grad, rg.grad, gg.grad, bg.grad, rm, rv))
+    finally:
+        ops._bn_bit_mask = prev
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert (outs[0][2] == 0).float().mean().item() > 0.2      # the mask does something: a fair share of the residual gradient is zeroed
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_bn_eval(dtype):
     from css_amd import ops
     g = torch.Generator().manual_seed(3)
