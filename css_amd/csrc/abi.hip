@@ -29,7 +29,7 @@ int cu_count(int device) {
 
 // ---- profiling ----
 struct ProfRec { hipEvent_t a, b; int kind; double work; bool alias; };   // alias: second record over the same event pair (not pooled)
-constexpr int PROF_KINDS = 13;
+constexpr int PROF_KINDS = 15;
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;       // recorded this epoch
@@ -51,16 +51,18 @@ struct ProfScope {
     r.alias = false;
     (void)hipEventRecord(r.a, st);
   }
-  int alias_kind = -1;      // also file this launch under a second kind (HBM view of a kernel that is listed under an MFMA kind)
-  double alias_work = 0;
+  // also file this launch under further kinds (e.g. the HBM view of a kernel that is listed under an MFMA kind)
+  int n_alias = 0, alias_kind[3] = {-1, -1, -1};
+  double alias_work[3] = {0, 0, 0};
+  void add_alias(int kind, double work) { if (n_alias < 3) { alias_kind[n_alias] = kind; alias_work[n_alias++] = work; } }
   ~ProfScope() {
     if (!on) return;
     (void)hipEventRecord(r.b, st);
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof.push_back(r);
-    if (alias_kind >= 0) {
+    for (int i = 0; i < n_alias; ++i) {
       ProfRec q = r;
-      q.kind = alias_kind; q.work = alias_work; q.alias = true;
+      q.kind = alias_kind[i]; q.work = alias_work[i]; q.alias = true;
       g_prof.push_back(q);
     }
   }
@@ -73,14 +75,20 @@ struct ConvProf : LaunchProf {
   alignas(ProfScope) unsigned char buf[sizeof(ProfScope)];
   ProfScope* cur = nullptr;
   double hbm_bytes = 0;     // > 0: an HBM-bound shape class (short-K 1x1 forward): its launches are also filed under kind 12 with their bytes
+  double ws_bytes = 0;      // algorithmic bytes of the call if it runs on conv_ws_kernel (kinds 13 / 14: FLOPs / bytes of those launches)
   ConvProf(int ko, int kb, double f, hipStream_t s) : kind_other(ko), kind_big(kb), flops(f), st(s) {}
-  void begin(bool big, double share) override {
+  void begin(bool big, double share, bool ws) override {
     cur = new (buf) ProfScope(big ? kind_big : kind_other, flops * share, st);
-    if (hbm_bytes > 0) { cur->alias_kind = 12; cur->alias_work = hbm_bytes * share; }
+    if (hbm_bytes > 0) cur->add_alias(12, hbm_bytes * share);
+    if (ws) { cur->add_alias(13, flops * share); cur->add_alias(14, ws_bytes * share); }
   }
   void end() override { if (cur) { cur->~ProfScope(); cur = nullptr; } }
 };
 // the write-bound 1x1 class (resnet.py:131-133, conv3 of a Bottleneck: K = planes <= 512 in, 4 x planes out): algorithmic bytes of one call
+double conv1x1_bytes(const ConvArgs& a, int dtype) {       // a 1x1 product read and written once (+ the addend)
+  const double e = dtype == CSS_BF16 ? 2 : 4;
+  return ((double)a.M * a.Ktot + (double)a.M * a.Cd * (a.addend ? 2 : 1) + (double)a.Cd * a.Ktot) * e;
+}
 double short_k_bytes(const ConvArgs& a, int dtype) {
   if (a.R != 1 || a.S != 1 || a.Ktot > 512 || a.Cd < 4 * a.Ktot) return 0;
   const double e = dtype == CSS_BF16 ? 2 : 4;
@@ -128,6 +136,7 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   a.M = N * Ho * Wo; a.Ktot = R * Sk * Cin;
   ConvProf cp(0, 5, alg_flops, S(stream));
   cp.hbm_bytes = short_k_bytes(a, dtype);
+  cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
@@ -144,6 +153,7 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   if (!stats || Mg < 128 || a.M % Mg) return CSS_ERR_ARG;
   ConvProf cp(0, 5, alg_flops, S(stream));
   cp.hbm_bytes = short_k_bytes(a, dtype);
+  cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
@@ -169,6 +179,7 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ConvProf cp(1, 6, alg_flops, S(stream));
+  cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
@@ -182,6 +193,7 @@ int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* 
   a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ConvProf cp(1, 6, alg_flops, S(stream));
+  cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 size_t css_conv2d_wgrad_ws_bytes(int M, int Ktot, int Cout, int dtype, int device) {

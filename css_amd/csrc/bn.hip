@@ -284,9 +284,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
   const int cv = blockIdx.y * TPC + cvi;
   if (rg >= RPB || cv >= CV) return;
   const int c = cv * VEC, g = blockIdx.z;
-  float sc[VEC], sh[VEC];
+  using P = Pairs<T>;
+  f32x2 sc[P::NP], sh[P::NP];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) { sc[e] = scale[g * C + c + e]; sh[e] = shift[g * C + c + e]; }
+  for (int p = 0; p < P::NP; ++p) {
+    sc[p] = f32x2{scale[g * C + c + 2 * p], scale[g * C + c + 2 * p + 1]};
+    sh[p] = f32x2{shift[g * C + c + 2 * p], shift[g * C + c + 2 * p + 1]};
+  }
   const int gbase = g * Mg;
   const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   // EW_UNROLL rows per trip, all loads issued before the first use: a thread's trips are a serial chain of ~2 us memory
@@ -307,11 +311,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
       if (ru < row1) {
         Vec16<T> o;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float x = v[u].f(e) * sc[e] + sh[e];
-          if (RES) x += rr[u].f(e);
-          if (RELU) x = fmaxf(x, 0.f);
-          o.set(e, x);
+        for (int p = 0; p < P::NP; ++p) {
+          f32x2 x = P::get(v[u], p) * sc[p] + sh[p];
+          if (RES) x += P::get(rr[u], p);
+          if (RELU) x = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+          P::set(o, p, x);
         }
         o.store(out + (size_t)ru * ldo + c);
         if (MASK) {      // ReLU mask for the backward passes: one byte per vector, of the STORED values (what reading `out` back would give)
@@ -343,13 +347,15 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
   const int TPC = CV < 256 ? CV : 256;
   const int cv = min(blockIdx.y * TPC + (int)(threadIdx.x % TPC), CV - 1);   // this thread's channel vector (as in channel_reduce2)
   const int g = blockIdx.z, c0 = cv * VEC;
-  float mu[VEC], is[VEC], sc[VEC], sh[VEC];
+  using P = Pairs<T>;
+  f32x2 mu[P::NP], is[P::NP], sc[P::NP], sh[P::NP];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    mu[e] = mean[g * C + c0 + e];
-    is[e] = invstd[g * C + c0 + e];
-    sc[e] = MODE == BN_MASK_RECOMPUTE ? scale[g * C + c0 + e] : 0.f;
-    sh[e] = MODE == BN_MASK_RECOMPUTE ? shift[g * C + c0 + e] : 0.f;
+  for (int p = 0; p < P::NP; ++p) {
+    const int ch = g * C + c0 + 2 * p;
+    mu[p] = f32x2{mean[ch], mean[ch + 1]};
+    is[p] = f32x2{invstd[ch], invstd[ch + 1]};
+    sc[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{scale[ch], scale[ch + 1]} : f32x2{0.f, 0.f};
+    sh[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{shift[ch], shift[ch + 1]} : f32x2{0.f, 0.f};
   }
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> gv, av, yv;
@@ -359,14 +365,24 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     unsigned bits = 0;
     if (MODE == BN_MASK_BITS) bits = mask[(size_t)r * CV + cv];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) {
-      float dz = gv.f(e);
-      if (MODE == BN_MASK_RECOMPUTE) { if (!(yv.f(e) * sc[e] + sh[e] > 0.f)) dz = 0.f; }
-      else if (MODE == BN_MASK_ACT) { if (!(av.f(e) > 0.f)) dz = 0.f; }
-      else if (MODE == BN_MASK_BITS) { if (!((bits >> e) & 1u)) dz = 0.f; }
-      const float xh = (yv.f(e) - mu[e]) * is[e];
-      s0[e] += dz;
-      s1[e] += dz * xh;
+    for (int p = 0; p < P::NP; ++p) {
+      f32x2 dz = P::get(gv, p);
+      const f32x2 yy = P::get(yv, p);
+      if (MODE == BN_MASK_RECOMPUTE) {
+        const f32x2 act = yy * sc[p] + sh[p];
+        dz = f32x2{act[0] > 0.f ? dz[0] : 0.f, act[1] > 0.f ? dz[1] : 0.f};
+      } else if (MODE == BN_MASK_ACT) {
+        const f32x2 act = P::get(av, p);
+        dz = f32x2{act[0] > 0.f ? dz[0] : 0.f, act[1] > 0.f ? dz[1] : 0.f};
+      } else if (MODE == BN_MASK_BITS) {
+        dz = f32x2{keep_if_bit(dz[0], bits, 2 * p), keep_if_bit(dz[1], bits, 2 * p + 1)};
+      }
+      const f32x2 xh = (yy - mu[p]) * is[p];
+      f32x2 a0 = f32x2{s0[2 * p], s0[2 * p + 1]}, a1 = f32x2{s1[2 * p], s1[2 * p + 1]};
+      a0 += dz;
+      a1 += dz * xh;
+      s0[2 * p] = a0[0]; s0[2 * p + 1] = a0[1];
+      s1[2 * p] = a1[0]; s1[2 * p + 1] = a1[1];
     }
   };
   channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
@@ -388,16 +404,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   if (rg >= RPB || cv >= CV) return;
   const int c = cv * VEC, g = blockIdx.z;
   const float inv_n = (float)(1.0 / (count_dev ? count_dev[g] : count));
-  float mu[VEC], is[VEC], gi[VEC], m1[VEC], m2[VEC], sc[VEC], sh[VEC];
+  using P = Pairs<T>;
+  f32x2 mu[P::NP], is[P::NP], gi[P::NP], m1[P::NP], m2[P::NP], sc[P::NP], sh[P::NP];
 #pragma unroll
-  for (int e = 0; e < VEC; ++e) {
-    mu[e] = mean[g * C + c + e];
-    is[e] = invstd[g * C + c + e];
-    gi[e] = gamma[c + e] * is[e];
-    m1[e] = (float)sums[(size_t)g * 2 * C + c + e] * inv_n;          // sums are [G][2][C]
-    m2[e] = (float)sums[(size_t)g * 2 * C + C + c + e] * inv_n;
-    sc[e] = MODE == BN_MASK_RECOMPUTE ? scale[g * C + c + e] : 0.f;
-    sh[e] = MODE == BN_MASK_RECOMPUTE ? shift[g * C + c + e] : 0.f;
+  for (int p = 0; p < P::NP; ++p) {
+    const int ch = g * C + c + 2 * p;
+    mu[p] = f32x2{mean[ch], mean[ch + 1]};
+    is[p] = f32x2{invstd[ch], invstd[ch + 1]};
+    gi[p] = f32x2{gamma[c + 2 * p], gamma[c + 2 * p + 1]} * is[p];
+    m1[p] = f32x2{(float)sums[(size_t)g * 2 * C + c + 2 * p], (float)sums[(size_t)g * 2 * C + c + 2 * p + 1]} * inv_n;          // sums are [G][2][C]
+    m2[p] = f32x2{(float)sums[(size_t)g * 2 * C + C + c + 2 * p], (float)sums[(size_t)g * 2 * C + C + c + 2 * p + 1]} * inv_n;
+    sc[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{scale[ch], scale[ch + 1]} : f32x2{0.f, 0.f};
+    sh[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{shift[ch], shift[ch + 1]} : f32x2{0.f, 0.f};
   }
   const int gbase = g * Mg;
   const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
@@ -421,14 +439,21 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       if (ru < row1) {
         Vec16<T> o, dr;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) {
-          float dz = gv[u].f(e);
-          if (MODE == BN_MASK_RECOMPUTE) { if (!(yv[u].f(e) * sc[e] + sh[e] > 0.f)) dz = 0.f; }
-          else if (MODE == BN_MASK_ACT) { if (!(av[u].f(e) > 0.f)) dz = 0.f; }
-          else if (MODE == BN_MASK_BITS) { if (!((bits[u] >> e) & 1u)) dz = 0.f; }
-          const float xh = (yv[u].f(e) - mu[e]) * is[e];
-          o.set(e, gi[e] * (dz - m1[e] - xh * m2[e]));
-          dr.set(e, dz);
+        for (int p = 0; p < P::NP; ++p) {
+          f32x2 dz = P::get(gv[u], p);
+          const f32x2 yy = P::get(yv[u], p);
+          if (MODE == BN_MASK_RECOMPUTE) {
+            const f32x2 act = yy * sc[p] + sh[p];
+            dz = f32x2{act[0] > 0.f ? dz[0] : 0.f, act[1] > 0.f ? dz[1] : 0.f};
+          } else if (MODE == BN_MASK_ACT) {
+            const f32x2 act = P::get(av[u], p);
+            dz = f32x2{act[0] > 0.f ? dz[0] : 0.f, act[1] > 0.f ? dz[1] : 0.f};
+          } else if (MODE == BN_MASK_BITS) {
+            dz = f32x2{keep_if_bit(dz[0], bits[u], 2 * p), keep_if_bit(dz[1], bits[u], 2 * p + 1)};
+          }
+          const f32x2 xh = (yy - mu[p]) * is[p];
+          P::set(o, p, gi[p] * (dz - m1[p] - xh * m2[p]));
+          P::set(dr, p, dz);
         }
         o.store(dy + (size_t)ru * lddy + c);
         if (dres) dr.store(dres + (size_t)ru * lddr + c);

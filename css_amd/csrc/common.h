@@ -69,6 +69,7 @@ template <typename T> struct Vec16 {
   union {
     uint4 raw;
     T e[N];
+    uint32_t w[4];
   };
   __device__ __forceinline__ Vec16() {}
   __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
@@ -77,6 +78,27 @@ template <typename T> struct Vec16 {
   __device__ __forceinline__ float f(int i) const { return ElemT<T>::to_f(e[i]); }
   __device__ __forceinline__ void set(int i, float v) { e[i] = ElemT<T>::from_f(v); }
 };
+
+// Pair view of a Vec16: the elementwise kernels do their arithmetic on float2 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two
+// elements per instruction - same rounding as the scalar forms) and convert two elements per v_cvt_pk_bf16_f32.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename T> struct Pairs;
+template <> struct Pairs<float> {
+  static constexpr int NP = 2;
+  static __device__ __forceinline__ f32x2 get(const Vec16<float>& v, int p) { return f32x2{v.e[2 * p], v.e[2 * p + 1]}; }
+  static __device__ __forceinline__ void set(Vec16<float>& v, int p, f32x2 x) { v.e[2 * p] = x[0]; v.e[2 * p + 1] = x[1]; }
+};
+template <> struct Pairs<bf16_t> {
+  static constexpr int NP = 4;
+  static __device__ __forceinline__ f32x2 get(const Vec16<bf16_t>& v, int p) {
+    return f32x2{__builtin_bit_cast(float, v.w[p] << 16), __builtin_bit_cast(float, v.w[p] & 0xffff0000u)};
+  }
+  static __device__ __forceinline__ void set(Vec16<bf16_t>& v, int p, f32x2 x) { v.e[2 * p] = (bf16_t)x[0]; v.e[2 * p + 1] = (bf16_t)x[1]; }
+};
+// x where bit `b` of bits is set, else +0 (bit test without a compare: a signed 1-bit field extract gives 0 / ~0)
+__device__ __forceinline__ float keep_if_bit(float x, unsigned bits, int b) {
+  return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)__builtin_amdgcn_sbfe((int)bits, b, 1));
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

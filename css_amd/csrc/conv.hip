@@ -1415,7 +1415,7 @@ int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) {
 }
 
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
-  auto P0 = [&](bool big, double share) { if (prof) prof->begin(big, share); };
+  auto P0 = [&](bool big, double share, bool ws = false) { if (prof) prof->begin(big, share, ws); };
   auto P1 = [&]() { if (prof) prof->end(); };
   ConvArgs a = a_in;
   a.m_begin = 0;
@@ -1436,7 +1436,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
     if (!no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) {
       // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
-      P0(true, 1.0);
+      P0(true, 1.0, true);
       css_launch_conv_ws(a, n_cu, st);
       P1();
     } else if (a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) {
@@ -1598,7 +1598,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
   dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
-  if (prof) prof->begin(big, 1.0);
+  if (prof) prof->begin(big, 1.0, false);
   if (!big || (size_t)a.tiles_k * a.tiles_n * a.splits * (256 * 256 * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path
   if (big) {
     hipLaunchKernelGGL(conv_wgrad_dma256_kernel, g, dim3(512), 0, st, a);

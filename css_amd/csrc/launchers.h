@@ -48,7 +48,7 @@ struct WgradArgs {
 // Optional per-KERNEL timing hook (abi.hip brackets each kernel launch with HIP events when profiling is on):
 // begin(big, share): big = the 256x256 LDS-DMA kernel, share = fraction of the call's output rows this launch covers.
 struct LaunchProf {
-  virtual void begin(bool big, double share) = 0;
+  virtual void begin(bool big, double share, bool ws) = 0;     // ws: the launch is conv_ws_kernel (conv_ws.hip)
   virtual void end() = 0;
 };
 int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
