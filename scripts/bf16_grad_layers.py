@@ -34,6 +34,14 @@ f2 = run(2, False)
 cos = lambda a, b: float(torch.nn.functional.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0))
 print(f"{'parameter':58s} {'|g| fp32':>10s} {'b1~f32':>8s} {'b2~f32':>8s} {'b1~b2':>8s} {'f32w2~f32':>9s} {'|b2|/|b1|':>9s}")
 names = list(f32)
+worst = sorted(names, key=lambda n: -abs(float((b2[n].norm() + 1e-30) / (b1[n].norm() + 1e-30)) - 1.0))[:12]
+print("largest |b2|/|b1| deviations:")
+for n in worst:
+    print(f"{n[:58]:58s} {float(f32[n].norm()):10.3e} {cos(b1[n], f32[n]):8.4f} {cos(b2[n], f32[n]):8.4f} {cos(b1[n], b2[n]):8.4f} {cos(f2[n], f32[n]):9.5f} "
+          f"{float(b2[n].norm() / b1[n].norm()):9.4f}  |b1|/|f32| {float(b1[n].norm() / f32[n].norm()):.3f} |b2|/|f32| {float(b2[n].norm() / f32[n].norm()):.3f}")
+tot = lambda d: float(torch.cat([d[n].flatten().double() for n in names]).norm())
+print("whole-gradient norms: f32", tot(f32), "f32 world2", tot(f2), "bf16 world1", tot(b1), "bf16 world2", tot(b2))
+print("sampled rows:")
 for n in names[:12] + names[len(names) // 3: len(names) // 3 + 4] + names[-8:]:
     print(f"{n[:58]:58s} {float(f32[n].norm()):10.3e} {cos(b1[n], f32[n]):8.4f} {cos(b2[n], f32[n]):8.4f} {cos(b1[n], b2[n]):8.4f} {cos(f2[n], f32[n]):9.5f} "
           f"{float(b2[n].norm() / b1[n].norm()):9.4f}")

@@ -49,10 +49,18 @@ if world > 1:
     dist.all_reduce(l)
     loss = l / world
 probe = grads[:: grads.numel() // 4096][:4096].cpu()
+# per-parameter samples along the backward chain (16 parameters, evenly spread; <= 512 elements each)
+layers, o = {}, 0
+plist = list(net.named_parameters())
+for i, (n_, p_) in enumerate(plist):
+    if i %% max(len(plist) // 16, 1) == 0:
+        gsl = grads[o:o + p_.numel()]
+        layers[n_] = gsl[:: max(gsl.numel() // 509, 1) | 1][:512].cpu().tolist()      # (odd stride: no aliasing with the [Cout][R][S][Cin] layout)
+    o += p_.numel()
 tail = grads[-(grads.numel() // 4):]                       # ASPP + decoder heads: the layers closest to the loss
 tail = tail[:: tail.numel() // 4096][:4096].cpu()
 out = dict(loss=float(loss), pred=pred.detach().float().cpu().flatten()[::97].tolist(), grad=probe.tolist(), grad_tail=tail.tolist(),
-           rm=net.resnet_bn1.running_mean.cpu().tolist())
+           rm=net.resnet_bn1.running_mean.cpu().tolist(), layers=layers)
 if rank == 0:
     json.dump(out, open(sys.argv[1], "w"))
 if world > 1:
@@ -113,13 +121,24 @@ def test_two_ranks_bf16_fused_statistics_path(tmp_path):
     cos_tail = float(torch.nn.functional.cosine_similarity(t1, t2, dim=0))
     print("bf16 world1 vs world2 gradient cosine: all parameters", cos_all, "ASPP + heads", cos_tail)
     # bf16 through 100+ batch-stat layers on 4 random images: the backward chain is chaotic at its far end.  Measured per parameter
-    # (scripts/bf16_grad_layers.py, round 2): the layers next to the loss agree to 0.999 between the two runs and with fp32, the backbone
-    # gradients of EITHER run have cosine ~0.6 with the fp32 gradients and ~0.7 with each other, and the all-parameter probe (dominated by
-    # the stem) moves between 0.36 and 0.94 from run to run and build to build (fp32 atomics in the loss backward are enough to decorrelate
-    # it) - it is reported, not asserted.  Asserted: finite gradients of comparable size, and the layers next to the loss.  The exact form of
-    # this check is test_syncbn_with_unequal_pixel_counts_per_rank (op level, against torch-CPU) and the fp32 test above (cosine > 0.999).
+    # (scripts/bf16_grad_layers.py, round 2): the layers next to the loss agree to 0.999 between the two runs and with fp32; the backbone
+    # gradients of EITHER run have cosine ~0.6 with the fp32 gradients, 0.65-0.82 with each other, and norms within 0.74-1.0 of each other.
+    # The old all-parameter probe (one element in 14500) holds a single stem-weight element that outweighs everything else in it - it read
+    # 0.36, 0.76 and 0.89 on three builds that pass every parity test - and is reported only.  Asserted: the layers next to the loss, and per
+    # parameter along the chain a positive correlation and comparable size (a wrong count or a missed all-reduce in SyncBN's backward shows as
+    # a factor of 2 or as no correlation at all).  The exact form of this check is test_syncbn_with_unequal_pixel_counts_per_rank (op level,
+    # against torch-CPU) and the fp32 test above (cosine > 0.999).
     assert torch.isfinite(g2).all() and cos_tail > 0.9
-    assert 0.5 < float(g2.norm() / g1.norm()) < 2.0
+    cs = []
+    for name in r1["layers"]:
+        a_, b_ = torch.tensor(r1["layers"][name]).double(), torch.tensor(r2["layers"][name]).double()
+        if float(a_.norm()) == 0.0 and float(b_.norm()) == 0.0:
+            continue                                    # (e.g. the padding-only taps of a dilated ASPP convolution on a 9x9 map)
+        c_, ratio = float(torch.nn.functional.cosine_similarity(a_, b_, dim=0)), float(b_.norm() / a_.norm())
+        print(f"  {name:50s} cosine {c_:.3f} norm ratio {ratio:.3f}")
+        assert c_ > 0.3 and 0.5 < ratio < 2.0, (name, c_, ratio)
+        cs.append(c_)
+    assert sum(cs) / len(cs) > 0.55, cs
     rm1, rm2 = torch.tensor(r1["rm"]), torch.tensor(r2["rm"])
     assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 2e-2
 
