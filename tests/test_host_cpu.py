@@ -350,3 +350,39 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
             assert any(f"s_waitcnt vmcnt({wv})" in l for l in body), (sym, wv)
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == ((2 if ks <= 4 else 1) * ks + 2) * 16384, sym
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
+
+
+def test_conv_ws_vmcnt_accounting_model():
+    """conv_ws_kernel waits for "my two LDS-DMA pieces of stage s" with s_waitcnt vmcnt(W): vector-memory operations retire in order, so
+    the wait is correct iff W <= the number of operations the wave issued AFTER those pieces, and free of unnecessary stalls iff W equals
+    it.  Replay the wave's issue order (csrc/conv_ws.hip: weights, LA stages of prologue, per tile [addend loads], per stage wait -> next
+    pieces -> MFMAs, the tile's stores) for every instance and check the constants of the source (W0 / W1 / W2, also pinned from the ISA
+    by test_conv_ws_kernel_isa_and_shape_rules) against the exact counts."""
+    for ks in (1, 2, 4, 8):
+        for stats, add in ((0, 0), (1, 0), (0, 1)):
+            if ks == 8 and add:
+                continue
+            nt = 2 if ks <= 4 else 1
+            la = nt * ks
+            nld, nst = (8 if add else 0), 8 + (4 if stats else 0)
+            w0 = 2 * (la - 1) + nld
+            w1 = w0 + (nld if nt >= 2 else 0) + nst
+            w2 = w1 + (nst if nt >= 2 else 0)
+            assert w2 <= 63
+            ops = []                       # program order: ("B",), ("piece", stage), ("load", tile), ("store", tile)
+            ops += [("B",)] * (2 * ks * 2)
+            for st in range(la):
+                ops += [("piece", st)] * 2
+            ntiles = 7
+            for ti in range(ntiles):
+                ops += [("load", ti)] * nld
+                for k in range(ks):
+                    s_ = ti * ks + k
+                    last = max(i for i, o in enumerate(ops) if o == ("piece", s_))
+                    younger = len(ops) - 1 - last
+                    w = w2 if ti >= 2 else (w1 if ti == 1 else w0)
+                    assert w <= younger, (ks, stats, add, ti, k, w, younger)          # correctness: the stage has landed after the wait
+                    if ti >= nt:
+                        assert w == younger, (ks, stats, add, ti, k, w, younger)      # steady state: not one operation more than needed
+                    ops += [("piece", s_ + la)] * 2
+                ops += [("store", ti)] * nst
