@@ -386,3 +386,38 @@ def test_conv_ws_vmcnt_accounting_model():
                         assert w == younger, (ks, stats, add, ti, k, w, younger)      # steady state: not one operation more than needed
                     ops += [("piece", s_ + la)] * 2
                 ops += [("store", ti)] * nst
+
+
+def test_committed_bench_line_and_profiles_agree():
+    """The round's evidence must be recomputable from profiles/ alone: the committed bench line is self-consistent (throughput = crops /
+    step time, frac = achieved / peak, achieved = algorithmic FLOPs / HIP-event time per launch) and its per-launch time of the dominant
+    kernel agrees with the rocprofv3 --kernel-trace --stats summary of the same build (another box of the pool: 5 %)."""
+    import csv
+    import glob
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench_line.json")))
+    assert lines, "no committed bench line"
+    tag = os.path.basename(lines[-1])[:3]
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["dtype"] == "bf16" and d["data"] == "synthetic" and d["vs_baseline"] is None
+    assert "513x513" in d["metric"] and "configs[1]" in d["config"]["workload"]
+    assert abs(d["value"] - d["config"]["global_batch"] * 1000.0 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert abs(r["achieved"] - r["alg_flops_per_launch"] / (r["avg_launch_us"] * 1e-6) / 1e12) < 1e-2 * r["achieved"]
+    assert r["traffic"] is None or (r["traffic"] > 0 and "replayed" in r["traffic_source"])
+    assert d["cpu_baseline"]["kind"] in ("port", "reference") and d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["value"] > 0
+    for k, v in d["kernels"].items():
+        assert v["bound"] in ("mfma", "hbm") and 0 < v["frac"] < 1, (k, v)
+    # dominant kernel: the persistent 256x256 kernels of the stats file (all instantiations), weighted by launches
+    stats = os.path.join(root, "profiles", tag + "_bench_kernel_stats.csv")
+    tot_ns = n = 0
+    for row in csv.DictReader(open(stats)):
+        if "conv_igemm_pp64_kernel" in row["Name"] or "conv_igemm_pp_kernel" in row["Name"]:
+            tot_ns += float(row["TotalDurationNs"])
+            n += int(row["Calls"])
+    assert n > 0
+    avg_us = tot_ns / n / 1e3
+    assert abs(avg_us - r["avg_launch_us"]) < 0.05 * avg_us, (avg_us, r["avg_launch_us"])
