@@ -369,8 +369,9 @@ class _BNAct(torch.autograd.Function):
             call("css_bn_apply", y, c, res, c, buf.data_ptr() + off * buf.element_size(), ldo, scale, shift, m, c, int(relu), mg, dc, dev, st)
         else:
             out = torch.empty_like(y)
-            if training and relu and res is not None and _bn_bit_mask:
+            if training and relu and res is not None and _bn_bit_mask and any(ctx.needs_input_grad):
                 # residual layer: the backward passes read the ReLU mask as one byte per 16-byte vector instead of `out` itself
+                # (not for the EMA teacher: its parameters and inputs do not require gradients - no backward, no mask to write)
                 mask = torch.empty((m, c // vec_of(dt)), dtype=torch.uint8, device=y.device)
                 call("css_bn_apply_mask", y, c, res, c, out, c, scale, shift, m, c, int(relu), mg, mask, dc, dev, st)
             else:
