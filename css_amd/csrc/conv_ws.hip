@@ -20,7 +20,11 @@
 //     requested at the START of the tile so that its wait does not drain the LDS-DMA queue.
 // vmcnt bookkeeping: loads, stores and LDS-DMA retire in order, so the wait for "my two pieces of stage s" is a COUNT of what the
 // wave has issued since: 2 (LA - 1) pieces + the epilogue stores (+ addend loads) of the two tiles in between - a constant because LA is a
-// whole number of tiles.
+// whole number of tiles (K = 512: eight stages per tile, ONE tile of look-ahead, 128 VGPRs of weights, no addend form).
+// tests/test_host_cpu.py replays the issue order against these counts and pins them from the ISA.
+// Compile-time switches (scripts/ws_bench.hip only; the library is built with none of them): WS_ABL_NOSTORE / _NOMFMA / _NODMA /
+// _PANEL_XCD and WS_STORE_AUX are timing ablations, WS_PP=1 is the ping-pong form of the K loop (waves 0-3 and 4-7 half a stage
+// apart: bit-identical, 10 % faster without stores, not faster with them - profiles/r02_ws_kernel.txt section 4 - so not shipped).
 #include "common.h"
 #include "launchers.h"
 #include <cstdlib>
