@@ -8,7 +8,8 @@
 //   * writes whole 128-byte lines (64 channels x 2 bytes per pixel) instead of half lines,
 //   * halves the LDS fragment reads per MFMA (8 ds_read_b128 per 32 MFMAs instead of 16),
 // at the price of 128 registers of weights per wave (K = 256 only; no room for the addend form) and of statistics slabs of 64 rows
-// (stage 2 would have to learn them: not written here - this prototype has the plain epilogue only).
+// (stage 2 would have to learn them: the STATS instance below writes them, the harness checks pairs of them against conv_ws_kernel's
+// 128-row slabs; 254 VGPRs with statistics, 238 without, no scratch).
 // Expected from the byte model: stores + fill 92 -> ~69 us, the 256 -> 1024 call 111 -> 85-90 us.
 //
 // Build + run (GPU box):  hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics scripts/proto/ws2_bench.hip -o build/ws2_bench
@@ -19,6 +20,17 @@ namespace {
 typedef __attribute__((address_space(3))) void w2_lds_void;
 constexpr unsigned W2_OOB = 0x80000000u;
 typedef __attribute__((ext_vector_type(4))) unsigned int w2_u32x4;
+typedef __attribute__((ext_vector_type(4))) float w2_f32x4;
+typedef __attribute__((ext_vector_type(2))) float w2_f32x2;
+__device__ __forceinline__ float w2_row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+  return v;
+}
+__device__ __forceinline__ float w2_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float w2_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 __device__ __forceinline__ void w2_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (w2_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
 }
@@ -32,11 +44,14 @@ __device__ __forceinline__ unsigned w2_pack2(float lo, float hi) {
 template <int N> __device__ __forceinline__ void w2_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 }  // namespace
 
-// grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 512) == 0; K = Cs = 256; plain epilogue
+// grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 512) == 0; K = Cs = 256.
+// STATS: batch-norm statistics slabs of 64 ROWS ([ceil(M / 64)][2][Cd] fp32: slab p = rows 64 p .. 64 p + 63, holding the rows that lie in the
+// statistics group of its first row) - css_bn_reduce_finalize_slabs would have to learn that slab height (tile_rows = 128).
+template <bool STATS>
 __global__ __launch_bounds__(512) void conv_ws2_kernel(const ConvArgs a) {
   constexpr int KS = 4, BM = 64, BN = 512, NT = 3, LA = NT * KS, NS = LA + 2;
   constexpr int STG = BM * 128;                                  // one stage: 64 pixels x 128 bytes (64 channels) = 8 KiB, one piece per wave
-  constexpr int NST = 8;                                         // stores of a tile per wave
+  constexpr int NST = 8 + (STATS ? 8 : 0);                       // stores of a tile per wave
   constexpr int W0 = LA - 1, W1 = W0 + NST, W2 = W1 + NST, W3 = W2 + NST;   // vmcnt of the stage wait in tiles 0, 1, 2, later ones
   static_assert(W3 <= 63, "vmcnt is a 6-bit counter");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG];
@@ -156,13 +171,43 @@ __global__ __launch_bounds__(512) void conv_ws2_kernel(const ConvArgs a) {
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? rowb + (unsigned)(nl + 16 * jp) * 2u : W2_OOB), 0, 0);
       }
     }
+    if (STATS) {
+      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
+      const unsigned base = (unsigned)(m0 >> 6) * 2u * (unsigned)a.Cd * 4u;
+      const int bnd = (m0 / a.stat_Mg + 1) * a.stat_Mg;
+      const bool whole = m0 + BM <= bnd;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w2_f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        auto accum = [&](bool test) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            f32x4 t = acc[i][j];
+            asm volatile("" : "+v"(t));
+            const unsigned lo = w2_pack2(t[0], t[1]), hi = w2_pack2(t[2], t[3]);
+            w2_f32x2 v01 = {w2_lo(lo), w2_hi(lo)}, v23 = {w2_lo(hi), w2_hi(hi)};
+            if (test && !(m0 + 16 * i + l15 < bnd)) { v01 = w2_f32x2{0.f, 0.f}; v23 = w2_f32x2{0.f, 0.f}; }
+            s01 += v01; s23 += v23;
+            q01 += v01 * v01; q23 += v23 * v23;
+          }
+        };
+        if (whole) accum(false);
+        else accum(true);
+        const w2_f32x4 os = {w2_row16_sum(s01[0]), w2_row16_sum(s01[1]), w2_row16_sum(s23[0]), w2_row16_sum(s23[1])};
+        const w2_f32x4 oq = {w2_row16_sum(q01[0]), w2_row16_sum(q01[1]), w2_row16_sum(q23[0]), w2_row16_sum(q23[1])};
+        const int n = n0w + 16 * j + 4 * lg;
+        const bool lane_ok = l15 == 0;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w2_u32x4, os), rs_s, (int)(lane_ok ? base + (unsigned)n * 4u : W2_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(w2_u32x4, oq), rs_s, (int)(lane_ok ? base + (unsigned)(a.Cd + n) * 4u : W2_OOB), 0, 0);
+      }
+    }
     __builtin_amdgcn_sched_barrier(0);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 bool css_conv_ws2_supported(const ConvArgs& a, int n_cu) {
-  if (a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias || a.stats || a.addend) return false;
+  if (a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias || a.addend) return false;
   if (a.Ktot != a.Cs || a.Cs != 256 || a.Cd < 512 || a.Cd % 512 || a.lds % 8 || a.ldd % 8) return false;
   const int np = a.Cd / 512;
   if (n_cu < 8 || n_cu % 8 || (n_cu / 8) % np) return false;
@@ -170,5 +215,10 @@ bool css_conv_ws2_supported(const ConvArgs& a, int n_cu) {
 }
 void css_launch_conv_ws2(ConvArgs a, int n_cu, hipStream_t st) {
   a.dst_bytes = (unsigned)((size_t)a.M * a.ldd * 2);
-  hipLaunchKernelGGL(conv_ws2_kernel, dim3(n_cu), dim3(512), 0, st, a);
+  if (a.stats) {
+    a.stat_bytes = (unsigned)((size_t)cdiv(a.M, 64) * 2 * a.Cd * 4);          // 64-row slabs
+    hipLaunchKernelGGL((conv_ws2_kernel<true>), dim3(n_cu), dim3(512), 0, st, a);
+  } else {
+    hipLaunchKernelGGL((conv_ws2_kernel<false>), dim3(n_cu), dim3(512), 0, st, a);
+  }
 }
