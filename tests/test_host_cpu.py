@@ -421,3 +421,60 @@ def test_committed_bench_line_and_profiles_agree():
     assert n > 0
     avg_us = tot_ns / n / 1e3
     assert abs(avg_us - r["avg_launch_us"]) < 0.05 * avg_us, (avg_us, r["avg_launch_us"])
+
+
+def test_conv_ws_index_maps():
+    """The index arithmetic of conv_ws_kernel (csrc/conv_ws.hip), replayed on the host: (1) the LDS-DMA pieces of a stage put source
+    chunk c of pixel row r at 16-byte position c ^ ((r >> 1) & 7) of LDS row r, every (row, chunk) exactly once; (2) the fragment read of
+    lane (l15, lg), pixel tile i, K half h returns row 16 i + l15, chunk 4 h + lg - the MFMA B operand layout - and the 64 lanes of one
+    ds_read_b128 touch 64 distinct 16-byte slots spread evenly over the 64 LDS banks (conflict-free); (3) after the v_permlane16_swap
+    exchange the 64 lanes of a store cover pixels x channels of the wave's 16 x 32 block exactly once, 64 contiguous bytes per pixel."""
+    # (1) issue side: wave w, piece i, lane -> LDS byte address and source (row, chunk)
+    lds = {}
+    for w in range(8):
+        for i in range(2):
+            for lane in range(64):
+                row = w * 16 + 8 * i + (lane >> 3)
+                cch0 = (lane & 7) ^ ((lane >> 4) & 3)
+                chunk = cch0 ^ ((i & 1) << 2)                       # source chunk this lane fetches
+                addr = w * 2048 + i * 1024 + lane * 16              # LDS-DMA: M0 base + 16 bytes per lane
+                assert addr // 128 == row
+                pos = (addr % 128) // 16
+                assert pos == chunk ^ ((row >> 1) & 7), (w, i, lane)
+                assert addr not in lds
+                lds[addr] = (row, chunk)
+    assert len(lds) == 128 * 8
+    # (2) consumer side
+    for i in range(8):
+        for h in range(2):
+            slots = []
+            for lane in range(64):
+                l15, lg = lane & 15, lane >> 4
+                sw = (l15 >> 1) & 7
+                addr = l15 * 128 + i * 2048 + (((4 * h + lg) ^ sw) << 4)
+                assert lds[addr] == (16 * i + l15, 4 * h + lg)
+                slots.append(addr)
+            assert len(set(slots)) == 64
+            banks = [((a_ // 4) + d) % 64 for a_ in slots for d in range(4)]       # a 16-byte read covers 4 consecutive banks
+            assert all(banks.count(b) == 4 for b in range(64))                     # 256 dwords over 64 banks: 4 each = the minimum
+    # (3) epilogue: register r of accumulator tile j holds channel 16 j + 4 lg + r of pixel l15; pack pairs, swap odd lane rows of the
+    # first operand with even lane rows of the second (v_permlane16_swap), store {lo0, hi0, lo1, hi1} at channel nl = 16 (lg & 1) + 8 (lg >> 1)
+    def packed(j, lg, half):       # channels held by the packed dword (lo: regs 0,1; hi: regs 2,3)
+        return [16 * j + 4 * lg + 2 * half, 16 * j + 4 * lg + 2 * half + 1]
+    covered = {}
+    for lane in range(64):
+        l15, lg = lane & 15, lane >> 4
+        regs = {}
+        for name, half in (("lo", 0), ("hi", 1)):
+            a_ = {g: packed(0, g, half) for g in range(4)}          # operand 0 (tile j = 0) per lane row
+            b_ = {g: packed(1, g, half) for g in range(4)}          # operand 1 (tile j = 1)
+            for g in (1, 3):                                        # odd rows of a <-> even rows of b
+                a_[g], b_[g - 1] = b_[g - 1], a_[g]
+            regs[name + "0"], regs[name + "1"] = a_[lg], b_[lg]
+        chans = regs["lo0"] + regs["hi0"] + regs["lo1"] + regs["hi1"]
+        nl = 16 * (lg & 1) + 8 * (lg >> 1)
+        assert chans == list(range(nl, nl + 8)), (lane, chans)
+        for c in chans:
+            assert (l15, c) not in covered
+            covered[(l15, c)] = lane
+    assert len(covered) == 16 * 32
