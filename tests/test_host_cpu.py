@@ -478,3 +478,49 @@ def test_conv_ws_index_maps():
             assert (l15, c) not in covered
             covered[(l15, c)] = lane
     assert len(covered) == 16 * 32
+
+
+def test_statistics_slab_protocol_model():
+    """The hand-over of batch-norm statistics from the convolution epilogues to stage 2 (csrc/bn.hip: bn_reduce_slabs_kernel; csrc/conv_pp.hip,
+    conv_pp64.hip, conv_ws.hip, conv.hip: the slab stores), replayed on the host with integers: a slab holds the sum of those of its rows that
+    lie in the statistics group of its FIRST row; group g = the slabs that START inside it + the rows from the group's start to the next slab
+    start, summed from the tensor itself.  Must give the plain per-group sums for every (M, groups) and for the three slab geometries: two
+    slabs per 256-row tile (128 + 128), per 272-row tile (144 + 128), and the uniform 64-row slabs scripts/proto/conv_ws2.hip would need."""
+    import random
+    rnd = random.Random(7)
+
+    def geometry(bm):
+        if bm == 64:                                   # uniform 64-row slabs
+            return (lambda p: p * 64), (lambda row: -(-row // 64))
+        start = lambda p: (p >> 1) * bm + (p & 1) * (bm - 128)
+
+        def first_from(row):                           # first slab whose start is >= row (bn.hip: first_slab_from)
+            t, rem = divmod(row, bm)
+            return 2 * t + (0 if rem == 0 else (1 if rem <= bm - 128 else 2))
+        return start, first_from
+
+    for bm in (256, 272, 64):
+        start, first_from = geometry(bm)
+        for _ in range(60):
+            g = rnd.choice((1, 2, 3, 4))
+            mg = rnd.randint(128, 1500)
+            m = g * mg
+            x = [rnd.randint(-50, 50) for _ in range(m)]
+            nslab = 0                                  # number of slabs that start below M
+            while start(nslab) < m:
+                nslab += 1
+            slabs = []
+            for p in range(nslab):
+                b0, b1 = start(p), min(start(p + 1), m)
+                bnd = (b0 // mg + 1) * mg
+                slabs.append(sum(x[r] for r in range(b0, b1) if r < bnd))
+            for gi in range(g):
+                b, e = gi * mg, (gi + 1) * mg
+                lo, hi = first_from(b), min(first_from(e), nslab)
+                tail_end = min(start(first_from(b)), e)
+                got = sum(slabs[lo:hi]) + sum(x[b:tail_end])
+                assert got == sum(x[b:e]), (bm, g, mg, gi)
+            # the first_from of bn.hip agrees with its definition
+            for row in (0, 1, 127, 128, 129, bm - 128, bm - 127, bm - 1, bm, bm + 1, m - 1, m):
+                p = first_from(row)
+                assert start(p) >= row and (p == 0 or start(p - 1) < row), (bm, row, p)
