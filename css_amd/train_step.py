@@ -65,7 +65,11 @@ class MixTrainer:
         self.bucket_mb = float(os.environ.get("CSS_GRAD_BUCKET_MB", "48"))
         self._grad_pg = None                   # process group of the gradient buckets (created on first use, on every rank)
         self._ready_order = None               # parameter spans in the order their gradients were reported (recorded on the first step)
-        self._buckets = None                   # [(runs = [(start, end), ...], number of reports that complete the bucket)]
+        self._buckets = None                   # [(runs = [(start, end), ...], frozenset of the bucket's spans)]
+        self._span_reports = None              # span -> number of gradient reports per step (recorded on the first step)
+        self._span_bucket = None               # span -> index of its bucket
+        self._flags = [torch.zeros(1, device=self.flat_g.device) for _ in range(2)]   # violation flag agreed across ranks (MAX all-reduce)
+        self._flag_pending = None
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -86,19 +90,19 @@ class MixTrainer:
 
     # ---- backward with the gradient all-reduce overlapped (DDP's bucketing, mix_label.py:77) ---------------------------------
     def _plan_buckets(self, order):
-        """Cut the recorded readiness order into buckets of ~bucket_mb; a bucket = the contiguous runs of the flat buffer its
-        parameters cover (backward runs the layers in reverse, so a bucket is one or two runs)."""
+        """Cut the recorded readiness order (first report of every span) into buckets of ~bucket_mb; a bucket = (the contiguous runs
+        of the flat buffer its parameters cover, the set of its spans) - backward runs the layers in reverse, so a bucket is one or
+        two runs."""
         limit = self.bucket_mb * 2 ** 20 / 4
-        buckets, cur, cnt, size = [], [], 0, 0
+        buckets, cur, size = [], [], 0
         for sp in order:
             cur.append(sp)
-            cnt += 1
             size += sp[1] - sp[0]
             if size >= limit:
-                buckets.append((self._runs(cur), cnt))
-                cur, cnt, size = [], 0, 0
+                buckets.append((self._runs(cur), frozenset(cur)))
+                cur, size = [], 0
         if cur:
-            buckets.append((self._runs(cur), cnt))
+            buckets.append((self._runs(cur), frozenset(cur)))
         return buckets
 
     @staticmethod
@@ -112,6 +116,12 @@ class MixTrainer:
         return [tuple(r) for r in runs]
 
     def _backward_and_reduce(self, total):
+        """Protocol: the first step records, per span of the flat buffer, HOW OFTEN its gradient is reported (a parameter
+        used by several graph nodes reports once per node) and the order in which the spans complete.  Later steps launch bucket b
+        when every span of buckets 0..b has received ALL its recorded reports - never on a count of reports alone - and always in
+        bucket order, so every rank issues the same sequence of collectives whatever the timing.  A report that does not fit the
+        record (a span completes twice, an unknown span, a span that stays incomplete) is a violation: the remaining buckets are still
+        launched in order, the ranks agree on the flag with one small all-reduce, and every rank raises at the same point (the start of its next step)."""
         sync = ops.collectives_on()
         overlap = sync and self.bucket_mb > 0
         if not overlap:
@@ -122,9 +132,11 @@ class MixTrainer:
             return
         if self._grad_pg is None:
             self._grad_pg = dist.new_group()     # same ranks, own communicator / stream
-        works, done, seen = [], [], set()
-        state = dict(n=0, b=0)
-        record = [] if self._buckets is None else None
+        works, done = [], []
+        counts = {}                              # span -> reports so far in this step
+        state = dict(b=0, bad=0)
+        recording = self._buckets is None
+        order = []
 
         def launch(runs):
             for a, b in runs:
@@ -133,39 +145,49 @@ class MixTrainer:
 
         def ready(p):
             sp = self._span.get(id(p))
-            if sp is None or sp in seen:
+            if sp is None:
                 return
-            seen.add(sp)
-            if record is not None:
-                record.append(sp)
+            n = counts.get(sp, 0) + 1
+            counts[sp] = n
+            if recording:
+                if n == 1:
+                    order.append(sp)
+                else:                            # completion order = order of the LAST report
+                    order.remove(sp)
+                    order.append(sp)
                 return
-            state["n"] += 1
-            while state["b"] < len(self._buckets) and state["n"] >= self._bucket_end[state["b"]]:
+            want = self._span_reports.get(sp)
+            if want is None or n > want:         # not in the record, or a contribution behind a bucket that may already be on the wire
+                state["bad"] = 1
+                return
+            if n < want:
+                return
+            self._pending[self._span_bucket[sp]] -= 1
+            while state["b"] < len(self._buckets) and self._pending[state["b"]] == 0:
                 launch(self._buckets[state["b"]][0])
                 state["b"] += 1
 
+        self._check_bucket_flag()                # the previous step's agreed flag (long since on the host side of the stream)
+        if not recording:
+            self._pending = [len(spans) for _, spans in self._buckets]
         prev = ops.set_grad_ready_callback(ready)
         try:
             with ops.direct_param_grads():
                 total.backward()
         finally:
             ops.set_grad_ready_callback(prev)
-        if record is not None:                   # first step: learn the order, reduce in one piece
-            self._ready_order = list(record)
-            self._buckets = self._plan_buckets(record)
-            ends, acc = [], 0
-            for _, cnt in self._buckets:
-                acc += cnt
-                ends.append(acc)
-            self._bucket_end = ends
-            self._n_reports = len(record)
+        if recording:                            # first step: learn the order and the report counts, reduce in one piece
+            self._ready_order = list(order)
+            self._span_reports = dict(counts)
+            self._buckets = self._plan_buckets(order)
+            self._span_bucket = {sp: b for b, (_, spans) in enumerate(self._buckets) for sp in spans}
             dist.all_reduce(self.flat_g, group=self._grad_pg)
             return
-        if state["n"] != self._n_reports:        # the graph changed (other losses / frozen layers): fall back, re-learn next step
-            for w in works:
-                w.wait()
-            self._buckets = None
-            raise RuntimeError("gradient readiness order changed between steps; buckets were reset - rebuild the trainer for a new graph")
+        if state["b"] < len(self._buckets):      # incomplete spans: the graph changed; keep the collective sequence identical on every rank
+            state["bad"] = 1
+            while state["b"] < len(self._buckets):
+                launch(self._buckets[state["b"]][0])
+                state["b"] += 1
         # the rest of the buffer: parameters that never report (gradient through autograd's own accumulation) and alignment gaps
         pos, rest = 0, []
         for a, b in sorted(done):
@@ -175,8 +197,26 @@ class MixTrainer:
         if pos < self.flat_g.numel():
             rest.append((pos, self.flat_g.numel()))
         launch(rest)
+        flag = self._flags[self.it & 1]
+        flag.fill_(float(state["bad"]))
+        works.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._grad_pg, async_op=True))
         for w in works:
             w.wait()                             # the compute stream waits for the buckets (host does not block on RCCL)
+        self._flag_pending = flag                # read at the start of the next step, on every rank at the same point of the protocol
+
+    def _check_bucket_flag(self):
+        """Raise - on every rank - when some rank's gradient reports did not fit the recorded plan.  The agreed flag is read ONE STEP
+        LATE (start of the next backward, or `finish()`), so that the host never blocks on the device inside a step."""
+        flag, self._flag_pending = self._flag_pending, None
+        if flag is not None and float(flag[0]) != 0.0:
+            self._buckets = None
+            raise RuntimeError("gradient readiness changed between steps on some rank (a span reported more or less often than on the "
+                               "first step); buckets were reset on every rank - the gradients of that step are invalid, rebuild the "
+                               "trainer for a new graph")
+
+    def finish(self):
+        """Call after the last step of a run: surfaces a pending bucket-plan violation of the final step."""
+        self._check_bucket_flag()
 
     @property
     def lr(self):

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <vector>
 #include <cstdlib>
+#include <cstring>
 struct Shape { const char* name; int N, H, W, Cin, Cout, R, stride, pad, dil; };
 int main() {
   std::vector<Shape> shapes = {
@@ -19,6 +20,22 @@ int main() {
       {"l1 1x1 64->256", 32, 129, 129, 64, 256, 1, 1, 0, 1},
   };
   const int only = getenv("CB_ONLY") ? atoi(getenv("CB_ONLY")) : -1;   // run a single shape (index into the table)
+  // CB_SHAPE="N,H,W,Cin,Cout,R,stride,pad,dil[;...]": run these shapes instead of the table (a 1x1 shape is a plain GEMM M = N*H*W, K = Cin:
+  // the comparison with scripts/gemm8p.hip on the same M / N / K)
+  static char names[32][64];
+  if (const char* cs = getenv("CB_SHAPE")) {
+    shapes.clear();
+    int v[9], n = 0;
+    while (*cs && sscanf(cs, "%d,%d,%d,%d,%d,%d,%d,%d,%d", v, v + 1, v + 2, v + 3, v + 4, v + 5, v + 6, v + 7, v + 8) == 9 && n < 32) {
+      snprintf(names[n], 64, "%dx%d^2 %dx%d %d->%d", v[0], v[1], v[5], v[5], v[3], v[4]);
+      shapes.push_back({names[n], v[0], v[1], v[2], v[3], v[4], v[5], v[6], v[7], v[8]});
+      ++n;
+      while (*cs && *cs != ';') ++cs;
+      if (*cs == ';') ++cs;
+    }
+  }
+  const bool uniform = getenv("CB_UNIFORM") != nullptr;                 // operands uniform in [-1, 1) like the yardstick GEMM's
+  auto f2bf = [](float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7FFF + ((u >> 16) & 1); return (unsigned short)(u >> 16); };
   for (auto& s : shapes) {
     if (only >= 0 && &s - shapes.data() != only) continue;
     const int Ho = (s.H + 2 * s.pad - s.dil * (s.R - 1) - 1) / s.stride + 1, Wo = Ho;
@@ -26,6 +43,10 @@ int main() {
     std::vector<unsigned short> hx(nx), hw(nw);
     for (auto& v : hx) v = 0x3C00 + (rand() & 0x3FF) - ((rand() & 1) << 15);   // random bf16-ish bit patterns around +-1
     for (auto& v : hw) v = 0x3800 + (rand() & 0x3FF) - ((rand() & 1) << 15);
+    if (uniform) {
+      for (auto& v : hx) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.0f - 1.0f);
+      for (auto& v : hw) v = f2bf((float)(rand() & 0xFFFFFF) / 8388608.0f - 1.0f);
+    }
     void *dx, *dw, *dy;
     float* dwg;
     hipMalloc(&dx, nx * 2); hipMalloc(&dw, nw * 2); hipMalloc(&dy, ny * 2); hipMalloc(&dwg, nw * 4);

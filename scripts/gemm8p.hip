@@ -1,0 +1,292 @@
+// Yardstick: the 256x256 8-phase bf16 GEMM of /opt/skills/guides/cdna_hip_programming.md ("The 256^2 8-phase template"), written
+// from the guide's specification (the example file it names is not on this image):
+//   C[M][N] (bf16) = A[M][K] . B[N][K]^T, 8 waves as 2 (M) x 4 (N), 128 x 64 outputs per wave, BK = 64, LDS = 2 buffers x 4 half-tiles
+//   (A0, A1, B0, B1: 128 rows x 128 B = 16 KiB each) = 128 KiB, one half-tile staged per phase by 2 LDS-DMA per thread, 4 phases per
+//   K tile (one 64 x 32 C quadrant x K = 64 = 16 v_mfma_f32_16x16x32_bf16 per phase), `s_waitcnt vmcnt(6)` once per K tile (three
+//   half-tiles stay in flight), raw s_barrier pairs, s_setprio around the MFMA cluster, the two wave rows one barrier apart.
+// Purpose: the known-good number on THIS box, on random data, at the conv shapes' M / N / K, next to
+// conv_igemm_pp64_kernel on the same GEMM (scripts/conv_bench.hip, CB_SHAPE=...).  Not part of the product.
+//
+// build: hipcc -O3 --offload-arch=gfx950 -o gemm8p scripts/gemm8p.hip ;  run: ./gemm8p [M N K]...
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cmath>
+#include <vector>
+#include <algorithm>
+#include <array>
+#include <cstring>
+#include <type_traits>
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((address_space(3))) void lds_void;
+constexpr unsigned G8_OOB = 0x80000000u;
+
+__device__ __forceinline__ void g8_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned voff, int soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+__device__ __forceinline__ void g8_swap16(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ unsigned g8_pack2(float lo, float hi) {
+  union { bf16_t h[2]; unsigned u; } t;
+  t.h[0] = (bf16_t)lo;
+  t.h[1] = (bf16_t)hi;
+  return t.u;
+}
+
+#ifndef G8_PERSIST
+#define G8_PERSIST 0
+#endif
+
+__global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ C, int M, int N, int K) {
+  constexpr int HALF = 128 * 128;   // one half-tile: 128 rows of 128 bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF];   // [buffer 0/1][A0, A1, B0, B1]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  const int nt_n = N >> 8, nwg = gridDim.x;
+  const int xcd = blockIdx.x & 7, q8 = nwg >> 3, r8 = nwg & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (blockIdx.x >> 3);
+  const int mt = wgid / nt_n, m0 = mt * 256, n0 = (wgid - mt * nt_n) * 256;
+  const int nk = K >> 6;
+  const int rows = min(256, M - m0);
+
+  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)A + (size_t)m0 * K * 2), 0, rows * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)B + (size_t)n0 * K * 2), 0, 256 * K * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc((void*)((char*)C + (size_t)m0 * N * 2), 0, rows * N * 2, 0x00020000);
+
+  // staging: piece p = i * 8 + wave of a half-tile = local rows 8 p + (lane >> 3), 16-byte position lane & 7; the chunk stored at
+  // position c of local row r is source chunk c ^ ((r >> 1) & 7)   (conflict-free ds_read_b128 of 16 consecutive rows)
+  unsigned aoff[2][2], boff[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int r = (i * 8 + wave) * 8 + (lane >> 3);
+      const int ch = (lane & 7) ^ ((r >> 1) & 7);
+      const int arow = (r >> 6) * 128 + h * 64 + (r & 63);     // A half h holds rows wr * 128 + h * 64 + [0, 64) of both wave rows
+      const int brow = (r >> 5) * 64 + h * 32 + (r & 31);      // B half h holds columns wc * 64 + h * 32 + [0, 32) of the four wave columns
+      aoff[h][i] = (unsigned)arow * (unsigned)K * 2u + (unsigned)ch * 16u;
+      boff[h][i] = (unsigned)brow * (unsigned)K * 2u + (unsigned)ch * 16u;
+    }
+  unsigned char* const st_base = smem + wave * 1024;
+  // slot: 0 = A0, 1 = A1, 2 = B0, 3 = B1
+  auto stage = [&](int buf, int slot, int kt) {
+    const bool live = kt < nk;
+    const int so = kt * 128;
+    unsigned char* d = st_base + (buf * 4 + slot) * HALF;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned off = slot < 2 ? aoff[slot][i] : boff[slot - 2][i];
+      g8_dma16(slot < 2 ? rs_a : rs_b, d + i * 8192, live ? off : G8_OOB, so);
+    }
+  };
+
+  const int sw = (l15 >> 1) & 7;
+  const int ko0 = ((lg ^ sw) << 4), ko1 = (((4 + lg) ^ sw) << 4);
+  const unsigned char* const a_rd = smem + (wr * 64 + l15) * 128;
+  const unsigned char* const b_rd = smem + 2 * HALF + (wc * 32 + l15) * 128;
+
+  f32x4 acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // prologue: tile 0 whole, tile 1 up to B1
+  stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
+  stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wr == 1) __builtin_amdgcn_s_barrier();     // the second wave row runs one barrier behind
+  asm volatile("" ::: "memory");
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#define G8_MFMA_QUAD(AH, FB, BH)                                                                                          \
+  _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kh], fa[i][kh], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);
+#define G8_PHASE_MID()                                  \
+  __builtin_amdgcn_sched_barrier(0);                    \
+  __builtin_amdgcn_s_barrier();                         \
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
+  __builtin_amdgcn_sched_barrier(0);                    \
+  __builtin_amdgcn_s_setprio(1);
+#define G8_PHASE_END()                   \
+  __builtin_amdgcn_s_setprio(0);         \
+  __builtin_amdgcn_sched_barrier(0);     \
+  __builtin_amdgcn_s_barrier();          \
+  asm volatile("" ::: "memory");         \
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto ktile = [&](auto BUFC, int t) {
+    constexpr int b = decltype(BUFC)::value;
+    const unsigned char* const ab = a_rd + b * 4 * HALF;
+    const unsigned char* const bb = b_rd + b * 4 * HALF;
+    // ---- phase 1: A0 x B0 ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fb0[j][0] = *reinterpret_cast<const bf16x8*>(bb + j * 2048 + ko0);
+      fb0[j][1] = *reinterpret_cast<const bf16x8*>(bb + j * 2048 + ko1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + ko0);
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(ab + i * 2048 + ko1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage(b ^ 1, 1, t + 1);                                   // (t+1).A1
+    asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");        // the four B0 reads are done: B0 of this buffer is restaged next phase
+    G8_PHASE_MID();
+    G8_MFMA_QUAD(0, fb0, 0);
+    G8_PHASE_END();
+    // ---- phase 2: A0 x B1 ----
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      fb1[j][0] = *reinterpret_cast<const bf16x8*>(bb + HALF + j * 2048 + ko0);
+      fb1[j][1] = *reinterpret_cast<const bf16x8*>(bb + HALF + j * 2048 + ko1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage(b, 2, t + 2);                                       // (t+2).B0
+    G8_PHASE_MID();
+    G8_MFMA_QUAD(0, fb1, 1);
+    G8_PHASE_END();
+    // ---- phase 3: A1 x B1 ----
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      fa[i][0] = *reinterpret_cast<const bf16x8*>(ab + HALF + i * 2048 + ko0);
+      fa[i][1] = *reinterpret_cast<const bf16x8*>(ab + HALF + i * 2048 + ko1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    stage(b, 0, t + 2);                                       // (t+2).A0
+    G8_PHASE_MID();
+    G8_MFMA_QUAD(1, fb1, 1);
+    G8_PHASE_END();
+    // ---- phase 4: A1 x B0 ----
+    stage(b, 3, t + 2);                                       // (t+2).B1
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // everything up to (t+1).A1 has landed: tile t+1 is whole
+    G8_PHASE_MID();
+    G8_MFMA_QUAD(1, fb0, 0);
+    G8_PHASE_END();
+  };
+
+  for (int t = 0; t < nk; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+  if (wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // epilogue from registers: lane holds channels 4 lg + {0..3} of pixel l15 per 16x16 tile; permlane16_swap pairs two tiles into
+  // 8 consecutive channels -> one 16-byte store per lane (64 contiguous bytes per pixel per instruction)
+  const int mrow0 = wr * 128, n0w = n0 + wc * 64;
+  const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int m = mrow0 + 16 * i + l15;
+    unsigned lo[4], hi[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      lo[j] = g8_pack2(acc[i][j][0], acc[i][j][1]);
+      hi[j] = g8_pack2(acc[i][j][2], acc[i][j][3]);
+    }
+#pragma unroll
+    for (int jp = 0; jp < 4; jp += 2) {
+      g8_swap16(lo[jp], lo[jp + 1]);
+      g8_swap16(hi[jp], hi[jp + 1]);
+      u32x4 v = {lo[jp], hi[jp], lo[jp + 1], hi[jp + 1]};
+      const int n = nl + 16 * jp;
+      __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, (int)(((unsigned)m * (unsigned)N + (unsigned)n) * 2u), 0, 0);
+    }
+  }
+}
+
+static unsigned short f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7FFF + ((u >> 16) & 1);
+  return (unsigned short)(u >> 16);
+}
+static float bf2f(unsigned short h) {
+  unsigned u = (unsigned)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+int main(int argc, char** argv) {
+  std::vector<std::array<int, 3>> shapes;
+  for (int i = 1; i + 2 < argc; i += 3) shapes.push_back({atoi(argv[i]), atoi(argv[i + 1]), atoi(argv[i + 2])});
+  if (shapes.empty())
+    shapes = {{4096, 4096, 4096}, {8192, 8192, 8192}, {131072, 256, 1024}, {131072, 256, 2304}, {131072, 256, 4608}, {131072, 256, 18432},
+              {131072, 512, 1024}, {131072, 512, 2304}, {131072, 512, 4608}, {135200, 256, 2304}, {135200, 512, 4608}, {131072, 1024, 256}};
+  const int rounds = getenv("G8_ROUNDS") ? atoi(getenv("G8_ROUNDS")) : 3;
+  for (auto& s : shapes) {
+    const int M = s[0], N = s[1], K = s[2];
+    if (N % 256 || K % 64 || K < 128) { printf("skip %d %d %d\n", M, N, K); continue; }
+    const size_t na = (size_t)M * K, nb = (size_t)N * K, nc = (size_t)M * N;
+    std::vector<unsigned short> ha(na), hb(nb), hc(nc);
+    unsigned long long st = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&]() { st = st * 6364136223846793005ull + 1442695040888963407ull; return (float)((st >> 40) & 0xFFFFFF) / 8388608.0f - 1.0f; };
+    for (auto& v : ha) v = f2bf(rnd());
+    for (auto& v : hb) v = f2bf(rnd());
+    void *da, *db, *dc;
+    hipMalloc(&da, na * 2); hipMalloc(&db, nb * 2); hipMalloc(&dc, nc * 2);
+    hipMemcpy(da, ha.data(), na * 2, hipMemcpyHostToDevice);
+    hipMemcpy(db, hb.data(), nb * 2, hipMemcpyHostToDevice);
+    hipMemset(dc, 0xFF, nc * 2);
+    const int grid = ((M + 255) / 256) * (N / 256);
+    auto launch = [&]() { hipLaunchKernelGGL(gemm8p_kernel, dim3(grid), dim3(512), 0, 0, da, db, dc, M, N, K); };
+    launch();
+    hipDeviceSynchronize();
+    hipMemcpy(hc.data(), dc, nc * 2, hipMemcpyDeviceToHost);
+    // check: 64 sampled rows (always including the first, the last and a tile edge) against a double-precision dot product
+    double maxerr = 0;
+    int bad = 0;
+    for (int sidx = 0; sidx < 64; ++sidx) {
+      const int m = sidx == 0 ? 0 : sidx == 1 ? M - 1 : sidx == 2 ? std::min(M - 1, 255) : sidx == 3 ? std::min(M - 1, 256) : (int)(((unsigned long long)sidx * 2654435761u) % M);
+      for (int n = 0; n < N; n += (sidx < 4 ? 1 : 7)) {
+        double ref = 0;
+        for (int k = 0; k < K; ++k) ref += (double)bf2f(ha[(size_t)m * K + k]) * (double)bf2f(hb[(size_t)n * K + k]);
+        const double got = bf2f(hc[(size_t)m * N + n]);
+        const double err = fabs(got - ref), tol = 0.02 * sqrt((double)K) * 0.34 + 0.008 * fabs(ref);
+        maxerr = std::max(maxerr, err);
+        if (!(err <= tol)) { if (bad < 5) printf("  MISMATCH m=%d n=%d got %f ref %f\n", m, n, got, ref); ++bad; }
+      }
+    }
+    // race screen: 20 more launches must reproduce the first result bit for bit
+    std::vector<unsigned short> hc2(nc);
+    int racebad = 0;
+    for (int r = 0; r < (getenv("G8_NORACE") ? 0 : 20); ++r) {
+      hipMemset(dc, 0xFF, nc * 2);
+      launch();
+      hipMemcpy(hc2.data(), dc, nc * 2, hipMemcpyDeviceToHost);
+      if (memcmp(hc.data(), hc2.data(), nc * 2)) ++racebad;
+    }
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    std::vector<float> us;
+    for (int r = 0; r < rounds; ++r) {
+      for (int i = 0; i < 3; ++i) launch();
+      const int reps = 20;
+      hipEventRecord(e0, 0);
+      for (int i = 0; i < reps; ++i) launch();
+      hipEventRecord(e1, 0);
+      hipEventSynchronize(e1);
+      float ms;
+      hipEventElapsedTime(&ms, e0, e1);
+      us.push_back(ms / reps * 1e3f);
+    }
+    std::sort(us.begin(), us.end());
+    const double flops = 2.0 * M * N * K;
+    printf("gemm8p M=%d N=%d K=%d grid=%d  min %8.1f us (%7.1f TF)  median %8.1f us (%7.1f TF)  maxerr %.3g bad %d racebad %d\n", M, N, K, grid, us[0],
+           flops / us[0] * 1e-6, us[us.size() / 2], flops / us[us.size() / 2] * 1e-6, maxerr, bad, racebad);
+    fflush(stdout);
+    hipFree(da); hipFree(db); hipFree(dc);
+  }
+  return 0;
+}

@@ -97,7 +97,7 @@ def test_world2_exchanges_equal_reference_gather():
     assert abs(res[0][4] - res[0][5]) < 1e-5 and abs(res[1][4] - res[1][5]) < 1e-5
 
 
-def _bucket_worker(rank, world, port, q):
+def _bucket_worker(rank, world, port, q, mode="plain"):
     """MixTrainer._backward_and_reduce on a toy graph (CPU tensors, gloo): layers whose backward ADDS the parameter gradient into the
     flat buffer and reports the parameter (as the HIP conv / batch-norm backward do), one parameter whose gradient goes through
     autograd's own accumulation (never reported), three steps: record, bucketed, bucketed."""
@@ -139,14 +139,21 @@ def _bucket_worker(rank, world, port, q):
     tr.flat_g = flat_g
     tr._span = {id(p): (o, e) for p, o, e in zip(params, offs, offs[1:] + [tot])}
     tr.bucket_mb = 4096 / 2 ** 20                                   # 1024 floats per bucket
-    tr._grad_pg = tr._ready_order = tr._buckets = None
+    tr._grad_pg = tr._ready_order = tr._buckets = tr._span_reports = tr._span_bucket = tr._flag_pending = None
+    tr._flags = [torch.zeros(1), torch.zeros(1)]
+    tr.it = 0
     errs = []
-    for step in range(3):
+    raised = []
+    for step in range(3 if mode == "plain" else 4):
+        tr.it = step
         flat_g.zero_()
         x = torch.full((), float(rank + 1 + step), requires_grad=True)
         h = x
-        for p in params[:-1]:
+        for i, p in enumerate(params[:-1]):
+            if mode == "violate" and step == 2 and rank == 1 and i == 3:
+                continue                                             # the graph changes on ONE rank: that layer never reports
             h = Lin.apply(h, p)
+        h = Lin.apply(h, params[1])                                  # a parameter used by two nodes reports twice (its bucket waits for both)
         total = h + (params[-1] * (rank + 2)).sum()                  # last parameter: plain autograd accumulation, never reported
         # reference: the same backward without any collective, then one all-reduce
         ref_g = torch.zeros(tot)
@@ -156,9 +163,17 @@ def _bucket_worker(rank, world, port, q):
         dist.all_reduce(ref_g)
         for p, o in zip(params, offs):
             p.grad = flat_g[o:o + p.numel()]
-        tr._backward_and_reduce(total)
+        try:
+            tr._backward_and_reduce(total)
+        except RuntimeError as e:
+            raised.append((step, "readiness changed" in str(e)))
+            continue
         errs.append((flat_g - ref_g).abs().max().item())
-    q.put((rank, errs, len(tr._buckets), [r for r, _ in tr._buckets], len(tr._ready_order)))
+    try:
+        tr.finish()
+    except RuntimeError as e:
+        raised.append((-1, "readiness changed" in str(e)))
+    q.put((rank, errs, len(tr._buckets) if tr._buckets else 0, [r for r, _ in tr._buckets] if tr._buckets else [], len(tr._ready_order), raised))
     dist.destroy_process_group()
 
 
@@ -174,12 +189,34 @@ def test_world2_bucketed_gradient_all_reduce_equals_one_all_reduce():
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    for rank, errs, nb, runs, nrep in res:
+    for rank, errs, nb, runs, nrep, raised in res:
         assert max(errs) == 0.0, (rank, errs)                        # two ranks: a + b in any order is the same float
         assert nrep == 7 and nb >= 2, (nb, nrep)
-        # backward visits the layers in reverse: every bucket is one contiguous run of the flat buffer
-        assert all(len(r) == 1 for r in runs), runs
+        assert not raised, raised
+        # backward visits the layers in reverse; the twice-used parameter completes last: at most two runs per bucket
+        assert all(len(r) <= 2 for r in runs), runs
     assert res[0][3] == res[1][3]                                    # same plan on both ranks
+
+
+def test_world2_bucket_plan_violation_raises_on_every_rank_without_hanging():
+    """when the graph of ONE rank changes (a layer stops reporting), that rank must not stop issuing the
+    collectives the other rank is waiting in, and both ranks must learn about it at the same point of the protocol: the start of
+    the next step, from the agreed flag."""
+    os.environ["CSS_FORCE_COLLECTIVES"] = "0"
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_bucket_worker, args=(r, 2, port, q, "violate")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, errs0, _, _, _, raised0), (r1, errs1, _, _, _, raised1) = res
+    assert raised1 == [(3, True)], raised1                           # the rank whose graph changed
+    assert raised0 == [(3, True)], raised0                           # the other rank: same step, from the agreed flag
+    assert errs0[:2] == [0.0, 0.0] and errs1[:2] == [0.0, 0.0]       # the steps before the change were exact
 
 
 def _mix_worker(rank, world, port, q):
