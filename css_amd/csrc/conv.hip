@@ -1184,6 +1184,12 @@ __device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0,
   return u.f;
 }
 
+// STAG (r03): the two waves of a SIMD (wn = 0 / 1) run the same program with one barrier per step, i.e. in lockstep: both read their
+// fragments, then both queue for the SIMD's one matrix pipe.  With STAG the second cout half defers the MFMAs of each step's second
+// 16-pixel half by one step (its fragments stay in registers across the barrier): after a barrier it multiplies while the first half
+// reads, then reads while the first half multiplies (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Same MFMA order per
+// accumulator, so the result is bit-identical.
+template <bool STAG>
 __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs a) {
   constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
   constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
@@ -1302,6 +1308,25 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
   issue(1);
   issue(2);
   int st_c = 0, st_i = 3;
+  if (STAG && wn == 1) {
+    for (int it = 0; it < nit; ++it) {
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (it > 0) mma(1);                 // second half of the previous step (fragments kept across the barrier)
+      __builtin_amdgcn_sched_barrier(0);
+      read_frags(st_c, 0);
+      read_frags(st_c, 1);                // (must be complete before the next barrier: the stage is refilled after it)
+      __builtin_amdgcn_sched_barrier(0);
+      issue(st_i);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(0);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_c = (st_c + 1) & 3;
+      st_i = (st_i + 1) & 3;
+    }
+    mma(1);
+  } else
   for (int it = 0; it < nit; ++it) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -1461,7 +1486,8 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
           // second-generation kernel (conv_pp.hip): persistent, one workgroup per CU walking full_mt * nt_n tiles
           b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
           const int tiles = full_mt * nt_n;
-          if (css_conv_pp64_supported(b)) css_launch_conv_pp64(b, tiles < n_cu ? tiles : n_cu, st);   // 128-byte rows (conv_pp64.hip)
+          if (css_conv_p8_supported(b)) css_launch_conv_p8(b, tiles < n_cu ? tiles : n_cu, st);        // 8-phase K loop (conv_p8.hip)
+          else if (css_conv_pp64_supported(b)) css_launch_conv_pp64(b, tiles < n_cu ? tiles : n_cu, st);   // 128-byte rows (conv_pp64.hip)
           else css_launch_conv_pp(b, 256, tiles < n_cu ? tiles : n_cu, st);
         } else {
           hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
@@ -1601,7 +1627,9 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   if (prof) prof->begin(big, 1.0, false);
   if (!big || (size_t)a.tiles_k * a.tiles_n * a.splits * (256 * 256 * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path
   if (big) {
-    hipLaunchKernelGGL(conv_wgrad_dma256_kernel, g, dim3(512), 0, st, a);
+    static const bool no_stag = getenv("CSS_WGRAD_NOSTAGGER") != nullptr;
+    if (no_stag) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<false>, g, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_dma256_kernel<true>, g, dim3(512), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
   } else if (dtype == CSS_BF16)

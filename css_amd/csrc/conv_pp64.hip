@@ -313,7 +313,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         // ---------------- MFMA segment ----------------
+#ifndef P6_NOPRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
         if (kt == 0 && h == 0) {
           const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -326,7 +328,9 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
         }
+#ifndef P6_NOPRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");                   // (the next LOAD segment's fragment reads must stay behind this barrier)

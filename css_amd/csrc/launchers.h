@@ -59,6 +59,8 @@ void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st);
 int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu);
 bool css_conv_pp64_supported(const ConvArgs& a);
 void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st);
+bool css_conv_p8_supported(const ConvArgs& a);
+void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st);
 bool css_conv_ws_supported(const ConvArgs& a, int n_cu);
 void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st);
 void css_conv_ws_set_enabled(int on);

@@ -2,6 +2,7 @@
 #include "../css_amd/csrc/conv.hip"
 #include "../css_amd/csrc/conv_pp.hip"
 #include "../css_amd/csrc/conv_pp64.hip"
+#include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
 #include <cstdio>
 #include <vector>

@@ -205,6 +205,7 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
   }
 }
 
+#ifndef G8_NO_MAIN
 static unsigned short f2bf(float f) {
   unsigned u;
   memcpy(&u, &f, 4);
@@ -290,3 +291,4 @@ int main(int argc, char** argv) {
   }
   return 0;
 }
+#endif

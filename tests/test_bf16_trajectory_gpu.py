@@ -1,0 +1,118 @@
+"""bf16 stays on the fp32 trajectory over many steps: the proxy this repo can offer for north_star's "mIoU within +-0.3 of the
+reference", which needs VOC and ImageNet weights that are not here.
+
+* 3 steps at 65^2 (B=2+2): fp32 HIP path against the fp32 CPU oracle step by step with the oracle's sampler draws injected - SGD
+  momentum, the EMA teacher and the prototype EMA carried across steps (/root/reference/mix_label.py:162-196,
+  generalframeworks/networks/ddp_model.py:93-97) - then the bf16 HIP path on the same steps;
+* 30 steps at 129^2, B=4+4, K=21: once with ``set_compute_dtype(bfloat16)``, once in fp32, both on the HIP path with the same seeds
+  (weights, crops, device sampler): the supervised loss decreases in both, the per-step losses agree within 5 %, the prototypes agree
+  (cosine >= 0.98 at step 30), nothing is NaN.
+"""
+import math
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gpu_util import dev  # noqa: E402
+
+K = 21
+
+
+def _trainer(S, seed, gain, dtype, lr, Q, N, total_iter=1000):
+    from css_amd.networks import resnet
+    from css_amd.networks.ddp_model import Model_mix
+    from css_amd.train_step import MixTrainer
+    from oracle import css_oracle as O
+    cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}}
+    m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.5)
+    sd = O.init_state("tv", K, 256, seed, gain)
+    m.model.load_state_dict(sd)
+    m.ema_model.load_state_dict(sd)
+    m = m.to(dev()).train().set_compute_dtype(dtype)
+    return MixTrainer(m, K, lr=lr, total_iter=total_iter, min_lr=0.0, num_queries=Q, num_negatives=N, strong_threshold=0.8,
+                      weak_threshold=0.0, un_threshold=0.97)
+
+
+def _batch(S, B, seed, block):
+    g = torch.Generator().manual_seed(seed)
+    l_img, u_img = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
+    nb = (S + block - 1) // block
+    l_lab = torch.randint(0, K, (B, nb, nb), generator=g).repeat_interleave(block, 1).repeat_interleave(block, 2)[:, :S, :S].clone()
+    # make the label a function of the image so that there is something to learn: class c shifts the three channels by a fixed code
+    code = torch.randn(K, 3, generator=g)
+    l_img = l_img * 0.5 + code[l_lab].permute(0, 3, 1, 2)
+    return l_img, l_lab, u_img
+
+
+def test_three_steps_fp32_and_bf16_vs_oracle():
+    from oracle import css_oracle as O
+    S, B, seed, gain = 65, 2, 7, 0.25
+    l_img, l_lab, u_img = _batch(S, B, 3, 13)
+    # lr: on a random-init network |grad| ~ 1e4 |param|, so at the training lr one SGD step moves the logits chaotically (a handful of
+    # ReLU-mask flips in the gradient change the next loss by per cents: tests/test_train_step_gpu.py compares its second step at
+    # 0.35 for that reason); 1e-5 keeps the three steps in the regime where losses can be compared tightly while momentum, the EMA
+    # teacher and the prototype EMA still carry state from step to step
+    lr3 = float(os.environ.get("CSS_TRAJ_LR3", "1e-5"))
+    args = dict(lr=lr3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=64, num_negatives=128)
+    st = O.MixState("tv", K, 256, seed, gain)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    recs, refs = [], []
+    for _ in range(3):
+        rec = {}
+        refs.append({k: float(v) for k, v in O.train_step_mix(st, l_img, l_lab, u_img, record=rec, **args).items() if k in ("sup", "unsup", "contrast")})
+        recs.append(rec)
+    for dtype, tol in ((torch.float32, 5e-3), (torch.bfloat16, 5e-2)):
+        tr = _trainer(S, seed, gain, dtype, lr3, 64, 128, total_iter=10 ** 9)
+        for i in range(3):
+            r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()), _injected=dict(anchor=recs[i]["anchor"], negative=recs[i]["negative"]))
+            for key in ("sup", "contrast"):
+                a, b = float(r[key]), refs[i][key]
+                print(f"{dtype} step {i} {key}: hip {a:.6f} oracle {b:.6f}")
+                assert math.isfinite(a) and abs(a - b) <= tol * max(1.0, abs(b)), (dtype, i, key, a, b)
+        pa, pb = tr.prototypes.cpu().double(), st.prototypes.double()
+        present = pb.abs().sum(1) > 0
+        cos = torch.nn.functional.cosine_similarity(pa[present], pb[present], dim=1)
+        print(dtype, "prototype cosine after 3 steps: min", float(cos.min()))
+        assert float(cos.min()) > (0.9999 if dtype == torch.float32 else 0.97)
+        del tr
+        torch.cuda.empty_cache()
+
+
+def test_thirty_steps_bf16_tracks_fp32():
+    S, B, seed, gain, steps = 129, 4, 11, 0.25, 30
+    l_img, l_lab, u_img = _batch(S, B, 5, 16)
+    runs = {}
+    for name, dtype in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+        tr = _trainer(S, seed, gain, dtype, float(os.environ.get("CSS_TRAJ_LR", "6.4e-3")), 256, 512)
+        np.random.seed(0)
+        torch.manual_seed(0)
+        hist = []
+        for _ in range(steps):
+            r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()))
+            hist.append({k: float(r[k]) for k in ("sup", "unsup", "contrast", "total")})
+        runs[name] = (hist, tr.prototypes.cpu().double(), tr.flat_p.detach().cpu().double())
+        del tr
+        torch.cuda.empty_cache()
+    hf, pf, wf = runs["f32"]
+    hb, pb, wb = runs["bf16"]
+    for i in range(steps):
+        print(f"step {i:2d}  fp32 sup {hf[i]['sup']:.4f} contrast {hf[i]['contrast']:.4f}   bf16 sup {hb[i]['sup']:.4f} contrast {hb[i]['contrast']:.4f}")
+    for h in (hf, hb):
+        assert all(math.isfinite(v) for d in h for k, v in d.items() if k != "unsup")        # (unsup is NaN by definition when no pixel is valid)
+        first, last = np.mean([d["sup"] for d in h[:3]]), np.mean([d["sup"] for d in h[-3:]])
+        assert last < first - 0.02, (first, last)                                            # the supervised loss goes down
+    worst = max(abs(a["sup"] - b["sup"]) / max(abs(a["sup"]), 1e-6) for a, b in zip(hf, hb))
+    worst_c = max(abs(a["contrast"] - b["contrast"]) / max(abs(a["contrast"]), 1.0) for a, b in zip(hf, hb))
+    present = pf.abs().sum(1) > 0
+    cos = torch.nn.functional.cosine_similarity(pf[present], pb[present], dim=1)
+    wcos = float(torch.nn.functional.cosine_similarity(wf - wf.mean(), wb - wb.mean(), dim=0))
+    print(f"30 steps: worst per-step |d sup| / sup {worst:.4f}, contrast {worst_c:.4f}; prototype cosine min {float(cos.min()):.4f}; weights cosine {wcos:.6f}")
+    assert worst <= 0.05 and worst_c <= 0.10, (worst, worst_c)
+    assert float(cos.min()) >= 0.98 and wcos > 0.999

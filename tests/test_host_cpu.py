@@ -212,17 +212,49 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     assert lds == 4 * (256 + 256) * 64 + 8 * 12 * 64 * 4, lds
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
     # weight-gradient kernel: inline-asm LDS-DMA (the only user of M0), counted vmcnt, transposing reads not serialised
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z24conv_wgrad_dma256_kernel"))
-    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-    body = lines[start:end]
-    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
-    assert len(mfma) == 16, len(mfma)
-    first_label = max(i for i in range(mfma[0]) if body[i].startswith(".LBB"))
-    assert not any("vmcnt(0)" in l for l in body[first_label:mfma[-1] + 1])
-    assert any("s_waitcnt vmcnt(8)" in l for l in body)
-    n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
-    assert n_dma == 16 and sum("m0" in l.split(";")[0] for l in body) == n_dma
-    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
+    # (two instances: <false> = both cout halves in lockstep; <true> = the second half defers each step's second 16-pixel half by one
+    # step - its own loop (first step peeled by the compiler: 8 + 16 + 8 MFMAs) with its own LDS-DMA issue)
+    for sym, nmfma, ndma in (("_Z24conv_wgrad_dma256_kernelILb0EE", 16, 16), ("_Z24conv_wgrad_dma256_kernelILb1EE", 48, 24)):
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+        assert len(mfma) == nmfma, (sym, len(mfma))
+        first_label = max(i for i in range(mfma[0]) if body[i].startswith(".LBB"))
+        assert not any("vmcnt(0)" in l for l in body[first_label:mfma[-1] + 1]), sym
+        assert any("s_waitcnt vmcnt(8)" in l for l in body), sym
+        n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
+        assert n_dma == ndma and sum("m0" in l.split(";")[0] for l in body) == n_dma, (sym, n_dma)
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
+
+
+def test_conv_p8_kernel_isa(tmp_path):
+    """conv_igemm_p8_kernel (conv_p8.hip): the 8-phase K loop keeps three half-tiles of LDS-DMA in flight across its barriers - ONE
+    counted ``s_waitcnt vmcnt(6)`` per K step, never ``vmcnt(0)`` between the first and the last MFMA of the loop; 128 KiB of LDS in
+    one object; no scratch; 16 MFMAs per phase (4 phases, each in a first-step and an accumulating form)."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv_p8.hip")
+    out = str(tmp_path / "conv_p8.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    lines = open(out).read().split("\n")
+    for sym in ("_Z20conv_igemm_p8_kernelILb0ELb0EE", "_Z20conv_igemm_p8_kernelILb1ELb0EE", "_Z20conv_igemm_p8_kernelILb0ELb1EE"):
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
+        assert len(mfma) == 4 * 2 * 16, (sym, len(mfma))
+        assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1]), sym       # (the only vmcnt(0) is the one before s_endpgm)
+        waits = [l for l in body[mfma[0]:mfma[-1] + 1] if "s_waitcnt vmcnt(" in l and "ASM" not in l]
+        assert any("vmcnt(6)" in l for l in waits), sym
+        assert sum("s_barrier" in l for l in body[mfma[0]:mfma[-1] + 1]) >= 6, sym       # (+ the two around the loop edge)
+        assert not any("scratch_" in l for l in body), sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 8 * 128 * 128, sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
 
 
 def test_eval_and_checkpoint_modules_import_without_gpu_and_alias():
