@@ -284,11 +284,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #else
 #define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
 #endif
-// interleave hint for the scheduler: after every two MFMAs of the segment one VALU instruction of the offset arithmetic
+// interleave hint for the scheduler: after every MFMA of the segment one VALU / SALU instruction of the offset arithmetic
 #define P8_MIX()                                                                  \
-  _Pragma("unroll") for (int g_ = 0; g_ < 8; ++g_) {                              \
-    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                            \
+  _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);                            \
   }
 #define P8_MID()                                        \
   __builtin_amdgcn_sched_barrier(0);                    \
@@ -302,25 +302,19 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   __builtin_amdgcn_s_barrier();          \
   asm volatile("" ::: "memory");         \
   __builtin_amdgcn_sched_barrier(0);
-  // one 64 x 32 quadrant x K = 64: rows AH * 64 + 16 i, channels BH * 32 + 16 j; first: the tile's first K step starts from zero.
-  // CODE = the offset arithmetic for a later phase: it sits in the same basic block as the MFMAs so that the scheduler can spread it
-  // between them (P8_MIX).
+  // one 64 x 32 quadrant x K = 64: rows AH * 64 + 16 i, channels BH * 32 + 16 j.  CODE = the offset arithmetic for a later phase:
+  // it sits in the same basic block as the MFMAs (there is no first-K-step branch: the accumulators are zeroed by the epilogue) so
+  // that the scheduler spreads it between them, one VALU instruction per MFMA (P8_MIX).
 #define P8_QUAD(AH, FB, BH, CODE)                                                                                                      \
-  if (first) {                                                                                                                         \
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};                                                                                              \
-    CODE;                                                                                                                              \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
-        acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][0], fa[i][0], z, 0, 0, 0);                     \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j)                                        \
-        acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][1], fa[i][1], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0); \
-    P8_MIX();                                                                                                                          \
-  } else {                                                                                                                             \
-    CODE;                                                                                                                              \
-    _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
-        acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kh], fa[i][kh], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0); \
-    P8_MIX();                                                                                                                          \
-  }
+  CODE;                                                                                                                                \
+  _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
+      acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kh], fa[i][kh], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0); \
+  P8_MIX();
 
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   int par = 0;                       // buffer of the K step being multiplied
   // LDS addresses of my fragment rows in buffer par, k halves 0 / 1 (recomputed for the next K step inside phase 4's MFMA segment)
   const unsigned ra_base = (unsigned)(uintptr_t)(p8_lds_void*)a_rd, rb_base = (unsigned)(uintptr_t)(p8_lds_void*)b_rd;
@@ -330,7 +324,6 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   for (int ti = 0; ti < nmy; ++ti) {
     const Tile ct = tile_info(ti);
     for (int kt = 0; kt < ct.nk; ++kt) {
-      const bool first = kt == 0;
       bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
       // ---- phase 1: A0 x B0 ----
 #pragma unroll
@@ -452,6 +445,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    __builtin_amdgcn_sched_barrier(0);
+    // the next tile accumulates from zero (no first-K-step form of the MFMA segments: they stay one basic block)
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     __builtin_amdgcn_sched_barrier(0);
     // the staging stream is inside tile ti+1 by now (every tile has at least three K steps): prepare tile ti+2 for it
     lane_setup(ti + 2, nrowoff, nrmask, nboff);

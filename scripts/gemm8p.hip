@@ -109,14 +109,19 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
 #define G8_MFMA_QUAD(AH, FB, BH)                                                                                          \
   _Pragma("unroll") for (int kh = 0; kh < 2; ++kh) _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int j = 0; j < 2; ++j) \
       acc[(AH) * 4 + i][(BH) * 2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(FB[j][kh], fa[i][kh], acc[(AH) * 4 + i][(BH) * 2 + j], 0, 0, 0);
+#ifdef G8_NOPRIO
+#define G8_PRIO(x)
+#else
+#define G8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #define G8_PHASE_MID()                                  \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_barrier();                         \
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    \
   __builtin_amdgcn_sched_barrier(0);                    \
-  __builtin_amdgcn_s_setprio(1);
+  G8_PRIO(1);
 #define G8_PHASE_END()                   \
-  __builtin_amdgcn_s_setprio(0);         \
+  G8_PRIO(0);                            \
   __builtin_amdgcn_sched_barrier(0);     \
   __builtin_amdgcn_s_barrier();          \
   asm volatile("" ::: "memory");         \

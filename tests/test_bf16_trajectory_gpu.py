@@ -4,9 +4,13 @@ reference", which needs VOC and ImageNet weights that are not here (VERDICT r02,
 * 3 steps at 65^2 (B=2+2): fp32 HIP path against the fp32 CPU oracle step by step with the oracle's sampler draws injected - SGD
   momentum, the EMA teacher and the prototype EMA carried across steps (/root/reference/mix_label.py:162-196,
   generalframeworks/networks/ddp_model.py:93-97) - then the bf16 HIP path on the same steps;
-* 30 steps at 129^2, B=4+4, K=21: once with ``set_compute_dtype(bfloat16)``, once in fp32, both on the HIP path with the same seeds
-  (weights, crops, device sampler): the supervised loss decreases in both, the per-step losses agree within 5 %, the prototypes agree
-  (cosine >= 0.98 at step 30), nothing is NaN.
+* 30 steps at 129^2, B=4+4, K=21 at the training lr (6.4e-3): once with ``set_compute_dtype(bfloat16)``, once in fp32, both on the HIP
+  path with the same seeds (weights, crops, device sampler).  Measured on MI355X: both runs take the supervised loss from 7.03 to
+  0.107 (0.4 % apart at step 30); during the fast descent the two curves are up to half a step apart in TIME (29 % apart at equal
+  step index around step 5, where the loss halves every two steps).  Asserted: no NaN; both runs end below a tenth of the initial loss;
+  every bf16 loss lies inside the fp32 curve's one-step neighbourhood (min / max over steps i-1 .. i+1, 8 % margin); the last five
+  steps agree within 5 %; the contrastive loss agrees within 1 % at every step; prototype cosine >= 0.98 and cosine of the centred
+  weight vectors >= 0.99 at step 30.
 """
 import math
 import os
@@ -56,9 +60,9 @@ def test_three_steps_fp32_and_bf16_vs_oracle():
     l_img, l_lab, u_img = _batch(S, B, 3, 13)
     # lr: on a random-init network |grad| ~ 1e4 |param|, so at the training lr one SGD step moves the logits chaotically (a handful of
     # ReLU-mask flips in the gradient change the next loss by per cents: tests/test_train_step_gpu.py compares its second step at
-    # 0.35 for that reason); 1e-5 keeps the three steps in the regime where losses can be compared tightly while momentum, the EMA
+    # 0.35 for that reason; measured here at 1e-5: 5e-3 apart by the third step); 1e-6 keeps the three steps in the regime where losses can be compared tightly while momentum, the EMA
     # teacher and the prototype EMA still carry state from step to step
-    lr3 = float(os.environ.get("CSS_TRAJ_LR3", "1e-5"))
+    lr3 = float(os.environ.get("CSS_TRAJ_LR3", "1e-6"))
     args = dict(lr=lr3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=64, num_negatives=128)
     st = O.MixState("tv", K, 256, seed, gain)
     torch.manual_seed(0)
@@ -68,7 +72,7 @@ def test_three_steps_fp32_and_bf16_vs_oracle():
         rec = {}
         refs.append({k: float(v) for k, v in O.train_step_mix(st, l_img, l_lab, u_img, record=rec, **args).items() if k in ("sup", "unsup", "contrast")})
         recs.append(rec)
-    for dtype, tol in ((torch.float32, 5e-3), (torch.bfloat16, 5e-2)):
+    for dtype, tol in ((torch.float32, 2e-3), (torch.bfloat16, 5e-2)):       # measured: 3e-4 / 5e-4 (fp32), 2.4e-2 (bf16)
         tr = _trainer(S, seed, gain, dtype, lr3, 64, 128, total_iter=10 ** 9)
         for i in range(3):
             r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()), _injected=dict(anchor=recs[i]["anchor"], negative=recs[i]["negative"]))
@@ -106,13 +110,21 @@ def test_thirty_steps_bf16_tracks_fp32():
         print(f"step {i:2d}  fp32 sup {hf[i]['sup']:.4f} contrast {hf[i]['contrast']:.4f}   bf16 sup {hb[i]['sup']:.4f} contrast {hb[i]['contrast']:.4f}")
     for h in (hf, hb):
         assert all(math.isfinite(v) for d in h for k, v in d.items() if k != "unsup")        # (unsup is NaN by definition when no pixel is valid)
-        first, last = np.mean([d["sup"] for d in h[:3]]), np.mean([d["sup"] for d in h[-3:]])
-        assert last < first - 0.02, (first, last)                                            # the supervised loss goes down
-    worst = max(abs(a["sup"] - b["sup"]) / max(abs(a["sup"]), 1e-6) for a, b in zip(hf, hb))
+        assert np.mean([d["sup"] for d in h[-3:]]) < 0.1 * h[0]["sup"], (h[0]["sup"], h[-1]["sup"])      # the supervised loss goes down
+    sf, sb = [d["sup"] for d in hf], [d["sup"] for d in hb]
+    worst = max(abs(a - b) / a for a, b in zip(sf, sb))
+    out = []
+    for i, b in enumerate(sb):
+        win = sf[max(i - 1, 0): i + 2]
+        if not 0.92 * min(win) <= b <= 1.08 * max(win):
+            out.append((i, b, win))
+    tail = abs(np.mean(sb[-5:]) - np.mean(sf[-5:])) / np.mean(sf[-5:])
     worst_c = max(abs(a["contrast"] - b["contrast"]) / max(abs(a["contrast"]), 1.0) for a, b in zip(hf, hb))
     present = pf.abs().sum(1) > 0
     cos = torch.nn.functional.cosine_similarity(pf[present], pb[present], dim=1)
     wcos = float(torch.nn.functional.cosine_similarity(wf - wf.mean(), wb - wb.mean(), dim=0))
-    print(f"30 steps: worst per-step |d sup| / sup {worst:.4f}, contrast {worst_c:.4f}; prototype cosine min {float(cos.min()):.4f}; weights cosine {wcos:.6f}")
-    assert worst <= 0.05 and worst_c <= 0.10, (worst, worst_c)
-    assert float(cos.min()) >= 0.98 and wcos > 0.999
+    print(f"30 steps: worst |d sup| / sup at equal step index {worst:.4f}, last five steps {tail:.4f}, contrast {worst_c:.4f}; "
+          f"prototype cosine min {float(cos.min()):.4f}; weights cosine {wcos:.6f}")
+    assert not out, out
+    assert tail <= 0.05 and worst_c <= 0.01, (tail, worst_c)
+    assert float(cos.min()) >= 0.98 and wcos >= 0.99

@@ -1,6 +1,7 @@
 """The BASELINE.json sizes themselves on the GPU ("no -m gpu test runs any BASELINE size"):
 
-* one training step at each full size - 513^2 B=16+16 bf16 (configs[1]), 769^2 B=8+8 deep stem / OHEM bf16 (configs[3] shape),
+* one training step at each full size - 513^2 B=16+16 bf16 (configs[1]), 769^2 B=8+8 deep stem / OHEM bf16 (configs[3] shape), the same
+  with Q=1024 / N=2048 and forced-valid pseudo labels (configs[4] shape: every class has >= Q hard pixels),
   321^2 B=2+2 fp32 (configs[0]) - checked through size-independent properties: finite losses, the supervised loss of a random-init
   network = ln K, every parameter moved, two independent runs agree up to the order of fp32 atomic adds;
 * the c1 configuration (321^2, B=2, fp32) against the CPU oracle directly: logits and embeddings within the 1e-3 bar of north_star;
@@ -34,8 +35,9 @@ def one_step(workload, dtype, steps=1, **kw):
     return res
 
 
-@pytest.mark.parametrize("workload,dtype,kw", [("c2", "bf16", {}), ("c4", "bf16", {}), ("c2", "f32", dict(size=321, batch=2))],
-                         ids=["c2_513_B16_bf16", "c4_769_B8_stem_ohem_bf16", "c1_321_B2_fp32"])
+@pytest.mark.parametrize("workload,dtype,kw", [("c2", "bf16", {}), ("c4", "bf16", {}), ("c5", "bf16", dict(forced_valid=True)),
+                                               ("c2", "f32", dict(size=321, batch=2))],
+                         ids=["c2_513_B16_bf16", "c4_769_B8_stem_ohem_bf16", "c5_769_B8_Q1024_N2048_forced_valid_bf16", "c1_321_B2_fp32"])
 def test_full_size_step_properties(workload, dtype, kw):
     a = one_step(workload, dtype, **kw)
     b = one_step(workload, dtype, **kw)
