@@ -382,6 +382,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     const int mrow0 = ct.m0 + wm * 128, n0w = ct.n0 + wn * 64;
     const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
+    // last tile of this workgroup: the ghost LDS-DMAs (issued by the last two K steps) must have landed before the workgroup's LDS is
+    // released - wait for them HERE, ahead of the stores, so that the wave can end with its stores in flight.  (A `vmcnt(0)` behind
+    // the stores holds the CU until the whole chip's output burst - 256 tiles x 128 KiB at once - has drained: 5-20 % of a launch
+    // in profiles/r03_store_stall.txt.)
+    if (ti == nmy - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p8_u32x4 radd[ADD ? 8 : 1][2];
     if (ADD) {
       const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
@@ -415,7 +420,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = p8_pack2(p8_lo(v[e]) + p8_lo(r[e]), p8_hi(v[e]) + p8_hi(r[e]));
         }
+#if defined(P8_ABL_NOSTORE)       // timing ablation (scripts/p8_bench.hip): keep the values alive, drop the stores
+        asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#else
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(ok ? rowb + (unsigned)n * 2u : P8_OOB), 0, 0);
+#endif
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -457,7 +466,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
   }
   if (wm == 0) __builtin_amdgcn_s_barrier();           // the barrier the other half ran at the start
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ghost DMAs must have landed before the workgroup's LDS is released
+  if (nmy == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (a workgroup without a tile: only its prologue's ghost DMAs)
 }
 
 // Supported: what conv_pp64.hip supports (at least three 64-channel K steps per tile).  CSS_NO_P8_CONV=1: back to conv_pp64.hip.

@@ -77,10 +77,13 @@ int main() {
       const int tiles = ((M + 255) / 256) * ((s.Cout + 255) / 256), grid = tiles < 256 ? tiles : 256;
       auto run = [&](int v) {
         ConvArgs b = a;
-        b.dst = dy[v];
-        if (ep == 1) { b.stats = dstat[v]; b.stat_Mg = M / 2; b.stat_G = 2; }
+        const int ob = (v == 0 || v == 4) ? 0 : 1;       // output buffer: pp64 variants -> 0, the others -> 1
+        b.dst = dy[ob];
+        if (ep == 1) { b.stats = dstat[ob]; b.stat_Mg = M / 2; b.stat_G = 2; }
         if (v == 0) css_launch_conv_pp64(b, grid, 0);
         else if (v == 1) css_launch_conv_p8(b, grid, 0);
+        else if (v == 3) css_launch_conv_p8(b, tiles, 0);             // the same kernel, one workgroup per tile (not persistent)
+        else if (v == 4) css_launch_conv_pp64(b, tiles, 0);
         else hipLaunchKernelGGL(gemm8p_kernel, dim3(tiles), dim3(512), 0, 0, dx, dw, dy[1], M, s.Cout, s.Cin);   // the yardstick on the same GEMM
       };
       const bool gemm = s.R == 1 && ep == 0 && s.Cout % 256 == 0 && s.Cin % 64 == 0;
@@ -114,9 +117,10 @@ int main() {
         hipMemcpy(h2.data(), dy[1], ny * 2, hipMemcpyDeviceToHost);
         for (size_t i = 0; i < ny; ++i) gmism += h0[i] != h2[i];
       }
-      std::vector<float> us[3];
+      std::vector<float> us[5];
       for (int r = 0; r < rounds; ++r)
-        for (int v = 0; v < (gemm ? 3 : 2); ++v) {
+        for (int v = 0; v < 5; ++v) {
+          if (v == 2 && !gemm) continue;
           for (int i = 0; i < 2; ++i) run(v);
           const int reps = 10;
           hipEventRecord(e0, 0);
@@ -127,13 +131,15 @@ int main() {
           hipEventElapsedTime(&ms, e0, e1);
           us[v].push_back(ms / reps * 1e3f);
         }
-      std::sort(us[0].begin(), us[0].end()); std::sort(us[1].begin(), us[1].end()); std::sort(us[2].begin(), us[2].end());
+      std::sort(us[0].begin(), us[0].end()); std::sort(us[1].begin(), us[1].end()); std::sort(us[2].begin(), us[2].end()); std::sort(us[3].begin(), us[3].end()); std::sort(us[4].begin(), us[4].end());
       const double flops = 2.0 * M * s.Cout * a.Ktot;
       const bool ok = mism == 0 && smism == 0 && racebad == 0;
       bad_total += !ok;
       printf("%-32s %-6s M=%d K=%d N=%d  pp64 %8.1f us (%6.1f TF)  p8 %8.1f us (%6.1f TF)  median p8/pp64 %.3f  mismatch %zu stats %zu racebad %d  %s\n", s.name,
              ep == 0 ? "plain" : ep == 1 ? "stats" : "addend", M, a.Ktot, s.Cout, us[0][0], flops / us[0][0] * 1e-6, us[1][0], flops / us[1][0] * 1e-6,
              us[1][rounds / 2] / us[0][rounds / 2], mism, smism, racebad, ok ? "OK" : "FAIL");
+      printf("%-32s        one workgroup per tile: p8 %8.1f us (%6.1f TF) median / pp64 persistent %.3f;  pp64 %8.1f us (%6.1f TF) median / pp64 persistent %.3f\n", "",
+             us[3][0], flops / us[3][0] * 1e-6, us[3][rounds / 2] / us[0][rounds / 2], us[4][0], flops / us[4][0] * 1e-6, us[4][rounds / 2] / us[0][rounds / 2]);
       if (gemm) printf("%-32s        gemm8p (yardstick, one workgroup per tile) %8.1f us (%6.1f TF)  median gemm8p/pp64 %.3f  mismatch vs pp64 %zu\n", "", us[2][0],
                        flops / us[2][0] * 1e-6, us[2][rounds / 2] / us[0][rounds / 2], gmism);
       fflush(stdout);
