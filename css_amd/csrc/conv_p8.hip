@@ -61,11 +61,34 @@ __device__ __forceinline__ float p8_lo(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float p8_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
+// Diagnostic build only (-DP8_STAMP, scripts/p8_bench.hip): s_memtime stamps at the segment boundaries of the first two tiles, written at
+// the very end through a.bias (unused by this kernel) - [workgroup][wave group][8] 64-bit ticks.
+#ifdef P8_STAMP
+#define P8_STAMP_AT(i)                                                                                  \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    unsigned long long t_;                                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    if ((i) < 8) stamps[(i)] = t_;                                                                      \
+  } while (0)
+#else
+#define P8_STAMP_AT(i)
+#endif
+
 template <bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
+#ifdef P8_STAMP
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  P8_STAMP_AT(0);
+#endif
   constexpr int BM = 256, BN = 256, BK = 64;
   constexpr int HALF = 128 * 128;                                // one half-tile: 128 rows of 128 bytes
+#ifdef P8_PSTAMPS
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + 8 * 256];     // + 64 stamp words per wave (diagnostic build)
+#else
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF];     // [buffer 0 / 1][A0, A1, B0, B1]
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -128,8 +151,10 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   //   B half h, local row r -> channel (r >> 5) * 64 + h * 32 + (r & 31) of the tile
   const int cch = (lane & 7) ^ (((wave & 1) << 2) | (lane >> 4));
   const int tabv_da = a.tab_da[lane < 63 ? lane : 62], tabv_kb = a.tab_kb[lane < 63 ? lane : 62], tabv_tap = a.tab_tap[lane < 63 ? lane : 62];
-  struct KPos { int ti, cs, it, nt, vb; bool live, need; };
-  KPos ps = {0, 0, 0, 1, 0, false, true};
+  // Position of the staging stream: tile ti, inner / outer counter of the K order (korder 1: tap inner, channel slice outer; 0: the
+  // reverse), with their limits; live = the tile exists (else ghost steps: zero fills), need = the next step is the first of tile ti.
+  struct KPos { int ti, pin, pout, lin, lout, vb; int live, need; };
+  KPos ps = {0, 0, 0, 1, 1, 0, 0, 1};
   // row q = 2 h + i (h: half-tile, i: piece)
   int rowoff[4], nrowoff[4];      // byte offset of the tap-(0,0) source pixel of my rows (+ my chunk), may be out of range: see rmask
   unsigned rmask[4], nrmask[4];   // bit (tr*S + ts): that tap of the row lies inside the source image
@@ -185,51 +210,50 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       bo[q] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)cch * 16u : P8_OOB;
     }
   };
-  auto kpos_switch = [&](KPos& p) {
-    p.need = false;
-    p.live = p.ti < nmy;
-    if (!p.live) return;
-    const Tile t = tile_info(p.ti);
-    p.cs = 0;
-    p.it = 0;
-    p.nt = __builtin_popcount(t.trm) * a.S;
-    p.vb = ((int)t.trm - 1) * 9;
-  };
-  auto kpos_next = [&](KPos& p) {
-    if (!p.live) return;
-    bool done = false;
-    if (a.korder == 0) {
-      if (++p.cs == ncs) {
-        p.cs = 0;
-        done = ++p.it == p.nt;
-      }
-    } else {
-      if (++p.it == p.nt) {
-        p.it = 0;
-        done = ++p.cs == ncs;
-      }
-    }
-    if (done) {
-      ++p.ti;
-      p.need = true;
-    }
-  };
-  // scalars of the K step whose offsets are being computed (set in phase 4 by step_begin; the offsets of that step's four half-tiles
-  // are computed from them in the MFMA segments of the next K step's phases 1-3)
+  // scalars of the K step whose offsets are being computed (set in phase 4; the offsets of that step's four half-tiles are computed from
+  // them in the MFMA segments of the next K step's phases 1-3)
   int tap_cur = 0, da_cur = 0, lim_cur = 0;
   unsigned kb_cur = 0;
-  auto step_begin = [&]() {
+  // The stream enters tile ps.ti (rare: once per tile, so it may branch; it sits in phase 4's load segment).
+  auto step_switch = [&]() {
     if (ps.need) {
-      kpos_switch(ps);
+      ps.need = 0;
+      ps.live = ps.ti < nmy;
+      if (ps.live) {
+        const Tile t = tile_info(ps.ti);
+        const int nt = __builtin_popcount(t.trm) * a.S;
+        ps.pin = 0;
+        ps.pout = 0;
+        ps.lin = a.korder ? nt : ncs;
+        ps.lout = a.korder ? ncs : nt;
+        ps.vb = ((int)t.trm - 1) * 9;
+      }
 #pragma unroll
       for (int q = 0; q < 4; ++q) { rowoff[q] = nrowoff[q]; rmask[q] = nrmask[q]; boff[q] = nboff[q]; }
     }
-    const int ix = ps.vb + ps.it;
+  };
+  // Scalars of the next K step + advance: BRANCH-FREE (selects only), so that it can sit inside phase 4's MFMA segment, spread between
+  // the MFMAs by the scheduler.  (The first version - if / else chains, ~60 SALU with five taken branches in phase 4's load segment -
+  // made phase 4 the longest phase of the K step: profiles/r03_p8_phase_stamps.txt.)
+  auto step_scalars = [&]() {
+    const int it = a.korder ? ps.pin : ps.pout, cs = a.korder ? ps.pout : ps.pin;
+    const int ix = ps.vb + it;
     tap_cur = __builtin_amdgcn_readlane(tabv_tap, ix);
-    da_cur = __builtin_amdgcn_readlane(tabv_da, ix) + ps.cs * (BK * 2);
-    kb_cur = (unsigned)(__builtin_amdgcn_readlane(tabv_kb, ix) + ps.cs * (BK * 2));
-    lim_cur = ps.live ? a.Cs - ps.cs * BK : 0;                 // channels left in this slice (ragged last slice); 0: ghost step
-    kpos_next(ps);
+    da_cur = __builtin_amdgcn_readlane(tabv_da, ix) + cs * (BK * 2);
+    kb_cur = (unsigned)(__builtin_amdgcn_readlane(tabv_kb, ix) + cs * (BK * 2));
+    lim_cur = ps.live ? a.Cs - cs * BK : 0;                    // channels left in this slice (ragged last slice); 0: ghost step
+    const int pin1 = ps.pin + 1;
+    const int wrap = pin1 == ps.lin;
+    const int pout1 = ps.pout + wrap;
+    const int done = wrap & (pout1 == ps.lout) & ps.live;
+    ps.pin = wrap ? 0 : pin1;
+    ps.pout = pout1;
+    ps.ti += done;
+    ps.need |= done;
+  };
+  auto step_begin = [&]() {
+    step_switch();
+    step_scalars();
   };
   unsigned char* const st_base = smem + wave * 1024;
   // The per-piece offsets are computed one phase AHEAD, inside the MFMA segment of the wave that will issue them (voff_a / voff_b
@@ -243,12 +267,16 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     for (int i = 0; i < 2; ++i) {
       const int q = h * 2 + i;
       v[i] = (rmask[q] & tb) ? (unsigned)(rowoff[q] + da_cur) : P8_OOB;
+      asm volatile("" : "+v"(v[i]));      // (pinned here: otherwise the optimizer sinks the arithmetic into the load segment of the phase that uses it)
     }
   };
   auto voff_b = [&](int h, unsigned (&v)[2]) {
     const bool okc = cch * 8 < lim_cur;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) v[i] = okc ? boff[h * 2 + i] + kb_cur : P8_OOB;     // (an OOB row stays out of range with kb added)
+    for (int i = 0; i < 2; ++i) {
+      v[i] = okc ? boff[h * 2 + i] + kb_cur : P8_OOB;          // (an OOB row stays out of range with kb added)
+      asm volatile("" : "+v"(v[i]));
+    }
   };
   auto stage = [&](__amdgpu_buffer_rsrc_t rs, int par, int slot, const unsigned (&v)[2]) {      // slot: 0 = A0, 1 = A1, 2 = B0, 3 = B1
     unsigned char* const d = st_base + (par * 4 + slot) * HALF;
@@ -274,22 +302,40 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   voff_b(0, vb0); voff_a(0, va0); voff_b(1, vb1); voff_a(1, va1);
   stage(rs_b, 1, 2, vb0); stage(rs_a, 1, 0, va0); stage(rs_b, 1, 3, vb1);
   step_begin();
+  P8_STAMP_AT(1);                                      // everything of the prologue issued
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");    // K step 0 has landed
   __builtin_amdgcn_s_barrier();
   if (wm == 1) __builtin_amdgcn_s_barrier();           // the second pixel half runs one barrier behind
   asm volatile("" ::: "memory");
+  P8_STAMP_AT(2);                                      // first data landed: the K loop starts
 
-#ifdef P8_NOPRIO
-#define P8_PRIO(x)
-#else
+// s_setprio around the MFMA segments: measured 1-2 % SLOWER here (profiles/r03_p8_final_harness.txt; the template needs it to keep
+// hipcc from moving MFMAs across its barriers - here sched_barriers pin the segments), so it is off unless -DP8_SETPRIO.
+#ifdef P8_SETPRIO
 #define P8_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define P8_PRIO(x)
 #endif
-// interleave hint for the scheduler: after every MFMA of the segment one VALU / SALU instruction of the offset arithmetic
+// interleave hint for the scheduler: after every MFMA of the segment up to two VALU / SALU instructions of the offset arithmetic
 #define P8_MIX()                                                                  \
   _Pragma("unroll") for (int g_ = 0; g_ < 16; ++g_) {                             \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                            \
-    __builtin_amdgcn_sched_group_barrier(0x006, 1, 0);                            \
+    __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);                            \
   }
+// -DP8_PSTAMPS=1: a stamp at every phase boundary of ONE K step (tile 0, K step 8); =2: also before / after each MFMA segment.
+// Lane 0 writes the low word into the wave's LDS stamp area (no LDS read is in flight at these points); copied out at the end.
+#ifdef P8_PSTAMPS
+#define P8_PS(idx, lvl)                                                                                                     \
+  if ((lvl) <= P8_PSTAMPS && pstamp_on) {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    unsigned long long t_;                                                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                              \
+    if (lane == 0) *(volatile unsigned*)(smem + 8 * HALF + wave * 256 + 4 * (idx)) = (unsigned)t_;                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  }
+#else
+#define P8_PS(idx, lvl)
+#endif
 #define P8_MID()                                        \
   __builtin_amdgcn_sched_barrier(0);                    \
   __builtin_amdgcn_s_barrier();                         \
@@ -325,6 +371,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     const Tile ct = tile_info(ti);
     for (int kt = 0; kt < ct.nk; ++kt) {
       bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#ifdef P8_PSTAMPS
+      const bool pstamp_on = ti == 0 && (kt == 8 || kt == 9);
+      const int pbase = (kt - 8) * 16;
+#endif
+      P8_PS(pbase + 0, 1);
       // ---- phase 1: A0 x B0 ----
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -341,8 +392,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       stage(rs_a, par ^ 1, 1, va1);                             // A1 of step t+1
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");        // my four B0 reads are done: B0 of this buffer is restaged next phase
       P8_MID();
+      P8_PS(pbase + 1, 2);
       P8_QUAD(0, fb0, 0, voff_b(0, vb0));                       // (+ offsets for phase 2; scalars of step t+2: set in phase 4 of the previous K step)
+      P8_PS(pbase + 2, 2);
       P8_END();
+      P8_PS(pbase + 3, 1);
       // ---- phase 2: A0 x B1 ----
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
@@ -352,8 +406,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       stage(rs_b, par, 2, vb0);                                 // B0 of step t+2
       P8_MID();
+      P8_PS(pbase + 4, 2);
       P8_QUAD(0, fb1, 1, voff_a(0, va0));
+      P8_PS(pbase + 5, 2);
       P8_END();
+      P8_PS(pbase + 6, 1);
       // ---- phase 3: A1 x B1 ----
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -363,21 +420,29 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       stage(rs_a, par, 0, va0);                                 // A0 of step t+2
       P8_MID();
+      P8_PS(pbase + 7, 2);
       P8_QUAD(1, fb1, 1, (voff_b(1, vb1), voff_a(1, va1)));
+      P8_PS(pbase + 8, 2);
       P8_END();
+      P8_PS(pbase + 9, 1);
       // ---- phase 4: A1 x B0 (no fragment reads: the scalar bookkeeping of the stream sits here) ----
       stage(rs_b, par, 3, vb1);                                 // B1 of step t+2
-      step_begin();                                             // scalars of step t+3 (and the tile switch of the stream)
+      step_switch();                                            // the stream enters a new tile (once per tile)
       // everything up to A1 of step t+1 has landed (this also waits for the previous tile's stores in a tile's first K step):
       // step t+1 is whole and is read from the next phase on
       asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       P8_MID();
+      P8_PS(pbase + 10, 2);
       par ^= 1;
       const unsigned po = (unsigned)par * (4 * HALF);
-      P8_QUAD(1, fb0, 0, (ra0 = ra_base + ko0 + po, ra1 = ra_base + ko1 + po, rb0 = rb_base + ko0 + po, rb1 = rb_base + ko1 + po));
+      P8_QUAD(1, fb0, 0, (ra0 = ra_base + ko0 + po, ra1 = ra_base + ko1 + po, rb0 = rb_base + ko0 + po, rb1 = rb_base + ko1 + po,
+                          step_scalars()));                     // + scalars of step t+3
+      P8_PS(pbase + 11, 2);
       P8_END();
+      P8_PS(pbase + 12, 1);
     }
 
+    if (ti < 2) P8_STAMP_AT(3 + 2 * ti);                 // K loop of tile ti done
     // ---------------- epilogue of tile ti (as conv_pp64.hip: no LDS, no barrier) ----------------
     const int mrow0 = ct.m0 + wm * 128, n0w = ct.n0 + wn * 64;
     const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
@@ -464,7 +529,22 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     // the staging stream is inside tile ti+1 by now (every tile has at least three K steps): prepare tile ti+2 for it
     lane_setup(ti + 2, nrowoff, nrmask, nboff);
     __builtin_amdgcn_sched_barrier(0);
+    if (ti < 2) P8_STAMP_AT(4 + 2 * ti);                 // epilogue (stores issued, accumulators zeroed, next-next tile set up)
   }
+#ifdef P8_PSTAMPS
+  if (a.bias && lane < 32 && (wave & 3) == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ((unsigned*)a.bias)[((size_t)blockIdx.x * 2 + wm) * 32 + lane] = *(volatile unsigned*)(smem + 8 * HALF + wave * 256 + 4 * lane);
+  }
+#endif
+#ifdef P8_STAMP
+  P8_STAMP_AT(7);
+  if (a.bias && lane == 0 && (wave & 3) == 0) {
+    unsigned long long* o = (unsigned long long*)a.bias + ((size_t)blockIdx.x * 2 + wm) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = stamps[i];
+  }
+#endif
   if (wm == 0) __builtin_amdgcn_s_barrier();           // the barrier the other half ran at the start
   if (nmy == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (a workgroup without a tile: only its prologue's ghost DMAs)
 }

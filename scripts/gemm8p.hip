@@ -40,9 +40,33 @@ __device__ __forceinline__ unsigned g8_pack2(float lo, float hi) {
 #define G8_PERSIST 0
 #endif
 
-__global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ C, int M, int N, int K) {
+#ifdef G8_STAMP
+#define G8_STAMP_AT(i)                                                                                  \
+  do {                                                                                                  \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    unsigned long long t_;                                                                              \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+    stamps[(i)] = t_;                                                                                   \
+  } while (0)
+#else
+#define G8_STAMP_AT(i)
+#endif
+__global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A, const void* __restrict__ B, void* __restrict__ C, int M, int N, int K
+#if defined(G8_STAMP) || defined(G8_PSTAMPS)
+                                                     , unsigned long long* dbg
+#endif
+) {
+#ifdef G8_STAMP
+  unsigned long long stamps[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  G8_STAMP_AT(0);
+#endif
   constexpr int HALF = 128 * 128;   // one half-tile: 128 rows of 128 bytes
+#ifdef G8_PSTAMPS
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + 8 * 256];
+#else
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF];   // [buffer 0/1][A0, A1, B0, B1]
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -100,10 +124,12 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
   // prologue: tile 0 whole, tile 1 up to B1
   stage(0, 2, 0); stage(0, 0, 0); stage(0, 3, 0); stage(0, 1, 0);
   stage(1, 2, 1); stage(1, 0, 1); stage(1, 3, 1);
+  G8_STAMP_AT(1);
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   if (wr == 1) __builtin_amdgcn_s_barrier();     // the second wave row runs one barrier behind
   asm volatile("" ::: "memory");
+  G8_STAMP_AT(2);
 
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #define G8_MFMA_QUAD(AH, FB, BH)                                                                                          \
@@ -127,8 +153,25 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
   asm volatile("" ::: "memory");         \
   __builtin_amdgcn_sched_barrier(0);
 
+#ifdef G8_PSTAMPS
+#define G8_PS(idx, lvl)                                                                                                     \
+  if ((lvl) <= G8_PSTAMPS && pstamp_on) {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+    unsigned long long t_;                                                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                              \
+    if (lane == 0) *(volatile unsigned*)(smem + 8 * HALF + wave * 256 + 4 * (idx)) = (unsigned)t_;                          \
+    __builtin_amdgcn_sched_barrier(0);                                                                                      \
+  }
+#else
+#define G8_PS(idx, lvl)
+#endif
   auto ktile = [&](auto BUFC, int t) {
     constexpr int b = decltype(BUFC)::value;
+#ifdef G8_PSTAMPS
+    const bool pstamp_on = t == 8 || t == 9;
+    const int pbase = (t - 8) * 16;
+#endif
+    G8_PS(pbase + 0, 1);
     const unsigned char* const ab = a_rd + b * 4 * HALF;
     const unsigned char* const bb = b_rd + b * 4 * HALF;
     // ---- phase 1: A0 x B0 ----
@@ -147,8 +190,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
     stage(b ^ 1, 1, t + 1);                                   // (t+1).A1
     asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");        // the four B0 reads are done: B0 of this buffer is restaged next phase
     G8_PHASE_MID();
+    G8_PS(pbase + 1, 2);
     G8_MFMA_QUAD(0, fb0, 0);
+    G8_PS(pbase + 2, 2);
     G8_PHASE_END();
+    G8_PS(pbase + 3, 1);
     // ---- phase 2: A0 x B1 ----
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -158,8 +204,11 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
     __builtin_amdgcn_sched_barrier(0);
     stage(b, 2, t + 2);                                       // (t+2).B0
     G8_PHASE_MID();
+    G8_PS(pbase + 4, 2);
     G8_MFMA_QUAD(0, fb1, 1);
+    G8_PS(pbase + 5, 2);
     G8_PHASE_END();
+    G8_PS(pbase + 6, 1);
     // ---- phase 3: A1 x B1 ----
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -169,20 +218,27 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
     __builtin_amdgcn_sched_barrier(0);
     stage(b, 0, t + 2);                                       // (t+2).A0
     G8_PHASE_MID();
+    G8_PS(pbase + 7, 2);
     G8_MFMA_QUAD(1, fb1, 1);
+    G8_PS(pbase + 8, 2);
     G8_PHASE_END();
+    G8_PS(pbase + 9, 1);
     // ---- phase 4: A1 x B0 ----
     stage(b, 3, t + 2);                                       // (t+2).B1
     asm volatile("s_waitcnt vmcnt(6)" ::: "memory");          // everything up to (t+1).A1 has landed: tile t+1 is whole
     G8_PHASE_MID();
+    G8_PS(pbase + 10, 2);
     G8_MFMA_QUAD(1, fb0, 0);
+    G8_PS(pbase + 11, 2);
     G8_PHASE_END();
+    G8_PS(pbase + 12, 1);
   };
 
   for (int t = 0; t < nk; t += 2) {
     ktile(std::integral_constant<int, 0>{}, t);
     if (t + 1 < nk) ktile(std::integral_constant<int, 1>{}, t + 1);
   }
+  G8_STAMP_AT(3);
   if (wr == 0) __builtin_amdgcn_s_barrier();
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -208,6 +264,20 @@ __global__ __launch_bounds__(512) void gemm8p_kernel(const void* __restrict__ A,
       __builtin_amdgcn_raw_buffer_store_b128(v, rs_c, (int)(((unsigned)m * (unsigned)N + (unsigned)n) * 2u), 0, 0);
     }
   }
+#ifdef G8_PSTAMPS
+  if (dbg && lane < 32 && (wave & 3) == 0) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    ((unsigned*)dbg)[((size_t)blockIdx.x * 2 + wr) * 32 + lane] = *(volatile unsigned*)(smem + 8 * HALF + wave * 256 + 4 * lane);
+  }
+#endif
+#ifdef G8_STAMP
+  G8_STAMP_AT(4);
+  if (dbg && lane == 0 && (wave & 3) == 0) {
+    unsigned long long* o = dbg + ((size_t)blockIdx.x * 2 + wr) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = stamps[i];
+  }
+#endif
 }
 
 #ifndef G8_NO_MAIN

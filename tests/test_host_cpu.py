@@ -249,8 +249,8 @@ def test_conv_p8_kernel_isa(tmp_path):
         mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
         assert len(mfma) == 4 * 16, (sym, len(mfma))
         assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1]), sym       # (the only vmcnt(0) is the one before s_endpgm)
-        waits = [l for l in body[mfma[0]:mfma[-1] + 1] if "s_waitcnt vmcnt(" in l and "ASM" not in l]
-        assert any("vmcnt(6)" in l for l in waits), sym
+        assert sum("s_waitcnt vmcnt(6)" in l for l in body) >= 2, sym                  # prologue + phase 4 of the K loop
+        assert not any("s_setprio" in l for l in body), sym                            # (measured slower here: conv_p8.hip)
         assert sum("s_barrier" in l for l in body[mfma[0]:mfma[-1] + 1]) >= 6, sym       # (+ the two around the loop edge)
         assert not any("scratch_" in l for l in body), sym
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 8 * 128 * 128, sym
