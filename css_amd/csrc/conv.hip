@@ -1378,6 +1378,217 @@ __global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs 
     }
 }
 
+// --------------------------------------------------------------------------
+// conv_wgrad_p8_kernel (r03): conv_wgrad_dma256_kernel's tile, fragments, walk and epilogue on the phase structure of conv_p8.hip.
+// What the yardstick GEMM and conv_igemm_p8_kernel taught (profiles/r03_p8_phase_stamps.txt): a load segment must hold nothing but
+// the fragment reads and the LDS-DMA issue - every VALU / SALU instruction and branch in it delays the barrier its SIMD partner's MFMA
+// segment ends on - and the two waves of a SIMD alternate cleanly only when both segments are short.  So a 32-pixel step becomes two
+// phases of one 16-pixel half each:
+//     [12 ds_read_b64_tr_b16 of (stage, half h) | Y piece h + X piece h of step t+3 | s_waitcnt vmcnt(10)]  s_barrier
+//     [lgkmcnt(0) | 8 MFMAs 32x32x16, the walk of pixel row h and the next phase's offsets spread between them]   s_barrier
+// with the second cout half (= the other wave of every SIMD) one barrier behind.  A thread's two LDS-DMA rows are pixel rows
+// prow and prow + 16 of a stage, i.e. piece i IS half i, so a half is restaged two phases after its last read (the template's rule),
+// and `vmcnt(10)` (five phases' pieces stay in flight) retires the half that the NEXT phase reads.  Same MFMA order per accumulator
+// as conv_wgrad_dma256_kernel: bit-identical results.
+__global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
+  constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
+  constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
+  constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wn = wave >> 2, wk = wave & 3;
+  const int per_z = a.tiles_k * a.tiles_n;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
+  if (zz >= a.splits) return;
+  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
+  const int m_begin = zz * a.m_per_split;
+  const int m_end = min(a.M, m_begin + a.m_per_split);
+  const int nit = (m_end - m_begin + BP - 1) / BP;
+  if (nit <= 0) return;
+
+  const int prow = tid >> 5;
+  const int schunk = ((((tid & 31) >> 2) ^ (prow & 3)) << 2) | (tid & 3);
+  const int kcol = k0 + schunk * 8;
+  const bool k_ok = kcol < a.Ktot;
+  const int tap = k_ok ? kcol / a.Cs : 0;
+  const int xc = k_ok ? kcol - tap * a.Cs : 0;
+  const int tr = tap / a.S, ts = tap - tr * a.S;
+  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
+  const int ncol = n0 + schunk * 8;
+  const bool n_ok = ncol < a.Cd;
+
+  const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
+  const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;
+  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
+  const int xrow = a.ldx * 2;
+  const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
+  const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;
+  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;
+  const int ystep = BP * a.ldy * 2;
+  int r_m[2], r_hs[2], r_ws[2];
+  unsigned r_xo[2], r_yo[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int m = m_begin + prow + i * 16;
+    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
+    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
+    const uint32_t hd = fdiv(rem, a.fd_w);
+    const uint32_t wd = rem - hd * a.fd_w.d;
+    r_m[i] = m;
+    r_hs[i] = (int)hd * a.stride + dh;
+    r_ws[i] = (int)wd * a.stride + dw_;
+    r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
+    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
+  }
+  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;
+  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
+  // offsets of pixel row i as it stands (OOB: past the slice / padding / tail columns -> zeros), then the row moves on by BP pixels
+  auto row_offsets = [&](int i, unsigned& vy, unsigned& vx) {
+    vy = (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB;
+    const bool ok = k_ok && r_m[i] < m_end && (unsigned)r_hs[i] < (unsigned)a.Hs && (unsigned)r_ws[i] < (unsigned)a.Ws;
+    vx = ok ? r_xo[i] : OOB;
+    asm volatile("" : "+v"(vy), "+v"(vx));     // (pinned: the optimizer must not sink this into the load segment that uses it)
+    r_m[i] += BP;
+    r_yo[i] += (unsigned)ystep;
+    int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
+    int dx = D0;
+    const bool cw = ws > ws_hi;
+    ws -= cw ? a.Wd * a.stride : 0;
+    hs += cw ? a.stride : 0;
+    dx += cw ? Dw : 0;
+    const bool ch = hs > hs_hi;
+    hs -= ch ? a.Hd * a.stride : 0;
+    dx += ch ? Dh : 0;
+    r_ws[i] = ws;
+    r_hs[i] = hs;
+    r_xo[i] += (unsigned)dx;
+  };
+  auto stage_half = [&](int stage, int i, unsigned vy, unsigned vx) {
+    const unsigned sy = lds0 + (unsigned)stage * ST_BYTES + (unsigned)i * 8192u;
+    dma16_lds(rs_y, sy, vy);
+    dma16_lds(rs_x, sy + T_BYTES, vx);
+  };
+
+  f32x16 acc[TN][TK];
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // prologue: steps 0, 1, 2 (data phases 0..5); offsets of data phase 6 ready for the first phase's issue
+  unsigned vy, vx;
+#pragma unroll
+  for (int st = 0; st < 3; ++st)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      row_offsets(i, vy, vx);
+      stage_half(st, i, vy, vx);
+    }
+  row_offsets(0, vy, vx);
+  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // data phase 0 has landed
+  __builtin_amdgcn_s_barrier();
+  if (wn == 1) __builtin_amdgcn_s_barrier();            // the second cout half runs one barrier behind
+  asm volatile("" ::: "memory");
+
+  // LDS byte addresses of my fragment reads in the stage being multiplied (half 0; half 1 = 16 rows = + 8192), see wg_frag_sw; they move
+  // on to the next stage inside phase 1's MFMA segment
+  unsigned fad[TN + TK];
+  {
+    const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+    const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * (g >> 1) + q) * 512u;
+#pragma unroll
+    for (int k = 0; k < TN + TK; ++k) {
+      const int C = (k < TN ? wn * WTN + k * 32 : wk * WTK + (k - TN) * 32) + 16 * (g & 1) + 4 * pp;
+      fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
+    }
+  }
+  typedef __attribute__((address_space(3))) s16x4 wgp_lds_v4;
+  auto frag = [&](unsigned ad) {
+    union { struct { s16x4 a, b; } s; bf16x8 f; } u;
+    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)ad);
+    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
+    return u.f;
+  };
+  int st_c = 0, st_i = 3;
+  for (int it = 0; it < nit; ++it) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      bf16x8 fy[TN], fx[TK];
+      // ---- load segment: fragments of half h, pieces of half h of step it+3, one counted wait ----
+#pragma unroll
+      for (int i = 0; i < TN; ++i) fy[i] = frag(fad[i] + h * 8192);
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j] + h * 8192);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_half(st_i, h, vy, vx);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // the half the NEXT phase reads has landed
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- MFMA segment: 8 MFMAs + the walk of the row the next phase issues (+ the next stage's read addresses) ----
+      row_offsets(h ^ 1, vy, vx);
+      if (h == 1) {
+        const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
+#pragma unroll
+        for (int k = 0; k < TN + TK; ++k) {
+          fad[k] += d;
+          asm volatile("" : "+v"(fad[k]));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 8; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    st_c = (st_c + 1) & 3;
+    st_i = (st_i + 1) & 3;
+  }
+  if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
+  const int l31 = lane & 31, lh = lane >> 5;
+  if (a.ws) {
+    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int kl = wk * WTK + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[nl * 256 + kl] = acc[i][j][r];
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < TN; ++i)
+#pragma unroll
+    for (int j = 0; j < TK; ++j) {
+      const int k = k0 + wk * WTK + j * 32 + l31;
+      if (k >= a.Ktot) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
+      }
+    }
+}
+
 // dw[n][k] += sum over the pixel slices of ws[tile][slice][n - n0][k - k0] (fixed order: the weight gradient is bit-reproducible).
 // grid = (64, tiles): block (bx, t) owns rows 4 bx .. 4 bx + 3 of tile t; thread = 4 consecutive k columns.
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
@@ -1627,9 +1838,12 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   if (prof) prof->begin(big, 1.0, false);
   if (!big || (size_t)a.tiles_k * a.tiles_n * a.splits * (256 * 256 * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path
   if (big) {
-    static const bool no_stag = getenv("CSS_WGRAD_NOSTAGGER") != nullptr;
-    if (no_stag) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<false>, g, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_dma256_kernel<true>, g, dim3(512), 0, st, a);
+    // CSS_WGRAD_KERNEL: 0 = conv_wgrad_dma256_kernel (both cout halves in lockstep), 1 = the same with the second half one half-step
+    // behind, 2 (default) = conv_wgrad_p8_kernel (two-phase steps)
+    static const int which = getenv("CSS_WGRAD_KERNEL") ? atoi(getenv("CSS_WGRAD_KERNEL")) : (getenv("CSS_WGRAD_NOSTAGGER") ? 0 : 2);
+    if (which == 0) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<false>, g, dim3(512), 0, st, a);
+    else if (which == 1) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<true>, g, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
   } else if (dtype == CSS_BF16)

@@ -226,6 +226,18 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
         n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
         assert n_dma == ndma and sum("m0" in l.split(";")[0] for l in body) == n_dma, (sym, n_dma)
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
+    # conv_wgrad_p8_kernel: two phases per 32-pixel step, each with its own counted wait; five phases' pieces stay in flight
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z20conv_wgrad_p8_kernel"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
+    assert len(mfma) == 16, len(mfma)
+    assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1])
+    assert sum("s_waitcnt vmcnt(10)" in l for l in body) == 3
+    assert sum("ds_read_b64_tr_b16" in l for l in body) == 24
+    n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
+    assert n_dma == 16 and sum("m0" in l.split(";")[0] for l in body) == n_dma, n_dma
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
 
 
 def test_conv_p8_kernel_isa(tmp_path):
