@@ -37,6 +37,7 @@ typedef __attribute__((address_space(3))) void p8_lds_void;
 constexpr unsigned P8_OOB = 0x80000000u;
 typedef __attribute__((ext_vector_type(4))) unsigned int p8_u32x4;
 typedef __attribute__((ext_vector_type(4))) float p8_f32x4;
+typedef __attribute__((ext_vector_type(2))) float p8_f32x2;
 
 __device__ __forceinline__ void p8_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (p8_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
@@ -83,7 +84,16 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   P8_STAMP_AT(0);
 #endif
   constexpr int BM = 256, BN = 256, BK = 64;
+  // Kernel arguments used more than once: ONE batch of scalar loads into locals the compiler cannot re-load (opaque "+s" copies).  With
+  // ~100 live SGPRs the tile / row set-up code otherwise fetches each ConvArgs field again at every use - 157 s_load + s_waitcnt pairs in
+  // the first build, ~10,000 cycles of prologue per launch (profiles/r03_p8_phase_stamps.txt) - where a spilled SGPR costs one v_readlane.
+  int a_R = a.R, a_M = a.M, a_Cd = a.Cd, a_S = a.S, a_pad = a.pad, a_dil = a.dil, a_korder = a.korder, a_mode = a.mode, a_Wd = a.Wd, a_Hs = a.Hs, a_stride = a.stride, a_m_begin = a.m_begin, a_Ws = a.Ws, a_Hd = a.Hd, a_Cs = a.Cs, a_lds = a.lds, a_ldd = a.ldd, a_Ktot = a.Ktot, a_stat_Mg = a.stat_Mg, a_ld_add = a.ld_add;
+  FastDiv a_fd_hw = a.fd_hw, a_fd_w = a.fd_w;
+  asm volatile("" : "+s"(a_R), "+s"(a_M), "+s"(a_Cd), "+s"(a_S), "+s"(a_pad), "+s"(a_dil), "+s"(a_korder), "+s"(a_mode), "+s"(a_Wd), "+s"(a_Hs));
+  asm volatile("" : "+s"(a_stride), "+s"(a_m_begin), "+s"(a_Ws), "+s"(a_Hd), "+s"(a_Cs), "+s"(a_lds), "+s"(a_ldd), "+s"(a_Ktot), "+s"(a_stat_Mg), "+s"(a_ld_add));
+  asm volatile("" : "+s"(a_fd_hw.mul), "+s"(a_fd_hw.shr), "+s"(a_fd_hw.d), "+s"(a_fd_w.mul), "+s"(a_fd_w.shr), "+s"(a_fd_w.d));
   constexpr int HALF = 128 * 128;                                // one half-tile: 128 rows of 128 bytes
+  constexpr int NEPI = 16 + (STATS ? 8 : 0);                     // store instructions of an epilogue (the addend loads of ADD are consumed inside it)
 #ifdef P8_PSTAMPS
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + 8 * 256];     // + 64 stamp words per wave (diagnostic build)
 #else
@@ -99,11 +109,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   const int G = gridDim.x, q8 = G >> 3, r8 = G & 7;
   const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
   const int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
-  const int nt_n = (a.Cd + BN - 1) / BN;
-  const int tiles = ((a.M - a.m_begin + BM - 1) / BM) * nt_n;
+  const int nt_n = (a_Cd + BN - 1) / BN;
+  const int tiles = ((a_M - a_m_begin + BM - 1) / BM) * nt_n;
   const int nmy = pos < tiles ? (tiles - pos + G - 1) / G : 0;
-  const int ncs = (a.Cs + BK - 1) / BK;                         // 64-channel slices (the last one may be ragged: Cs = 304)
-  const int hw = a.Hd * a.Wd;
+  const int ncs = (a_Cs + BK - 1) / BK;                         // 64-channel slices (the last one may be ragged: Cs = 304)
+  const int hw = a_Hd * a_Wd;
 
   unsigned long long src_p = (unsigned long long)a.src, wt_p = (unsigned long long)a.wt;
   int src_n = (int)a.src_bytes, wt_n = (int)a.wt_bytes;
@@ -117,28 +127,28 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     Tile t;
     const int lt = ti * G + pos;
     const int mt = nt_n == 1 ? lt : lt / nt_n;
-    t.m0 = a.m_begin + mt * BM;
+    t.m0 = a_m_begin + mt * BM;
     t.n0 = (lt - mt * nt_n) * BN;
-    t.trm = (1u << a.R) - 1;
-    int nvr = a.R;
-    if (a.R > 1) {
-      const int mlast = min(t.m0 + BM, a.M) - 1;
-      const int i0 = (int)fdiv((uint32_t)t.m0, a.fd_hw), i1 = (int)fdiv((uint32_t)mlast, a.fd_hw);
-      const int h0 = (int)fdiv((uint32_t)(t.m0 - i0 * hw), a.fd_w), h1 = (int)fdiv((uint32_t)(mlast - i1 * hw), a.fd_w);
+    t.trm = (1u << a_R) - 1;
+    int nvr = a_R;
+    if (a_R > 1) {
+      const int mlast = min(t.m0 + BM, a_M) - 1;
+      const int i0 = (int)fdiv((uint32_t)t.m0, a_fd_hw), i1 = (int)fdiv((uint32_t)mlast, a_fd_hw);
+      const int h0 = (int)fdiv((uint32_t)(t.m0 - i0 * hw), a_fd_w), h1 = (int)fdiv((uint32_t)(mlast - i1 * hw), a_fd_w);
       if (i1 - i0 <= 1) {
-        const int alo = h0, ahi = i1 == i0 ? h1 : a.Hd - 1, blo = i1 == i0 ? h0 : 0, bhi = h1;
+        const int alo = h0, ahi = i1 == i0 ? h1 : a_Hd - 1, blo = i1 == i0 ? h0 : 0, bhi = h1;
         unsigned msk = 0;
         int cnt = 0;
 #pragma unroll 1
-        for (int r = 0; r < a.R; ++r) {
-          const int o = a.mode == 0 ? r * a.dil - a.pad : a.pad - r * a.dil;     // source row = output row + o (stride 1 whenever R > 1)
-          const bool v = (alo + o <= a.Hs - 1 && ahi + o >= 0) || (blo + o <= a.Hs - 1 && bhi + o >= 0);
+        for (int r = 0; r < a_R; ++r) {
+          const int o = a_mode == 0 ? r * a_dil - a_pad : a_pad - r * a_dil;     // source row = output row + o (stride 1 whenever R > 1)
+          const bool v = (alo + o <= a_Hs - 1 && ahi + o >= 0) || (blo + o <= a_Hs - 1 && bhi + o >= 0);
           if (v) { msk |= 1u << r; ++cnt; }
         }
         if (cnt > 0) { t.trm = msk; nvr = cnt; }
       }
     }
-    t.nk = ncs * nvr * a.S;
+    t.nk = ncs * nvr * a_S;
     return t;
   };
 
@@ -167,47 +177,47 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     }
     const int lt = ti * G + pos;
     const int mt = nt_n == 1 ? lt : lt / nt_n;
-    const int m0 = a.m_begin + mt * BM, n0 = (lt - mt * nt_n) * BN;
+    const int m0 = a_m_begin + mt * BM, n0 = (lt - mt * nt_n) * BN;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int h = q >> 1, i = q & 1;
       const int m = m0 + i * 128 + h * 64 + wave * 8 + (lane >> 3);
       unsigned msk = 0;
       int off = 0;
-      if (m < a.M) {
-        const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
+      if (m < a_M) {
+        const uint32_t n_img = fdiv((uint32_t)m, a_fd_hw);
         const uint32_t rem = (uint32_t)m - n_img * (uint32_t)hw;
-        const int hd = (int)fdiv(rem, a.fd_w);
-        const int wd = (int)rem - hd * a.Wd;
+        const int hd = (int)fdiv(rem, a_fd_w);
+        const int wd = (int)rem - hd * a_Wd;
         int h0, w0;      // source coordinate of tap (0,0)
         bool ok0 = true;
-        if (a.mode == 0) {
-          h0 = hd * a.stride - a.pad;
-          w0 = wd * a.stride - a.pad;
+        if (a_mode == 0) {
+          h0 = hd * a_stride - a_pad;
+          w0 = wd * a_stride - a_pad;
         } else {
-          h0 = hd + a.pad;
-          w0 = wd + a.pad;
-          if (a.stride == 2) {          // (1x1 only, checked by the launcher): the pixel has a source only at even coordinates
+          h0 = hd + a_pad;
+          w0 = wd + a_pad;
+          if (a_stride == 2) {          // (1x1 only, checked by the launcher): the pixel has a source only at even coordinates
             ok0 = !((h0 | w0) & 1);
             h0 >>= 1;
             w0 >>= 1;
           }
         }
-        off = (((int)n_img * a.Hs + h0) * a.Ws + w0) * a.lds * 2 + cch * 16;
-        const int sgn = a.mode == 0 ? a.dil : -a.dil;
+        off = (((int)n_img * a_Hs + h0) * a_Ws + w0) * a_lds * 2 + cch * 16;
+        const int sgn = a_mode == 0 ? a_dil : -a_dil;
         unsigned bit = 1;
 #pragma unroll 1
-        for (int r = 0; r < a.R; ++r)
+        for (int r = 0; r < a_R; ++r)
 #pragma unroll 1
-          for (int s = 0; s < a.S; ++s, bit <<= 1) {
+          for (int s = 0; s < a_S; ++s, bit <<= 1) {
             const int hs = h0 + sgn * r, ws = w0 + sgn * s;
-            if (ok0 && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws) msk |= bit;
+            if (ok0 && (unsigned)hs < (unsigned)a_Hs && (unsigned)ws < (unsigned)a_Ws) msk |= bit;
           }
       }
       ro[q] = off;
       rm[q] = msk;
       const int n = n0 + (i * 2 + (wave >> 2)) * 64 + h * 32 + (wave & 3) * 8 + (lane >> 3);
-      bo[q] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)cch * 16u : P8_OOB;
+      bo[q] = n < a_Cd ? (unsigned)n * (unsigned)a_Ktot * 2u + (unsigned)cch * 16u : P8_OOB;
     }
   };
   // scalars of the K step whose offsets are being computed (set in phase 4; the offsets of that step's four half-tiles are computed from
@@ -221,11 +231,11 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       ps.live = ps.ti < nmy;
       if (ps.live) {
         const Tile t = tile_info(ps.ti);
-        const int nt = __builtin_popcount(t.trm) * a.S;
+        const int nt = __builtin_popcount(t.trm) * a_S;
         ps.pin = 0;
         ps.pout = 0;
-        ps.lin = a.korder ? nt : ncs;
-        ps.lout = a.korder ? ncs : nt;
+        ps.lin = a_korder ? nt : ncs;
+        ps.lout = a_korder ? ncs : nt;
         ps.vb = ((int)t.trm - 1) * 9;
       }
 #pragma unroll
@@ -236,12 +246,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   // the MFMAs by the scheduler.  (The first version - if / else chains, ~60 SALU with five taken branches in phase 4's load segment -
   // made phase 4 the longest phase of the K step: profiles/r03_p8_phase_stamps.txt.)
   auto step_scalars = [&]() {
-    const int it = a.korder ? ps.pin : ps.pout, cs = a.korder ? ps.pout : ps.pin;
+    const int it = a_korder ? ps.pin : ps.pout, cs = a_korder ? ps.pout : ps.pin;
     const int ix = ps.vb + it;
     tap_cur = __builtin_amdgcn_readlane(tabv_tap, ix);
     da_cur = __builtin_amdgcn_readlane(tabv_da, ix) + cs * (BK * 2);
     kb_cur = (unsigned)(__builtin_amdgcn_readlane(tabv_kb, ix) + cs * (BK * 2));
-    lim_cur = ps.live ? a.Cs - cs * BK : 0;                    // channels left in this slice (ragged last slice); 0: ghost step
+    lim_cur = ps.live ? a_Cs - cs * BK : 0;                    // channels left in this slice (ragged last slice); 0: ghost step
     const int pin1 = ps.pin + 1;
     const int wrap = pin1 == ps.lin;
     const int pout1 = ps.pout + wrap;
@@ -370,6 +380,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   for (int ti = 0; ti < nmy; ++ti) {
     const Tile ct = tile_info(ti);
     for (int kt = 0; kt < ct.nk; ++kt) {
+      const bool after_epi = kt == 0 && ti > 0;
       bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
 #ifdef P8_PSTAMPS
       const bool pstamp_on = ti == 0 && (kt == 8 || kt == 9);
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
         fa[i][1] = frag(ra1, i * 2048);
       }
       __builtin_amdgcn_sched_barrier(0);
-      stage(rs_a, par ^ 1, 1, va1);                             // A1 of step t+1
+      if (!after_epi) stage(rs_a, par ^ 1, 1, va1);             // A1 of step t+1 (a tile's first K step: already issued ahead of the epilogue's stores)
       asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");        // my four B0 reads are done: B0 of this buffer is restaged next phase
       P8_MID();
       P8_PS(pbase + 1, 2);
@@ -428,9 +439,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
       // ---- phase 4: A1 x B0 (no fragment reads: the scalar bookkeeping of the stream sits here) ----
       stage(rs_b, par, 3, vb1);                                 // B1 of step t+2
       step_switch();                                            // the stream enters a new tile (once per tile)
-      // everything up to A1 of step t+1 has landed (this also waits for the previous tile's stores in a tile's first K step):
-      // step t+1 is whole and is read from the next phase on
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      // everything up to A1 of step t+1 has landed: step t+1 is whole and is read from the next phase on.  vmcnt is in order and counts
+      // stores: in a tile's first K step the NEPI stores of the previous epilogue are younger than that A1 (issued ahead of them), so the
+      // wait can leave them outstanding - they get a second K step to drain before the next wait, which does include them (every CU ends
+      // its tile at the same time: 256 x 128 KiB of stores at once, ~7 us: profiles/r03_store_stall.txt)
+      if (after_epi) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 + NEPI) : "memory");      // (leaves the epilogue's stores in flight)
+      else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
       P8_MID();
       P8_PS(pbase + 10, 2);
       par ^= 1;
@@ -443,9 +457,12 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     }
 
     if (ti < 2) P8_STAMP_AT(3 + 2 * ti);                 // K loop of tile ti done
+    // A1 of the next K step goes out HERE, ahead of the stores (it is phase 1's piece of that step: see there and phase 4's wait)
+    stage(rs_a, par ^ 1, 1, va1);
+    __builtin_amdgcn_sched_barrier(0);
     // ---------------- epilogue of tile ti (as conv_pp64.hip: no LDS, no barrier) ----------------
     const int mrow0 = ct.m0 + wm * 128, n0w = ct.n0 + wn * 64;
-    const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
+    const int bnd = STATS ? (mrow0 / a_stat_Mg + 1) * a_stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
     // last tile of this workgroup: the ghost LDS-DMAs (issued by the last two K steps) must have landed before the workgroup's LDS is
     // released - wait for them HERE, ahead of the stores, so that the wave can end with its stores in flight.  (A `vmcnt(0)` behind
@@ -460,7 +477,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mrow0 + 16 * i + l15, n = nl + 32 * h;
-          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a.M && n < a.Cd) ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)n) * 2u : P8_OOB), 0, 0);
+          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a_M && n < a_Cd) ? ((unsigned)m * (unsigned)a_ld_add + (unsigned)n) * 2u : P8_OOB), 0, 0);
         }
     }
 #pragma unroll
@@ -472,14 +489,14 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
         lo[j] = p8_pack2(acc[i][j][0], acc[i][j][1]);
         hi[j] = p8_pack2(acc[i][j][2], acc[i][j][3]);
       }
-      const unsigned rowb = (unsigned)m * (unsigned)a.ldd * 2u;
+      const unsigned rowb = (unsigned)m * (unsigned)a_ldd * 2u;
 #pragma unroll
       for (int jp = 0; jp < 4; jp += 2) {
         p8_swap16(lo[jp], lo[jp + 1]);
         p8_swap16(hi[jp], hi[jp + 1]);
         p8_u32x4 v = {lo[jp], hi[jp], lo[jp + 1], hi[jp + 1]};
         const int n = nl + 16 * jp;
-        const bool ok = m < a.M && n < a.Cd;
+        const bool ok = m < a_M && n < a_Cd;
         if (ADD) {
           const p8_u32x4 r = radd[ADD ? i : 0][jp >> 1];
 #pragma unroll
@@ -495,27 +512,35 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     }
     if (STATS) {
       const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
-      const unsigned base = (unsigned)(mrow0 >> 7) * 2u * (unsigned)a.Cd * 4u;
+      const unsigned base = (unsigned)(mrow0 >> 7) * 2u * (unsigned)a_Cd * 4u;
+      // sum and sum of squares of the bf16-ROUNDED outputs (what the batch norm will read), two values per instruction (v_pk_add_f32 /
+      // v_pk_fma_f32); the row test only in the one slab per statistics group that straddles the group boundary (as conv_ws.hip)
+      const bool whole = mrow0 + 128 <= bnd;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        float ss[4] = {0.f, 0.f, 0.f, 0.f}, qq[4] = {0.f, 0.f, 0.f, 0.f};
+        p8_f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
+        auto accum = [&](bool test) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          f32x4 t = acc[i][j];
-          asm volatile("" : "+v"(t));       // opaque: otherwise the packed values of the store loop stay alive (CSE) across the epilogue
-          const unsigned lo = p8_pack2(t[0], t[1]), hi = p8_pack2(t[2], t[3]);
-          const bool keep = mrow0 + 16 * i + l15 < bnd;
-          const float v0 = keep ? p8_lo(lo) : 0.f, v1 = keep ? p8_hi(lo) : 0.f, v2 = keep ? p8_lo(hi) : 0.f, v3 = keep ? p8_hi(hi) : 0.f;
-          ss[0] += v0; ss[1] += v1; ss[2] += v2; ss[3] += v3;
-          qq[0] += v0 * v0; qq[1] += v1 * v1; qq[2] += v2 * v2; qq[3] += v3 * v3;
-        }
+          for (int i = 0; i < 8; ++i) {
+            f32x4 t = acc[i][j];
+            asm volatile("" : "+v"(t));       // opaque: otherwise the packed values of the store loop stay alive (CSE) across the epilogue
+            const unsigned lo = p8_pack2(t[0], t[1]), hi = p8_pack2(t[2], t[3]);
+            p8_f32x2 v01 = {p8_lo(lo), p8_hi(lo)}, v23 = {p8_lo(hi), p8_hi(hi)};
+            if (test && !(mrow0 + 16 * i + l15 < bnd)) { v01 = p8_f32x2{0.f, 0.f}; v23 = p8_f32x2{0.f, 0.f}; }   // (rows >= M hold zeros already)
+            s01 += v01; s23 += v23;
+            q01 += v01 * v01; q23 += v23 * v23;
+          }
+        };
+        if (whole) accum(false);
+        else accum(true);
+        const float ss[4] = {s01[0], s01[1], s23[0], s23[1]}, qq[4] = {q01[0], q01[1], q23[0], q23[1]};
         p8_f32x4 os, oq;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { os[r] = p8_row16_sum(ss[r]); oq[r] = p8_row16_sum(qq[r]); }
         const int n = n0w + 16 * j + 4 * lg;
-        const bool lane_ok = l15 == 0 && n < a.Cd && mrow0 < a.M;
+        const bool lane_ok = l15 == 0 && n < a_Cd && mrow0 < a_M;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, os), rs_s, (int)(lane_ok ? base + (unsigned)n * 4u : P8_OOB), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, oq), rs_s, (int)(lane_ok ? base + (unsigned)(a.Cd + n) * 4u : P8_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, oq), rs_s, (int)(lane_ok ? base + (unsigned)(a_Cd + n) * 4u : P8_OOB), 0, 0);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
