@@ -268,6 +268,15 @@ int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, int G, dou
   return css_launch_bn_reduce_slabs(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
                                     sums_out, C, y, ldy, tile_rows, S(stream));
 }
+size_t css_bn_ws_bytes(void) { return css_bn_ws_bytes_(); }
+int css_bn_reduce_finalize_slabs_ws(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                    float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, void* ws, int device,
+                                    css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_reduce_slabs_ws(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
+                                       sums_out, C, y, ldy, tile_rows, ws, S(stream));
+}
 int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale, float* shift, int C, int device,
                     css_stream_t stream) {

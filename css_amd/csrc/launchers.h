@@ -77,6 +77,10 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, hipStream_t st);
+size_t css_bn_ws_bytes_();
+int css_launch_bn_reduce_slabs_ws(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                                  float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, void* ws, hipStream_t st);
 int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                            float* shift, int C, hipStream_t st);

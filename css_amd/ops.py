@@ -311,6 +311,22 @@ def _row_stride(t):
     return ld if ld >= t.shape[-1] else None
 
 
+_bn_ws = {}
+
+
+def _bn_workspace(device, stream):
+    """Zero-initialised workspace of the two-level batch-norm stage 2 (css_bn_reduce_finalize_slabs_ws), one per (device, stream):
+    every call leaves it zeroed.  CSS_BN_STAGE2_ONE_LEVEL=1: None (the one-level kernel)."""
+    if _bn_one_level:
+        return None
+    key = (device.index, stream)
+    ws = _bn_ws.get(key)
+    if ws is None:
+        ws = torch.zeros(_lib.lib().css_bn_ws_bytes(), dtype=torch.uint8, device=device)
+        _bn_ws[key] = ws
+    return ws
+
+
 class _BNAct(torch.autograd.Function):
     """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
@@ -336,15 +352,15 @@ class _BNAct(torch.autograd.Function):
             mean, invstd = torch.empty(g * c, **f32), torch.empty(g * c, **f32)
             if sync and collectives_on():
                 stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)     # [G][2][C] sums + [G] local row counts
-                call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
-                     None, stats, c, y, c, fused[4], dev, st)
+                call("css_bn_reduce_finalize_slabs_ws", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
+                     None, stats, c, y, c, fused[4], _bn_workspace(y.device, st), dev, st)
                 dist.all_reduce(stats)          # SyncBN: (sum, sum of squares, count) of every rank - counts may differ per rank
                 count_t = stats[g * 2 * c:]
                 call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
                      mean, invstd, scale, shift, c, dev, st)
             else:
-                call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
-                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, fused[4], dev, st)
+                call("css_bn_reduce_finalize_slabs_ws", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
+                     float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, fused[4], _bn_workspace(y.device, st), dev, st)
         elif training:
             nrb = _lib.query("css_bn_nrb", mg, g, c, dc)
             partial = torch.empty((g, nrb, 2 * c), dtype=torch.float64, device=y.device)
@@ -433,6 +449,8 @@ _bn_groups = 1
 _nbt_sink = None
 # CSS_BN_NO_MASK=1: residual layers re-read their activation tensor for the ReLU mask in backward (round-2 behaviour; A/B and parity tests)
 _bn_bit_mask = os.environ.get("CSS_BN_NO_MASK") != "1"
+# CSS_BN_STAGE2_ONE_LEVEL=1: the one-level stage 2 of the fused statistics (round-2 kernel; A/B and parity tests)
+_bn_one_level = os.environ.get("CSS_BN_STAGE2_ONE_LEVEL") == "1"
 
 
 class bn_groups:

@@ -122,6 +122,14 @@ CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, in
                                          float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
                                          float* scale, float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows,
                                          int device, css_stream_t stream);
+/* css_bn_reduce_finalize_slabs as a two-level reduction (C/64 x 16 workgroups, fp64 atomics into the workspace, the last workgroup
+ * finalizes): same results to fp64 rounding, a third of the time.  ws: css_bn_ws_bytes() bytes, caller-owned, zero-initialised ONCE
+ * (every call leaves it zeroed); one workspace per stream.  Falls back to the one-level kernel when ws == NULL. */
+CSS_API size_t css_bn_ws_bytes(void);
+CSS_API int css_bn_reduce_finalize_slabs_ws(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
+                                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                            float* scale, float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows,
+                                            void* ws, int device, css_stream_t stream);
 CSS_API int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                             float* shift, int C, int device, css_stream_t stream);
