@@ -228,104 +228,6 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
       });
 }
 
-// bn_reduce_slabs_kernel as a TWO-LEVEL reduction in one launch (r03).  The one-level kernel reads the ~2 MB of slab rows with C/8 = 32
-// blocks and 32-byte segments per row (8 channels of a 2C-float row): 15 us per launch, 224 launches per step, all of it latency.
-// Here grid = (C/64 channel blocks) x (S2F_RP row partitions): a block reads whole 256-byte runs of its share of every group's slabs
-// (thread = 4 channels x one of 16 row lanes, fp64 accumulation), reduces its 16 row lanes in LDS and adds 2 x 64 doubles per group
-// into acc[G][2][C] with fp64 atomics (S2F_RP adders per address); the block that draws the last ticket reads acc back, finalizes every
-// channel (groups in order: the running statistics take their G updates one after the other) and leaves acc and the ticket ZERO for
-// the next launch.  acc / ticket: a caller-owned workspace, zero-initialised once (css_bn_ws_bytes).
-// Ordering: every block's atomic adds are complete (s_waitcnt vmcnt(0) after them) before its ticket add; the last block takes acc back
-// with returning atomic exchanges (read-and-zero at the memory side, where the adds were made).
-constexpr int S2F_RP = 16;
-__global__ __launch_bounds__(256) void bn_reduce_slabs_fast_kernel(const float* __restrict__ partial, int nslab, int Mg, int G, double count,
-                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                                   float* running_mean, float* running_var, float momentum, float eps,
-                                                                   float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
-                                                                   double* sums_out, int C, const bf16_t* __restrict__ y, int ldy, int BM,
-                                                                   double* __restrict__ acc, unsigned* __restrict__ ticket) {
-  __shared__ double red[2][16][64];
-  __shared__ unsigned last_flag;
-  const int tid = threadIdx.x, rl = tid >> 4, c4 = tid & 15;
-  const int cb = blockIdx.x, rp = blockIdx.y;
-  const int c = cb * 64 + c4 * 4;
-  const bool c_ok = c < C;                     // (C is a multiple of 4)
-  for (int g = 0; g < G; ++g) {
-    const int b = g * Mg, e = b + Mg;
-    const int lo = first_slab_from(b, BM);
-    int hi = first_slab_from(e, BM);
-    if (hi > nslab) hi = nslab;
-    const int n = hi - lo;
-    const int s0 = lo + (int)((long)n * rp / S2F_RP), s1 = lo + (int)((long)n * (rp + 1) / S2F_RP);
-    double a[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
-    if (c_ok) {
-      for (int r = s0 + rl; r < s1; r += 16) {
-        const float4 v = *reinterpret_cast<const float4*>(partial + (size_t)r * 2 * C + c);
-        const float4 w = *reinterpret_cast<const float4*>(partial + (size_t)r * 2 * C + C + c);
-        a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-        q[0] += w.x; q[1] += w.y; q[2] += w.z; q[3] += w.w;
-      }
-      if (rp == 0) {          // head of the group: the (< 144) rows between the group boundary and the next slab start, from y itself
-        int te = slab_start(first_slab_from(b, BM), BM);
-        if (te > e) te = e;
-        for (int r = b + rl; r < te; r += 16) {
-          const bf16x4 v = *reinterpret_cast<const bf16x4*>(y + (size_t)r * ldy + c);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const double x = (double)(float)v[k];
-            a[k] += x;
-            q[k] += x * x;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { red[0][rl][c4 * 4 + k] = a[k]; red[1][rl][c4 * 4 + k] = q[k]; }
-    __syncthreads();
-    if (tid < 128) {
-      const int w = tid >> 6, cc = tid & 63;
-      double t = 0;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) t += red[w][r][cc];
-      if (cb * 64 + cc < C) atomicAdd(acc + ((size_t)g * 2 + w) * C + cb * 64 + cc, t);
-    }
-    __syncthreads();
-  }
-  // ticket: all of this block's adds are done before it counts as arrived
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    last_flag = t == gridDim.x * gridDim.y - 1;
-    if (last_flag) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  if (sums_out && tid < G) sums_out[(size_t)G * 2 * C + tid] = (double)Mg;          // local row counts behind the sums (SyncBN)
-  for (int ch = tid; ch < C; ch += 256) {
-    for (int g = 0; g < G; ++g) {
-      double* p0 = acc + ((size_t)g * 2 + 0) * C + ch;
-      double* p1 = acc + ((size_t)g * 2 + 1) * C + ch;
-      // read-and-zero in ONE atomic at the memory side (where the adds were made): no cache of this or a later launch can hold a stale copy
-      const double a0 = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(p0), 0ull));
-      const double a1 = __longlong_as_double((long long)atomicExch(reinterpret_cast<unsigned long long*>(p1), 0ull));
-      if (sums_out) {
-        sums_out[(size_t)g * 2 * C + ch] = a0;
-        sums_out[(size_t)g * 2 * C + C + ch] = a1;
-      } else {
-        bn_finalize_one(a0, a1, count, gamma[ch], beta[ch], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
-                        scale_out + g * C, shift_out + g * C, ch);
-      }
-    }
-  }
-  if (tid == 0) atomicExch(ticket, 0u);
-}
-
 template <typename T>
 __global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, int Mg, int C, int ld,
                                                        int rows_per_block, double* partial) {
@@ -619,23 +521,6 @@ int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, doubl
   if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C || (tile_rows != 256 && tile_rows != 272)) return CSS_ERR_ARG;
   hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, 2 * cdiv(M, tile_rows), Mg, G, count, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy, tile_rows);
-  CSS_CHECK_LAUNCH();
-  return CSS_OK;
-}
-// workspace of the two-level stage 2: acc [G][2][C] fp64 for the largest (G, C) + the ticket word; zero-initialised ONCE by the caller
-size_t css_bn_ws_bytes_() { return (size_t)8 * 2 * 4096 * 8 + 256; }
-int css_launch_bn_reduce_slabs_ws(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                                  float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, void* ws, hipStream_t st) {
-  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C || (tile_rows != 256 && tile_rows != 272)) return CSS_ERR_ARG;
-  if (!ws || (C % 4) || (size_t)G * 2 * C * 8 + 256 > css_bn_ws_bytes_() || (ldy % 4) || (reinterpret_cast<uintptr_t>(y) & 7))
-    return css_launch_bn_reduce_slabs(partial, M, Mg, G, count, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift,
-                                      sums_out, C, y, ldy, tile_rows, st);
-  double* acc = reinterpret_cast<double*>(ws);
-  unsigned* ticket = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(ws) + css_bn_ws_bytes_() - 256);
-  hipLaunchKernelGGL(bn_reduce_slabs_fast_kernel, dim3(cdiv(C, 64), S2F_RP), dim3(256), 0, st, partial, 2 * cdiv(M, tile_rows), Mg, G, count, gamma,
-                     beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy, tile_rows, acc,
-                     ticket);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

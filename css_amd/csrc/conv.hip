@@ -1670,6 +1670,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
+    if (a.add_mask && (no_dma || no_256 || !css_conv_ws_supported(a, n_cu))) return CSS_ERR_ARG;   // masked addend: conv_ws.hip only (ask css_conv_ws_applies first)
     if (!no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) {
       // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
       P0(true, 1.0, true);

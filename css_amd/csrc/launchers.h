@@ -21,6 +21,8 @@ struct ConvArgs {
   int stat_G;                     // number of statistics groups (total M / stat_Mg), filled by the launcher
   const void* addend;             // [M][ld_add] tensor added to the result before it is stored (residual gradient), or null
   int ld_add;
+  const unsigned char* add_mask;  // with addend (conv_ws.hip only): [M][Cd/8] ReLU bit mask of css_bn_apply_mask - element e of a 16-byte addend
+  unsigned mask_bytes;            // vector counts only where bit e of its byte is set (the residual gradient bn_bwd_apply would have written)
   // conv_igemm_pp_kernel (conv_pp.hip), filled by the launcher:
   unsigned dst_bytes;             // bytes of dst the launch may write (buffer descriptor: rows >= M are dropped by the range check)
   FastDiv fd_hw, fd_w;            // division by Hd*Wd and Wd
@@ -77,10 +79,6 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, hipStream_t st);
-size_t css_bn_ws_bytes_();
-int css_launch_bn_reduce_slabs_ws(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
-                                  float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
-                                  float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, void* ws, hipStream_t st);
 int css_launch_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                            float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                            float* shift, int C, hipStream_t st);

@@ -380,9 +380,10 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
                    check=True, capture_output=True, timeout=600)
     lines = open(out).read().split("\n")
     # (KS, STATS, ADD) -> the vmcnt values of the stage wait in tile 0 / tile 1 / later tiles (conv_ws.hip: W0, W1, W2)
+    # (ADD: 0 none, 1 addend, 2 addend under the ReLU bit mask: 8 more loads per tile)
     for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (22, 38, 46)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (10, 26, 34)),
-                              (8, 1, 0, (14, 26)), (8, 0, 0, (14, 22))):
-        sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELb{ad}EEv8ConvArgs:"
+                              (8, 1, 0, (14, 26)), (8, 0, 0, (14, 22)), (4, 0, 2, (30, 54, 62)), (2, 0, 2, (22, 46, 54)), (1, 0, 2, (18, 42, 50))):
+        sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELi{ad}EEv8ConvArgs:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
@@ -403,12 +404,12 @@ def test_conv_ws_vmcnt_accounting_model():
     pieces -> MFMAs, the tile's stores) for every instance and check the constants of the source (W0 / W1 / W2, also pinned from the ISA
     by test_conv_ws_kernel_isa_and_shape_rules) against the exact counts."""
     for ks in (1, 2, 4, 8):
-        for stats, add in ((0, 0), (1, 0), (0, 1)):
+        for stats, add in ((0, 0), (1, 0), (0, 1), (0, 2)):          # add = 2: addend + its ReLU bit mask (8 more loads per tile)
             if ks == 8 and add:
                 continue
             nt = 2 if ks <= 4 else 1
             la = nt * ks
-            nld, nst = (8 if add else 0), 8 + (4 if stats else 0)
+            nld, nst = (16 if add == 2 else 8 if add else 0), 8 + (4 if stats else 0)
             w0 = 2 * (la - 1) + nld
             w1 = w0 + (nld if nt >= 2 else 0) + nst
             w2 = w1 + (nst if nt >= 2 else 0)

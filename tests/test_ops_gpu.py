@@ -331,31 +331,6 @@ def test_conv_epilogue_bn_statistics(case):
     want = torch.stack([yy.sum(1), (yy * yy).sum(1)], 1).reshape(-1)
     assert rel_err(sums.cpu()[:groups * 2 * cout], want) < 1e-6
     assert sums.cpu()[groups * 2 * cout:].tolist() == [float(mg)] * groups        # this rank's rows per group ride behind the sums
-    # the two-level stage 2 (fp64 atomics into a zeroed workspace, the last workgroup finalizes) = the one-level kernel: raw sums
-    # and the train-mode finalize, on repeated calls (every call must leave the workspace zeroed)
-    from css_amd import _lib
-    ws = torch.zeros(_lib.lib().css_bn_ws_bytes(), dtype=torch.uint8, device=dev())
-    for rep in range(3):
-        sums2 = torch.full_like(sums, -1.0)
-        call("css_bn_reduce_finalize_slabs_ws", part, mg * groups, mg, groups, float(mg), None, None, None, None, 0.0, 0.0, None, None, None,
-             None, sums2, cout, y, cout, bm, ws, d, st)
-        assert rel_err(sums2.cpu()[:groups * 2 * cout], sums.cpu()[:groups * 2 * cout]) < 1e-12, rep
-        assert torch.equal(sums2[groups * 2 * cout:], sums[groups * 2 * cout:])
-        torch.cuda.synchronize()
-        assert int(ws.count_nonzero()) == 0, rep
-    fin = []
-    for two_level in (False, True):
-        rm, rv = torch.zeros(cout, device=dev()), torch.ones(cout, device=dev())
-        o = [torch.empty(groups * cout, device=dev()) for _ in range(4)]
-        if two_level:
-            call("css_bn_reduce_finalize_slabs_ws", part, mg * groups, mg, groups, float(mg), gamma, beta, rm, rv, 0.1, 1e-5, *o, None, cout, y,
-                 cout, bm, ws, d, st)
-        else:
-            call("css_bn_reduce_finalize_slabs", part, mg * groups, mg, groups, float(mg), gamma, beta, rm, rv, 0.1, 1e-5, *o, None, cout, y,
-                 cout, bm, d, st)
-        fin.append([t.cpu() for t in o] + [rm.cpu(), rv.cpu()])
-    for a_, b_ in zip(*fin):
-        assert rel_err(a_, b_) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
