@@ -213,24 +213,6 @@ int css_conv2d_wgrad(const void* x, const void* dy, float* dw, float* ws, size_t
   ConvProf cp(2, 7, alg_flops, S(stream));
   return css_launch_wgrad(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
-int css_conv2d_dgrad_add_masked(const void* dy, const void* w_t, void* dx, const void* addend, const unsigned char* mask, int ld_add, int N, int H,
-                                int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R, int Sk, int stride, int pad, int dil,
-                                double alg_flops, int dtype, int device, css_stream_t stream) {
-  set_dev(device);
-  if (stride != 1 || !mask || !addend || ld_add != Cin || (Cin % 8)) return CSS_ERR_ARG;
-  ConvArgs a = {};
-  a.src = dy; a.wt = w_t; a.dst = dx; a.bias = nullptr;
-  a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.lds = lddy;
-  a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
-  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add;
-  a.add_mask = mask;
-  a.M = N * H * W; a.Ktot = R * Sk * Cout;
-  if ((size_t)a.M * (Cin / 8) >= 0x7FFFFFF0ull) return CSS_ERR_ARG;
-  a.mask_bytes = (unsigned)((size_t)a.M * (Cin / 8));
-  ConvProf cp(1, 6, alg_flops, S(stream));
-  cp.ws_bytes = conv1x1_bytes(a, dtype);
-  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
-}
 int css_conv_ws_applies(int M, int K, int ld_src, int N, int ld_dst, int R, int Sk, int stride, int pad, int has_stats, int has_addend, int ld_add,
                         int has_bias, int dtype, int n_cu) {
   static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;

@@ -474,8 +474,13 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_b
 // Template: BM x BN tile with NWM x NWN waves of 64 x (BN/NWN) outputs.  <256,128,4,2> is the kernel described above; the 4-wave
 // instances <128,128,2,2> / <128,64,2,2> serve leftover rows and the narrow layers (rows per DMA pass = 8 per wave, so a thread's
 // rows are prow + 8*NW*i and the swizzle term ((r >> 1) & 7) stays the same for all of them; vmcnt = A_IT + B_IT).
-template <int BM, int BN, int NWM, int NWN, int NST = 3>
-__global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const ConvArgs a) {
+// NWK = 2 (r03, the leftover launches: <= one workgroup per CU, so a CU's four SIMDs hold ONE wave each and nothing hides the K loop's
+// wait -> barrier -> issue -> read -> multiply chain, 0.96 us per K step): a second group of NWM x NWN waves in the same workgroup runs
+// the second half of the K steps on a stage ring of its own - two waves per SIMD at different points of the chain, half as many steps
+// each - and the halves are added through LDS before the (unchanged) epilogue.  fp32 sums of two halves instead of one chain: the
+// result differs from NWK = 1 in the last bit (the parity tests compare both against torch-CPU).
+template <int BM, int BN, int NWM, int NWN, int NST = 3, int NWK = 1>
+__global__ __launch_bounds__(64 * NWM * NWN * NWK) void conv_igemm_dma_kernel(const ConvArgs a) {
   using T = bf16_t;
   constexpr int BK = 64, VEC = 8, NW = NWM * NWN, RP = 8 * NW;     // NST LDS stages, NST-1 K tiles in flight
   constexpr int A_IT = BM / RP, B_IT = BN / RP;        // DMA wave-instructions per thread per stage (rows t>>3 + RP i)
@@ -489,18 +494,20 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
   // the waitcnt pass then puts s_waitcnt vmcnt(0) in front of the fragment reads (it must assume the in-flight LDS-DMA
   // writes alias them), which serialises the two-tiles-in-flight pipeline (measured: 64 -> 90 ms per step).
 #ifdef CSS_ABL_NOSSTAT
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NWK * NST * ST_BYTES];
   float* sstat = reinterpret_cast<float*>(smem);
   constexpr bool DSTATS = false;
 #else
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + NPAIR * 12 * WTN * 4];
-  float* sstat = reinterpret_cast<float*>(smem + NST * ST_BYTES);   // 4 wave pairs x [counter + pad | slot | slot], see store_wave_tile
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NWK * NST * ST_BYTES + NPAIR * 12 * WTN * 4];
+  float* sstat = reinterpret_cast<float*>(smem + NWK * NST * ST_BYTES);   // 4 wave pairs x [counter + pad | slot | slot], see store_wave_tile
   constexpr bool DSTATS = true;
   if (a.stats && threadIdx.x < NPAIR) reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * WTN] = 0;   // ordered by the main loop's barriers
 #endif
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kg = NWK > 1 ? (int)threadIdx.x / (64 * NW) : 0;                 // K group of this wave (wave-uniform)
+  const int tid = (int)threadIdx.x - kg * (64 * NW), lane = tid & 63, wave = tid >> 6;     // thread / wave index inside its K group
   const int wm = wave / NWN, wn = wave % NWN;
+  unsigned char* const sring = smem + kg * (NST * ST_BYTES);                  // this group's stage ring
   const int nt_n = (a.Cd + BN - 1) / BN;
   const int ntiles = gridDim.x;
   const int q8 = ntiles >> 3, r8 = ntiles & 7;
@@ -582,6 +589,25 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
     }
   }
 
+  // K steps of this group: [kg * nkg, min(nk, (kg + 1) * nkg)); a later group starts at the tap / channel slice of its first step
+  // (Cs is a whole number of K tiles for this kernel: a step never straddles two taps)
+  const int nkg = (nk + NWK - 1) / NWK;
+  int steps_left = nkg;
+  if (NWK > 1) {
+    const int s0 = kg * nkg;
+    steps_left = max(0, min(nk, s0 + nkg) - s0);
+    if (kg > 0) {
+      const int ncs = a.Cs / BK, v = s0 / ncs, sl = s0 - v * ncs;
+      for (int j = 0; j < v && tr < a.R; ++j)
+        if (++ts == a.S) {
+          ts = 0;
+          ++tr;
+          while (tr < a.R && !((tr_mask >> tr) & 1)) ++tr;
+        }
+      kc += sl * BK;
+      kglob = (tr * a.S + ts) * a.Cs + kc;
+    }
+  }
   // Byte offsets of this thread's A rows for the CURRENT tap and channel position; within a tap they simply advance by
   // BK*2 bytes per K tile, so the (expensive) coordinate / bounds arithmetic runs only when the tap changes.
   unsigned offA[A_IT];
@@ -614,11 +640,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
   tap_offsets();
   // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*64*NW + w*64, +64) of the stage image
   auto issue = [&](int stage) {
-    unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
+    unsigned char* sa = sring + stage * ST_BYTES + wave * 1024;
+    const bool live = NWK == 1 || steps_left > 0;          // past this group's share: zeros into a free stage
+    --steps_left;
     unsigned char* sb = sa + A_BYTES;
 #pragma unroll
-    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * (NW * 1024), offA[i]);
-    const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * 2u : OOB;
+    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * (NW * 1024), live ? offA[i] : OOB);
+    const unsigned kb = (live && kglob < a.Ktot) ? (unsigned)kglob * 2u : OOB;
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * (NW * 1024), (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
     kglob += BK;
@@ -654,7 +682,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
   for (int ks = 0; ks < 4; ++ks) koff[ks] = (((2 * ks + lh) ^ xr) << 4);
   const int a_row = (wm * WTM + l31) * ROWB, b_row = A_BYTES + (wn * WTN + l31) * ROWB;
   auto compute = [&](int stage) {
-    const unsigned char* sbase = smem + stage * ST_BYTES;
+    const unsigned char* sbase = sring + stage * ST_BYTES;
     // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (two register sets, statically indexed)
     bf16x8 fw[2][TN], fa[2][TM];
 #pragma unroll
@@ -684,7 +712,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
 #pragma unroll
   for (int s0 = 0; s0 < NST - 1; ++s0) issue(s0);
   int st_c = 0, st_i = NST - 1;
-  for (int kt = 0; kt < nk; ++kt) {
+  for (int kt = 0; kt < nkg; ++kt) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NST - 2) * (A_IT + B_IT)) : "memory");   // this wave's share of tile kt landed, later tiles may fly
     __builtin_amdgcn_s_barrier();
     issue(st_i);                       // tile kt+NST-1 (past the end: all-OOB = zeros into a free stage)
@@ -697,8 +725,31 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must land before the stages are reused below
   __builtin_amdgcn_s_barrier();
 
+  if (NWK > 1) {
+    // the second K group hands its partial sums over through ITS ring (free now); the first adds them and runs the epilogue alone
+    static_assert(NWK == 1 || NW * TN * TM * 16 * 64 * 4 <= NST * ST_BYTES, "partial sums fit one ring");
+    float* red = reinterpret_cast<float*>(smem + NST * ST_BYTES) + wave * (TN * TM * 16 * 64) + lane;
+    if (kg == 1) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * TM + j) * 16 + r) * 64] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (kg == 0) {
+#pragma unroll
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * TM + j) * 16 + r) * 64];
+    }
+  }
   // ---- epilogue (as in conv_igemm_kernel): accumulators -> wave-private LDS -> 16-byte row stores
   T* Cw = reinterpret_cast<T*>(smem) + wave * (WTM * CSTR);
+  if (kg == 0)
 #pragma unroll
   for (int i = 0; i < TN; ++i) {
 #pragma unroll
@@ -723,7 +774,8 @@ __global__ __launch_bounds__(64 * NWM * NWN) void conv_igemm_dma_kernel(const Co
     }
   }
   __syncthreads();
-  store_wave_tile<T, WTM, WTN, CSTR, BN, DSTATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane, sstat + ((wm >> 1) * NWN + wn) * 12 * WTN);
+  if (kg == 0)
+    store_wave_tile<T, WTM, WTN, CSTR, BN, DSTATS>(a, Cw, m0 + wm * WTM, n0 + wn * WTN, wm & 1, lane, sstat + ((wm >> 1) * NWN + wn) * 12 * WTN);
 }
 
 // --------------------------------------------------------------------------
@@ -1625,9 +1677,13 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 // --------------------------------------------------------------------------
 // 128-row tiles (leftover rows of the big-tile kernels, layers with Cout <= 64): LDS-DMA instances; CSS_SMALL_DMA=0 selects the
 // register-staged kernels instead (kept for the fp32 path and as the A/B reference)
-static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b) {
+static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b, int n_cu = 0) {
   static const bool dma = !(getenv("CSS_SMALL_DMA") && atoi(getenv("CSS_SMALL_DMA")) == 0) && !getenv("CSS_NO_DMA_CONV");
-  if (dma && b.Cs % 64 == 0) {      // (channel counts that are not whole K tiles - the 7x7 stem - change tap inside a tile: register-staged)
+  static const bool no_split = getenv("CSS_NO_SMALL_SPLITK") != nullptr;
+  if (dma && b.Cs % 64 == 0 && !no_split && n_cu > 0 && (int)g.x <= n_cu && b.Ktot >= 8 * 64 && !b.bias) {
+    // at most one workgroup per CU (the leftover rows of the persistent kernels): two K groups per workgroup
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2, 3, 2>), g, dim3(512), 0, st, b);
+  } else if (dma && b.Cs % 64 == 0) {      // (channel counts that are not whole K tiles - the 7x7 stem - change tap inside a tile: register-staged)
     hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2>), g, dim3(256), 0, st, b);
   } else {
     hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, b);
@@ -1670,7 +1726,6 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
-    if (a.add_mask && (no_dma || no_256 || !css_conv_ws_supported(a, n_cu))) return CSS_ERR_ARG;   // masked addend: conv_ws.hip only (ask css_conv_ws_applies first)
     if (!no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) {
       // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
       P0(true, 1.0, true);
@@ -1715,7 +1770,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
           static const int rem_mode = getenv("CSS_REM_N64") ? atoi(getenv("CSS_REM_N64")) : 1;
           const int wgs128 = cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128);
           if ((rem_mode == 1 && wgs128 * 2 <= n_cu) || (rem_mode == 2 && wgs128 <= n_cu))
-            launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b);
+            launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b, n_cu);
           else
             launch_small_n128(dim3(wgs128), st, b);
         }

@@ -81,7 +81,7 @@ template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_st
 #endif
 
 // KS = K / 64 (stages per pixel tile).  grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 256) == 0.
-template <int KS, bool STATS, int ADD>
+template <int KS, bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   constexpr int NT = KS <= 4 ? 2 : 1;                            // whole tiles of look-ahead (K = 512: one - the ring is 160 KiB either way)
   constexpr int BM = 128, BN = 256, LA = NT * KS, NS = LA + 2;
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #else
   constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = false;
 #endif
-  constexpr int NLD = ADD == 2 ? 16 : (ADD ? 8 : 0), NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
+  constexpr int NLD = ADD ? 8 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
   constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
   constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + (NT >= 2 ? NLD : 0) + NST, W2 = W1 + (NT >= 2 ? NST : 0);   // vmcnt of the stage wait in tile 0, tile 1, later tiles
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
@@ -180,7 +180,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);            // first of my 8 channels in a store (after the lane swap)
 
   ws_u32x4 radd[ADD ? 8 : 1];
-  unsigned rmsk[ADD == 2 ? 8 : 1];      // ADD == 2: one byte per addend vector, bit e = element e passes (the ReLU mask of css_bn_apply_mask)
   // ---------------- epilogue of a tile (rows m0e ..): no LDS, no barrier ----------------
   auto epilogue = [&](int m0e) {
     const int bnd = STATS ? (m0e / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
@@ -193,15 +192,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       ws_swap16(hi0, hi1);
       ws_u32x4 v = {lo0, hi0, lo1, hi1};
       if (ADD) {
-        ws_u32x4 r = radd[ADD ? i : 0];
-        if (ADD == 2) {
-          // masked addend = the residual gradient bn_bwd_apply would have written (dres = da where the block's ReLU passed, else 0):
-          // bit 2e / 2e+1 of the byte -> low / high half of dword e (bitfield insert of the two sign-extended bits)
-          const int mk = (int)rmsk[ADD == 2 ? i : 0];
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            r[e] &= ((unsigned)__builtin_amdgcn_sbfe(mk, 2 * e, 1) & 0x0000ffffu) | ((unsigned)__builtin_amdgcn_sbfe(mk, 2 * e + 1, 1) & 0xffff0000u);
-        }
+        const ws_u32x4 r = radd[ADD ? i : 0];
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(r[e]), ws_hi(v[e]) + ws_hi(r[e]));
       }
@@ -248,14 +239,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     for (int i = 0; i < (ADD ? 8 : 0); ++i) {
       const int m = m0e + 16 * i + l15;
       radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)nl) * 2u : WS_OOB), 0, 0);
-    }
-    if (ADD == 2) {
-      const __amdgpu_buffer_rsrc_t rs_m = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
-#pragma unroll
-      for (int i = 0; i < (ADD == 2 ? 8 : 0); ++i) {
-        const int m = m0e + 16 * i + l15;
-        rmsk[i] = __builtin_amdgcn_raw_buffer_load_b8(rs_m, (int)(m < a.M ? (unsigned)m * (unsigned)(a.Cd >> 3) + (unsigned)(nl >> 3) : WS_OOB), 0, 0);
-      }
     }
   };
   auto mfma_half = [&](const bf16x8 (&fa)[8], int q, bool first) {
@@ -356,26 +339,6 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       // compiler reads one fragment, waits for it, issues its two MFMAs, and so on - every LDS latency exposed.  (The addend variant
       // holds 32 more registers: it reads and multiplies one 32-channel half of the stage at a time.)
       constexpr int HB = (ADD || KS > 4) ? 1 : 2;        // K halves per batch (K = 512: 128 registers of weights)
-      if constexpr (ADD == 2 && KS == 4) {
-        // masked-addend form at K = 256: 64 VGPRs of weights + 64 accumulators + 32 of addend + 8 mask words leave 16 for fragments -
-        // four pixel tiles at a time (this form is bound by its three tensor streams, not by the MFMAs)
-#pragma unroll
-        for (int hb = 0; hb < (ABL_NOMFMA ? 0 : 2); ++hb)
-#pragma unroll
-          for (int ih = 0; ih < 2; ++ih) {
-            bf16x8 fq[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) fq[i] = *reinterpret_cast<const bf16x8*>(ab + (4 * ih + i) * 2048 + (((4 * hb + lg) ^ sw) << 4));
-            __builtin_amdgcn_sched_barrier(0);
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-              for (int j = 0; j < 2; ++j)
-                acc[4 * ih + i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[2 * k + hb][j], fq[i], (k == 0 && hb == 0) ? z : acc[4 * ih + i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-      } else
 #pragma unroll
       for (int hb = 0; hb < (ABL_NOMFMA ? 0 : 2); hb += HB) {
         bf16x8 fa[HB][8];
@@ -418,10 +381,9 @@ bool css_conv_ws_supported(const ConvArgs& a, int n_cu) {
 template <int KS>
 static void launch_ws(const ConvArgs& a, int grid, hipStream_t st) {
   const dim3 g(grid), b(512);
-  if (a.stats) hipLaunchKernelGGL((conv_ws_kernel<KS, true, 0>), g, b, 0, st, a);
-  else if (a.addend && a.add_mask) hipLaunchKernelGGL((conv_ws_kernel<KS, false, 2>), g, b, 0, st, a);
-  else if (a.addend) hipLaunchKernelGGL((conv_ws_kernel<KS, false, 1>), g, b, 0, st, a);
-  else hipLaunchKernelGGL((conv_ws_kernel<KS, false, 0>), g, b, 0, st, a);
+  if (a.stats) hipLaunchKernelGGL((conv_ws_kernel<KS, true, false>), g, b, 0, st, a);
+  else if (a.addend) hipLaunchKernelGGL((conv_ws_kernel<KS, false, true>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((conv_ws_kernel<KS, false, false>), g, b, 0, st, a);
 }
 void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st) {
   a.dst_bytes = (unsigned)((size_t)a.M * a.ldd * 2);

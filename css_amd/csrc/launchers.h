@@ -21,8 +21,6 @@ struct ConvArgs {
   int stat_G;                     // number of statistics groups (total M / stat_Mg), filled by the launcher
   const void* addend;             // [M][ld_add] tensor added to the result before it is stored (residual gradient), or null
   int ld_add;
-  const unsigned char* add_mask;  // with addend (conv_ws.hip only): [M][Cd/8] ReLU bit mask of css_bn_apply_mask - element e of a 16-byte addend
-  unsigned mask_bytes;            // vector counts only where bit e of its byte is set (the residual gradient bn_bwd_apply would have written)
   // conv_igemm_pp_kernel (conv_pp.hip), filled by the launcher:
   unsigned dst_bytes;             // bytes of dst the launch may write (buffer descriptor: rows >= M are dropped by the range check)
   FastDiv fd_hw, fd_w;            // division by Hd*Wd and Wd

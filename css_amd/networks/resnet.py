@@ -44,14 +44,10 @@ class Bottleneck(nn.Module):
 
     def forward(self, x):
         identity = x
-        lazy = False
         if torch.is_grad_enabled() and x.requires_grad:
             # x feeds conv1 AND the residual branch (identity, or the downsample convolution): take that branch's input from
-            # conv1's tap so that the backward adds its gradient inside conv1's dgrad store (ops.conv2d).  Identity blocks: the
-            # gradient of that branch is bn3's incoming gradient under the block's ReLU mask - it travels as (gradient, bit mask) and
-            # conv1's dgrad masks its addend itself (tap=2 / lazy_res) where the weight-stationary kernel serves that dgrad.
-            lazy = self.downsample is None and self.training and ops.lazy_residual_ok(x, self.conv1.out_channels)
-            out, identity = self.conv1(x, tap=2 if lazy else True)
+            # conv1's tap so that the backward adds its gradient inside conv1's dgrad store (ops.conv2d)
+            out, identity = self.conv1(x, tap=True)
             x = identity
         else:
             out = self.conv1(x)
@@ -59,7 +55,7 @@ class Bottleneck(nn.Module):
         out = self.bn2(self.conv2(out), relu=True)
         if self.downsample is not None:
             identity = self.downsample[1](self.downsample[0](x))
-        return self.bn3(self.conv3(out), res=identity, relu=True, lazy_res=lazy)
+        return self.bn3(self.conv3(out), res=identity, relu=True)
 
 
 def _init_weights(model, zero_init_residual):

@@ -81,11 +81,11 @@ class HipBatchNorm2d(nn.Module):
             b.num_batches_tracked.copy_(m.num_batches_tracked)
         return b
 
-    def forward(self, x, res=None, relu=False, out_into=None, lazy_res=False):
+    def forward(self, x, res=None, relu=False, out_into=None):
         if self.training:
             ops.count_bn_batch(self.num_batches_tracked)
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, self.training,
-                          self.momentum, self.eps, self.sync, out_into=out_into, lazy_res=lazy_res)
+                          self.momentum, self.eps, self.sync, out_into=out_into)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"

@@ -206,7 +206,6 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.bias_ref = bias
         ctx.cfg = (stride, pad, dil, bias is not None, flops)
-        ctx.lazy_tap = tap == 2      # the tap's gradient arrives as (da, ReLU bit mask): see _BNAct.backward / lazy_res
         if tap:
             return y, x      # x comes back as a second output: its gradient is folded into this op's dgrad store
         return y
@@ -232,15 +231,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
-            mask = getattr(dtap, "_css_res_mask", None) if dtap is not None else None
-            if ctx.lazy_tap and dtap is not None and mask is None:
-                # the producer promised (da, mask) or an already-masked tensor tagged False: an untagged gradient means autograd
-                # re-materialised it on the way (accumulation, a view copy) and the unmasked values would be added silently
-                raise _lib.CssHipError("lazy residual gradient lost its tag between bn3 and conv1: do not consume the tap elsewhere")
-            if dtap is not None and mask is not None and mask is not False:
-                call("css_conv2d_dgrad_add_masked", dyp, wt, dx, dtap, mask, cp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride,
-                     pad, dil, flops, dc, dev, st)
-            elif dtap is not None:
+            if dtap is not None:
                 dtap = dtap.contiguous()
                 call("css_conv2d_dgrad_add", dyp, wt, dx, dtap, cp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride,
                      pad, dil, flops, dc, dev, st)
@@ -325,8 +316,7 @@ class _BNAct(torch.autograd.Function):
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None,
-                lazy_res=False):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -393,7 +383,6 @@ class _BNAct(torch.autograd.Function):
             ctx.save_for_backward(y, out if (relu and res is not None and mask is None) else None, mean, invstd, gamma, scale, shift, count_t, mask)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
-        ctx.lazy_res = bool(lazy_res) and mask is not None
         return out
 
     @staticmethod
@@ -431,29 +420,19 @@ class _BNAct(torch.autograd.Function):
         if sync and collectives_on():
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
-        lazy = ctx.lazy_res and has_res and mask is not None and ldda == c
-        dres = torch.empty_like(y) if has_res and not lazy else None
+        dres = torch.empty_like(y) if has_res else None
         if mask is not None:
             call("css_bn_bwd_apply_mask", da, ldda, mask, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, count_t, m, c, mg, dc, dev, st)
         else:
             call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
                  int(relu), mg, dc, dev, st)
-        if lazy:
-            # the residual-branch gradient is da where the block's ReLU passed: instead of writing it as a tensor (277 MB per layer-3
-            # block) hand (da, bit mask) to the consumer - conv1's dgrad, which applies the mask to its addend (css_conv2d_dgrad_add_masked)
-            dres = da.view(da.shape)
-            dres._css_res_mask = mask
-        elif ctx.lazy_res and dres is not None:
-            dres._css_res_mask = False      # materialised after all (strided da): tagged so that the consumer's check passes
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
 _nbt_sink = None
 # CSS_BN_NO_MASK=1: residual layers re-read their activation tensor for the ReLU mask in backward (round-2 behaviour; A/B and parity tests)
 _bn_bit_mask = os.environ.get("CSS_BN_NO_MASK") != "1"
-# CSS_NO_LAZY_RES=1: the residual-branch gradient of every Bottleneck is written as a tensor by the batch-norm backward (round-2 behaviour)
-_lazy_res = os.environ.get("CSS_NO_LAZY_RES") != "1"
 
 
 class bn_groups:
@@ -484,20 +463,9 @@ def count_bn_batch(counter):
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
-           groups=None, out_into=None, lazy_res=False):
-    """lazy_res: ``res`` is the tap of a convolution called with ``tap=2`` (conv2d): backward hands that convolution (da, ReLU bit mask)
-    instead of the masked residual gradient as a tensor."""
+           groups=None, out_into=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
-                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into, lazy_res)
-
-
-def lazy_residual_ok(x, cout):
-    """Can the gradient of the residual tap of a 1x1 stride-1 convolution x[N,H,W,Cin] -> cout travel as (da, bit mask)?  Needs the
-    weight-stationary kernel in its addend form for that convolution's data gradient (K = cout, N = Cin) and the bit-mask batch norm."""
-    if not (_bn_bit_mask and _lazy_res and x.dtype == torch.bfloat16 and x.is_cuda):
-        return False
-    n, h, w, cin = x.shape
-    return bool(_lib.query("css_conv_ws_applies", n * h * w, cout, cout, cin, cin, 1, 1, 1, 0, 0, 1, cin, 0, dtype_code(x.dtype), 0))
+                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into)
 
 
 # --------------------------------------------------------------------------

@@ -74,14 +74,6 @@ CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, i
 CSS_API int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx,
                                  int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                  int device, css_stream_t stream);
-/* css_conv2d_dgrad_add whose addend is MASKED on the fly: addend = the gradient `da` that reached a residual block's output and mask =
- * the ReLU bit mask css_bn_apply_mask wrote for that output ([M][Cin/8] bytes, bit e of a byte = element e of the 16-byte vector was
- * > 0): element e of the addend counts only where its bit is set - the residual-branch gradient (resnet.py:136-137: out += identity;
- * relu) without css_bn_bwd_apply_mask having to write it as a tensor of its own.  Weight-stationary kernel only: ask
- * css_conv_ws_applies(..., has_addend = 1, ...) first (CSS_ERR_ARG otherwise); ld_add == Cin. */
-CSS_API int css_conv2d_dgrad_add_masked(const void* dy, const void* w_t, void* dx, const void* addend, const unsigned char* mask, int ld_add, int N,
-                                        int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad,
-                                        int dil, double alg_flops, int dtype, int device, css_stream_t stream);
 /* dw: fp32 [Cout][R][S][Cin], ACCUMULATED: zero it first unless accumulating on purpose.  The pixels are reduced in slices (one
  * workgroup per weight tile and slice).  ws (optional, caller-owned, ws_bytes >= css_conv2d_wgrad_ws_bytes(N*Ho*Wo, R*S*Cin, Cout, ..)):
  * the slices' partial tiles are written there with plain stores and summed into dw in a fixed order by a second kernel - faster than

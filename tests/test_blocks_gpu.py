@@ -141,52 +141,3 @@ def test_aspp_decoder_heads():
     print("aspp/decoder grad errs: max", max(errs.values()), {k: f"{v:.1e}" for k, v in errs.items() if v > TOL})
     for n, e in errs.items():
         assert e < (2e-3 if (n == "x4" or "convs.4." in n) else TOL), (n, e)
-
-
-@pytest.mark.parametrize("li,bi,size,batch", [(1, 1, 33, 2), (3, 5, 17, 4), (2, 1, 17, 3)])
-def test_bottleneck_lazy_residual_gradient_is_bit_identical(li, bi, size, batch):
-    """Identity Bottlenecks in bf16 (resnet.py:119-139): the gradient of the residual branch travels to conv1's data gradient as
-    (bn3's incoming gradient, ReLU bit mask) and conv_ws_kernel masks its addend itself (css_conv2d_dgrad_add_masked) instead of
-    css_bn_bwd_apply_mask writing the masked tensor - same values added in the same place, so every gradient must be BIT-identical to
-    the materialised path (CSS_NO_LAZY_RES=1), and the masked entry point must really have run."""
-    from oracle import css_oracle as O
-    from css_amd import _lib, ops
-    from css_amd.networks import resnet
-    from css_amd.networks.deeplabv3.deeplabv3 import DeepLabv3Plus_with_rep
-    sd = O.init_state("tv", 21, 256, 7)
-    spec = O.backbone_spec("tv")["layers"][li - 1][bi]
-    prefix = f"resnet_layer{li}.{bi}."
-    cin = spec["conv1"]["cin"]
-    g = torch.Generator().manual_seed(100 + li)
-    x = torch.randn(batch, cin, size, size, generator=g)
-    wl = torch.randn(batch, cin, size, size, generator=g)
-    net = DeepLabv3Plus_with_rep(resnet.resnet101_tv(), dilate_scale=8, num_classes=21)
-    blk = _load(getattr(net, f"resnet_layer{li}")[bi], sd, prefix)
-    assert blk.downsample is None
-    calls = []
-    real_call = ops.call
-
-    def spy(name, *a):
-        calls.append(name)
-        return real_call(name, *a)
-
-    res = []
-    for lazy in (True, False):
-        ops._lazy_res = lazy
-        ops.call = spy
-        calls.clear()
-        try:
-            for p_ in blk.parameters():
-                p_.grad = None
-            xg = to_nhwc(x, torch.bfloat16).requires_grad_(True)
-            og = blk(xg)
-            (og.float() * to_nhwc(wl, torch.float32)).sum().backward()
-            torch.cuda.synchronize()
-        finally:
-            ops.call = real_call
-            ops._lazy_res = True
-        assert ("css_conv2d_dgrad_add_masked" in calls) == lazy, calls
-        assert ("css_conv2d_dgrad_add" in calls) == (not lazy), calls
-        res.append([og.detach().clone(), xg.grad.clone()] + [p_.grad.clone() for p_ in blk.parameters()])
-    for a_, b_ in zip(*res):
-        assert torch.equal(a_, b_)
