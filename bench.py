@@ -237,7 +237,7 @@ def pmc_traffic(workload):
         return None, None
     rd = wr = n = 0.0
     for r in csv.DictReader(open(files[-1])):
-        if "conv_igemm_pp" in r["kernel"]:
+        if "conv_igemm_pp" in r["kernel"] or "conv_igemm_p8" in r["kernel"]:
             k = float(r["launches"])
             rd += float(r["read_MB_per_launch_corrected_x2"]) * k
             wr += float(r["write_MB_per_launch"]) * k
@@ -255,9 +255,9 @@ def rooflines(prof, dtype, workload):
     ig_ms, ig_n, ig_fl = (a - b for a, b in zip(tot("igemm256_fwd", "igemm256_dgrad"), prof["conv_ws_flops"]))
     ach = ig_fl / (ig_ms * 1e-3) if ig_ms > 0 else 0.0
     traffic, src = pmc_traffic(workload)
-    roof = {"bound": "mfma", "kernel": "conv_igemm_pp64_kernel (+ conv_igemm_pp_kernel for the shapes with < 3 K steps of 64): the persistent 256x256-tile "
-                                       "implicit-GEMM convolution, every forward + dgrad launch of one step after the timed region (the short-K 1x1 class now runs on "
-                                       "conv_ws_kernel: see kernels.conv_ws_kernel)",
+    roof = {"bound": "mfma", "kernel": "conv_igemm_p8_kernel (+ conv_igemm_pp_kernel for the shapes with < 3 K steps of 64): the persistent 256x256-tile "
+                                       "implicit-GEMM convolution on the 8-phase K loop, every forward + dgrad launch of one step after the timed region "
+                                       "(the short-K 1x1 class runs on conv_ws_kernel: see kernels.conv_ws_kernel)",
             "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src, "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
             "alg_flops_per_launch": ig_fl / max(ig_n, 1)}

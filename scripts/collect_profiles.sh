@@ -20,6 +20,17 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 F=$(find /tmp/prof_fetch -name "*.db" | head -1); W=$(find /tmp/prof_write -name "*.db" | head -1)
 [ -n "$F" ] && [ -n "$W" ] && python3 $ROOT/scripts/pmc_summary.py $F $W > $OUT/${TAG}_pmc_hbm_traffic_c2.csv
+# the same two traffic passes for the Cityscapes-shaped workload (extra.c4.roofline.traffic of the default bench line)
+B4="python3 $ROOT/bench.py --workload c4 --steps 1 --warmup 1 --no-cpu-baseline --no-extra"
+run4() {
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 600 rocprofv3 --pmc "$@" --kernel-trace -d /tmp/prof_$name -o p -- $B4 > /tmp/prof_$name.log 2>&1 || echo "$name: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt
+}
+run4 fetch4 FETCH_SIZE
+run4 write4 WRITE_SIZE
+F=$(find /tmp/prof_fetch4 -name "*.db" | head -1); W=$(find /tmp/prof_write4 -name "*.db" | head -1)
+[ -n "$F" ] && [ -n "$W" ] && python3 $ROOT/scripts/pmc_summary.py $F $W > $OUT/${TAG}_pmc_hbm_traffic_c4.csv
 # per-kernel time: --kernel-trace --stats only (never next to --pmc), three steps
 rm -rf /tmp/prof_stats
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /tmp/prof_stats.log 2>&1 || echo "stats: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt

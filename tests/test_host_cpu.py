@@ -461,7 +461,7 @@ def test_committed_bench_line_and_profiles_agree():
     stats = os.path.join(root, "profiles", tag + "_bench_kernel_stats.csv")
     tot_ns = n = 0
     for row in csv.DictReader(open(stats)):
-        if "conv_igemm_pp64_kernel" in row["Name"] or "conv_igemm_pp_kernel" in row["Name"]:
+        if "conv_igemm_p8_kernel" in row["Name"] or "conv_igemm_pp64_kernel" in row["Name"] or "conv_igemm_pp_kernel" in row["Name"]:
             tot_ns += float(row["TotalDurationNs"])
             n += int(row["Calls"])
     assert n > 0
