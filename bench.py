@@ -52,6 +52,18 @@ WORKLOADS = {
 
 
 # ---- N > 1 without a launcher: start the ranks ourselves -------------------------------------------------------------------------
+def source_sha256():
+    """Digest of the product sources this line was measured on (scripts/source_hash.py; checked by tests/test_host_cpu.py)."""
+    try:
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("source_hash", os.path.join(ROOT, "scripts", "source_hash.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod.source_hash(ROOT)
+    except Exception:
+        return None
+
+
 def free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -429,7 +441,7 @@ def main():
                        "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
             "roofline": roof, "kernels": kernels,
             "step_alg_tflops": round(8 * B * meta["fwd_flop"] / (dt / a.steps) / 1e12, 2),
-            "losses": losses,
+            "losses": losses, "source_sha256": source_sha256(),
         }
         if rccl:
             res["rccl"] = rccl

@@ -182,19 +182,35 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
-int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
-                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+static int dgrad_add_impl(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, const unsigned char* mask, int N, int H, int W, int Cin,
+                          int lddx, int Ho, int Wo, int Cout, int lddy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype,
+                          int device, css_stream_t stream) {
   set_dev(device);
   if (stride != 1 && stride != 2) return CSS_ERR_ARG;
+  if (mask) {       // one mask byte per 16-byte vector of the addend: whole aligned vectors only
+    const int vec = dtype == CSS_BF16 ? 8 : 4;
+    if (!addend || (Cin % vec) || (lddx % vec) || (ld_add % vec) || (reinterpret_cast<uintptr_t>(dx) & 15) || (reinterpret_cast<uintptr_t>(addend) & 15))
+      return CSS_ERR_ARG;
+  }
   ConvArgs a = {};
   a.src = dy; a.wt = w_t; a.dst = dx; a.bias = nullptr;
   a.N = N; a.Hs = Ho; a.Ws = Wo; a.Cs = Cout; a.lds = lddy;
   a.Hd = H; a.Wd = W; a.Cd = Cin; a.ldd = lddx;
-  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil; a.mode = 1; a.addend = addend; a.ld_add = ld_add; a.add_mask = mask;
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ConvProf cp(1, 6, alg_flops, S(stream));
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
+}
+int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
+                     int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
+  return dgrad_add_impl(dy, w_t, dx, addend, ld_add, nullptr, N, H, W, Cin, lddx, Ho, Wo, Cout, lddy, R, Sk, stride, pad, dil, alg_flops, dtype, device, stream);
+}
+int css_conv2d_dgrad_add_masked(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, const unsigned char* mask, int N, int H, int W, int Cin,
+                                int lddx, int Ho, int Wo, int Cout, int lddy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype,
+                                int device, css_stream_t stream) {
+  if (!mask) return CSS_ERR_ARG;
+  return dgrad_add_impl(dy, w_t, dx, addend, ld_add, mask, N, H, W, Cin, lddx, Ho, Wo, Cout, lddy, R, Sk, stride, pad, dil, alg_flops, dtype, device, stream);
 }
 size_t css_conv2d_wgrad_ws_bytes(int M, int Ktot, int Cout, int dtype, int device) {
   return css_wgrad_ws_bytes_(M, Ktot, Cout, dtype, cu_count(device));

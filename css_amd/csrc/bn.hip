@@ -16,7 +16,7 @@
 // stores: 1000 blocks doing fp64 atomics onto the same 2C addresses ran at ~390 GB/s, the contended-atomic regime).
 // Stage 2 (bn_reduce*_kernel below) sums the partial rows in fp64.
 template <typename T, typename F>
-__device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per_block, double* partial) {
+__device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per_block, double* partial, bool rev = false) {
   // blockIdx.z = statistics group (one group per forward pass batched into the tensor); gridDim.x = row blocks per group
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
@@ -30,7 +30,8 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
 #pragma unroll
   for (int e = 0; e < VEC; ++e) s0[e] = s1[e] = 0.f;
   const int gbase = blockIdx.z * Mg;
-  const int row0 = gbase + blockIdx.x * rows_per_block;
+  const int bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;      // (bn_pass_order: last rows first)
+  const int row0 = gbase + bx * rows_per_block;
   const int row1 = min(gbase + Mg, row0 + rows_per_block);
   if (active) {
     int r = row0 + rg;
@@ -50,7 +51,7 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
   }
   __syncthreads();
   if (rg == 0 && cv < CV) {
-    double* p0 = partial + ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 2 * C + cv * VEC;
+    double* p0 = partial + ((size_t)blockIdx.z * gridDim.x + bx) * 2 * C + cv * VEC;
 #pragma unroll
     for (int e = 0; e < VEC; ++e) {
       double a0 = 0, a1 = 0;
@@ -276,7 +277,7 @@ template <typename T, bool MASK, bool RES, bool RELU>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, int ldy, const T* __restrict__ res, int ldr,
                                                        T* __restrict__ out, int ldo, const float* __restrict__ scale,
                                                        const float* __restrict__ shift, int Mg, int C, int rows_per_block,
-                                                       unsigned char* __restrict__ mask) {
+                                                       unsigned char* __restrict__ mask, int rev) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
@@ -292,7 +293,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     sh[p] = f32x2{shift[g * C + c + 2 * p], shift[g * C + c + 2 * p + 1]};
   }
   const int gbase = g * Mg;
-  const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
+  const int bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;      // (bn_pass_order: last rows first)
+  const int row0 = gbase + bx * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   // EW_UNROLL rows per trip, all loads issued before the first use: a thread's trips are a serial chain of ~2 us memory
   // round trips, which (not bandwidth) bounded the 10-40 MB layers.
   for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
                                                             const float* __restrict__ mean, const float* __restrict__ invstd,
                                                             const float* __restrict__ scale, const float* __restrict__ shift,
                                                             int Mg, int C, int rows_per_block, double* partial,
-                                                            const unsigned char* __restrict__ mask) {
+                                                            const unsigned char* __restrict__ mask, int rev) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256;
@@ -385,7 +387,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
       s1[2 * p] = a1[0]; s1[2 * p + 1] = a1[1];
     }
   };
-  channel_reduce2<T>(f, Mg, C, rows_per_block, partial);
+  channel_reduce2<T>(f, Mg, C, rows_per_block, partial, rev != 0);
 }
 
 template <typename T, int MODE>
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
                                                            const double* __restrict__ sums, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, double count, const double* __restrict__ count_dev,
-                                                           int Mg, int C, int rows_per_block, const unsigned char* __restrict__ mask) {
+                                                           int Mg, int C, int rows_per_block, const unsigned char* __restrict__ mask, int rev) {
   constexpr int VEC = 16 / sizeof(T);
   const int CV = C / VEC;
   const int TPC = CV < 256 ? CV : 256, RPB = 256 / TPC;
@@ -418,7 +420,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     sh[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{shift[ch], shift[ch + 1]} : f32x2{0.f, 0.f};
   }
   const int gbase = g * Mg;
-  const int row0 = gbase + blockIdx.x * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
+  const int bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;      // (bn_pass_order: last rows first)
+  const int row0 = gbase + bx * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
     Vec16<T> gv[EW_UNROLL], av[EW_UNROLL], yv[EW_UNROLL];
     unsigned bits[EW_UNROLL];
@@ -463,6 +466,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 }
 
 // ---- launchers -----------------------------------------------------------
+// Row order of the streaming passes.  Their input was written a moment ago by a kernel that walks the rows upwards, so what the 256 MB
+// Infinity Cache still holds is the END of that tensor: a pass that starts at row 0 misses, and pushes the cached tail out with its own
+// traffic before it gets there.  Bit 0: bn_apply walks the rows downwards (its producer is the convolution), bit 1: bn_bwd_reduce
+// (producer: the data-gradient convolution), bit 2: bn_bwd_apply (producer of what the cache holds: bn_bwd_reduce itself - if that
+// ran downwards, the cache holds the first rows and this pass should walk upwards).  CSS_BN_PASS_ORDER overrides.
+static inline int bn_pass_order() {
+  static const int v = getenv("CSS_BN_PASS_ORDER") ? atoi(getenv("CSS_BN_PASS_ORDER")) : 1;      // (measured, profiles/r03_dres_mask_and_bn_order.txt: bit 0 -0.25 ms per step, bits 1 and 2 nothing)
+  return v;
+}
+
 // Tensors are [M = G*Mg][C]: G statistics groups of Mg rows each (G forward passes batched into one tensor).
 // rows per block: every block streams >= 64 KiB (so that the partial rows stay a few % of the tensor), at most ~1024 blocks
 static inline int pick_rows_per_block(int Mg, int G, int C, int vec) {
@@ -568,7 +581,7 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
 #define CSS_BN_APPLY_LAUNCH(MASK, RES, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_apply_kernel<T, MASK, RES, RELU>), g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, \
-                     Mg, C, rpb, mask)
+                     Mg, C, rpb, mask, bn_pass_order() & 1)
   // (the elementwise kernels sit close to instruction-bound: mask / residual / ReLU are compile-time choices)
   if (mask) {
     if (!res || !relu) return CSS_ERR_ARG;                 // the bit mask exists for residual + ReLU layers
@@ -604,7 +617,7 @@ static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, con
   const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
 #define CSS_BN_RED_LAUNCH(MODE)                                                                                                      \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean, invstd, \
-                     scale, shift, Mg, C, rpb, partial, mask)
+                     scale, shift, Mg, C, rpb, partial, mask, (bn_pass_order() >> 1) & 1)
   if (mode == BN_NORELU) CSS_BN_RED_LAUNCH(BN_NORELU);
   else if (mode == BN_MASK_RECOMPUTE) CSS_BN_RED_LAUNCH(BN_MASK_RECOMPUTE);
   else if (mode == BN_MASK_ACT) CSS_BN_RED_LAUNCH(BN_MASK_ACT);
@@ -640,7 +653,7 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
   const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
 #define CSS_BN_APP_LAUNCH(MODE)                                                                                                       \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, \
-                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, rpb, mask)
+                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, rpb, mask, (bn_pass_order() >> 2) & 1)
   if (mode == BN_NORELU) CSS_BN_APP_LAUNCH(BN_NORELU);
   else if (mode == BN_MASK_RECOMPUTE) CSS_BN_APP_LAUNCH(BN_MASK_RECOMPUTE);
   else if (mode == BN_MASK_ACT) CSS_BN_APP_LAUNCH(BN_MASK_ACT);

@@ -100,6 +100,11 @@ __device__ __forceinline__ float keep_if_bit(float x, unsigned bits, int b) {
   return __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x) & (unsigned)__builtin_amdgcn_sbfe((int)bits, b, 1));
 }
 
+// the same for a 32-bit word of two bf16 (elements 2w, 2w+1 of a 16-byte vector): 0xFFFF in every half whose bit is set
+__device__ __forceinline__ unsigned keep_mask_bf16x2(unsigned bits, int w) {
+  return ((unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * w, 1) & 0xFFFFu) | ((unsigned)__builtin_amdgcn_sbfe((int)bits, 2 * w + 1, 1) & 0xFFFF0000u);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -112,12 +112,16 @@ __device__ __forceinline__ void store_wave_tile(const ConvArgs& a, const T* Cw, 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) v[it].load(Cw + (r0 + it * RSTEP) * CSTR + cv * VEC);
     if (addp) {
+      unsigned mk[NIT];
 #pragma unroll
-      for (int it = 0; it < NIT; ++it) r[it].load(addp + (size_t)(mrow0 + r0 + it * RSTEP) * a.ld_add + n);
+      for (int it = 0; it < NIT; ++it) {
+        r[it].load(addp + (size_t)(mrow0 + r0 + it * RSTEP) * a.ld_add + n);
+        mk[it] = a.add_mask ? a.add_mask[(size_t)(mrow0 + r0 + it * RSTEP) * (a.Cd / VEC) + n / VEC] : 0xFFFFu;
+      }
 #pragma unroll
       for (int it = 0; it < NIT; ++it)
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) v[it].set(e, v[it].f(e) + r[it].f(e));
+        for (int e = 0; e < VEC; ++e) v[it].set(e, v[it].f(e) + keep_if_bit(r[it].f(e), mk[it], e));
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) v[it].store(dst + (size_t)(mrow0 + r0 + it * RSTEP) * a.ldd + n);
@@ -138,8 +142,9 @@ __device__ __forceinline__ void store_wave_tile(const ConvArgs& a, const T* Cw, 
         if (addp) {
           Vec16<T> r;
           r.load(addp + (size_t)m * a.ld_add + n);
+          const unsigned mk = a.add_mask ? a.add_mask[(size_t)m * (a.Cd / VEC) + n / VEC] : 0xFFFFu;
 #pragma unroll
-          for (int e = 0; e < VEC; ++e) v.set(e, v.f(e) + r.f(e));
+          for (int e = 0; e < VEC; ++e) v.set(e, v.f(e) + keep_if_bit(r.f(e), mk, e));
         }
         v.store(o);
       } else {
@@ -148,7 +153,7 @@ __device__ __forceinline__ void store_wave_tile(const ConvArgs& a, const T* Cw, 
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
           if (n + e < a.Cd) {
-            if (addp) v.set(e, v.f(e) + ElemT<T>::to_f(addp[(size_t)m * a.ld_add + n + e]));
+            if (addp) v.set(e, v.f(e) + ElemT<T>::to_f(addp[(size_t)m * a.ld_add + n + e]));      // (no mask here: css_conv2d_dgrad_add_masked requires Cd % VEC == 0)
             o[e] = v.e[e];
           }
         }
@@ -1731,7 +1736,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
       P0(true, 1.0, true);
       css_launch_conv_ws(a, n_cu, st);
       P1();
-    } else if (a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) {
+    } else if (a.Cd >= 256 && !no_dma && !no_256 && !a.add_mask && css_conv_pp_plan(a, n_cu) == 272) {
       // 272-row tiles of the persistent kernel cover every row in whole rounds of the chip: one launch
       ConvArgs b = a;
       b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);

@@ -470,14 +470,20 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     // in profiles/r03_store_stall.txt.)
     if (ti == nmy - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     p8_u32x4 radd[ADD ? 8 : 1][2];
+    unsigned rmk[ADD ? 8 : 1][2];
+    const bool has_mask = ADD && a.add_mask != nullptr;
     if (ADD) {
       const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
+      // optional ReLU bit mask of the addend (css_conv2d_dgrad_add_masked): one byte per 16-byte vector
+      const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
 #pragma unroll
       for (int i = 0; i < 8; ++i)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mrow0 + 16 * i + l15, n = nl + 32 * h;
           radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a_M && n < a_Cd) ? ((unsigned)m * (unsigned)a_ld_add + (unsigned)n) * 2u : P8_OOB), 0, 0);
+          if (has_mask) rmk[i][h] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)((m < a_M && n < a_Cd) ? (unsigned)m * ((unsigned)a_Cd >> 3) + ((unsigned)n >> 3) : P8_OOB), 0, 0);
+          else rmk[i][h] = 0xFFu;
         }
     }
 #pragma unroll
@@ -498,7 +504,10 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
         const int n = nl + 16 * jp;
         const bool ok = m < a_M && n < a_Cd;
         if (ADD) {
-          const p8_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          p8_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          const unsigned mk = rmk[ADD ? i : 0][jp >> 1];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = p8_pack2(p8_lo(v[e]) + p8_lo(r[e]), p8_hi(v[e]) + p8_hi(r[e]));
         }
@@ -587,6 +596,7 @@ void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st) {
   a.korder = korder_env >= 0 ? (korder_env != 0) : (a.R * a.S > 1 ? 1 : 0);
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   // tap lists per set of valid kernel rows (see conv_pp64.hip)
   const int tapstep = (a.mode == 0 ? a.dil : -a.dil) * a.lds * 2;
   for (int v = 1; v < (1 << a.R); ++v) {

@@ -393,6 +393,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     //   lane group g = 0: tile j ch 0-7 | g = 1: tile j+1 ch 0-7 | g = 2: tile j ch 8-15 | g = 3: tile j+1 ch 8-15   (j = 0, 2)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
     pp_u32x4 radd[ADD ? TI0 : 1][2];
+    const bool has_mask = ADD && TI0 == 8 && a.add_mask != nullptr;      // (the opt-in 272-row variant has no register left: the dispatch keeps masked launches off it)
     if (ADD) {
       // all 16 addend vectors of the wave tile are requested before the first one is used: ONE drain of the vector-memory queue per
       // tile (the compiler waits for an ordinary load with everything older, i.e. with the LDS-DMA of the next tile's first K steps)
@@ -424,7 +425,16 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         const bool ok = m < a.M && n < a.Cd;
         if (ADD) {
           // dgrad: + the residual branch's gradient (bf16 + bf16 in fp32, rounded once: what autograd's add would give)
-          const pp_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          pp_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          // optional ReLU bit mask of the addend (css_conv2d_dgrad_add_masked), one byte per 16-byte vector: fetched where it is used (this
+          // kernel is a fallback of conv_igemm_p8_kernel, which requests the bytes together with the addend; 16 more registers spill here)
+          unsigned mk = 0xFFu;
+          if (has_mask) {
+            const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
+            mk = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)(ok ? (unsigned)m * ((unsigned)a.Cd >> 3) + ((unsigned)n >> 3) : PP_OOB), 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = pp_pack2(pp_lo(v[e]) + pp_lo(r[e]), pp_hi(v[e]) + pp_hi(r[e]));
         }
@@ -523,6 +533,7 @@ void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st) {
   a.korder = korder_env >= 0 ? korder_env : (a.R * a.S > 1 ? 1 : 0);   // (measured on the harness: 1 beats 0 by 3-5 % on the 3x3 shapes, 2 loses)
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, tile_rows) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   const dim3 g(grid), b(512);
   if (tile_rows == 272) {
     if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<9, true, false>), g, b, 0, st, a);

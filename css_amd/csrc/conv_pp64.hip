@@ -345,6 +345,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
     const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
     p6_u32x4 radd[ADD ? 8 : 1][2];
+    const bool has_mask = ADD && a.add_mask != nullptr;
     if (ADD) {
       const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
 #pragma unroll
@@ -373,7 +374,16 @@ __global__ __launch_bounds__(512) void conv_igemm_pp64_kernel(const ConvArgs a) 
         const int n = nl + 16 * jp;
         const bool ok = m < a.M && n < a.Cd;
         if (ADD) {
-          const p6_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          p6_u32x4 r = radd[ADD ? i : 0][jp >> 1];
+          // optional ReLU bit mask of the addend (css_conv2d_dgrad_add_masked), one byte per 16-byte vector: fetched where it is used (this
+          // kernel is a fallback of conv_igemm_p8_kernel, which requests the bytes together with the addend; 16 more registers spill here)
+          unsigned mk = 0xFFu;
+          if (has_mask) {
+            const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
+            mk = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)(ok ? (unsigned)m * ((unsigned)a.Cd >> 3) + ((unsigned)n >> 3) : P6_OOB), 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = p6_pack2(p6_lo(v[e]) + p6_lo(r[e]), p6_hi(v[e]) + p6_hi(r[e]));
         }
@@ -437,6 +447,7 @@ void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st) {
   a.korder = korder_env >= 0 ? (korder_env != 0) : (a.R * a.S > 1 ? 1 : 0);
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   // tap lists: for every non-empty set v of valid kernel rows (bit r of v: row r reads something but padding for the tile), the taps
   // (r, s) in order with the byte offset of the source pixel relative to tap (0,0), the byte offset inside a weight row, and the bit
   // index of the tap in the per-pixel validity masks

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #else
   constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = false;
 #endif
-  constexpr int NLD = ADD ? 8 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
+  constexpr int NLD = ADD ? 10 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
   constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
   constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + (NT >= 2 ? NLD : 0) + NST, W2 = W1 + (NT >= 2 ? NST : 0);   // vmcnt of the stage wait in tile 0, tile 1, later tiles
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
@@ -180,6 +180,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);            // first of my 8 channels in a store (after the lane swap)
 
   ws_u32x4 radd[ADD ? 8 : 1];
+  // optional ReLU bit mask of the addend (css_conv2d_dgrad_add_masked): one byte per 16-byte vector.  The wave's 16 x 4 vectors of pixel
+  // tile i are 16 rows x one dword of mask: lane (l15, lg) fetches the dwords of pixel tiles lg and lg + 4 (two registers, two requests -
+  // one register per vector sends the K = 256 instance to scratch) and the epilogue takes its byte from the owner with ds_bpermute
+  unsigned rmk[ADD ? 2 : 1];
+  const bool has_mask = ADD && a.add_mask != nullptr;
   // ---------------- epilogue of a tile (rows m0e ..): no LDS, no barrier ----------------
   auto epilogue = [&](int m0e) {
     const int bnd = STATS ? (m0e / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
@@ -192,7 +197,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       ws_swap16(hi0, hi1);
       ws_u32x4 v = {lo0, hi0, lo1, hi1};
       if (ADD) {
-        const ws_u32x4 r = radd[ADD ? i : 0];
+        ws_u32x4 r = radd[ADD ? i : 0];
+        const unsigned mw = (unsigned)__builtin_amdgcn_ds_bpermute(((i & 3) * 16 + l15) * 4, (int)rmk[ADD ? i >> 2 : 0]);
+        const unsigned mk = has_mask ? (mw >> (8 * (2 * (lg & 1) + (lg >> 1)))) & 0xFFu : 0xFFu;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(r[e]), ws_hi(v[e]) + ws_hi(r[e]));
       }
@@ -235,6 +244,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     // requested a whole tile ahead of its use: by then everything older (LDS-DMA pieces of earlier stages) has landed anyway, so
     // waiting for it costs nothing - an addend requested inside the epilogue drains the whole in-order queue once per tile
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
+    // (always issued - the vmcnt bookkeeping counts NLD = 10 loads per tile; without a mask the offset is out of range and the dword unused)
+#pragma unroll
+    for (int q = 0; q < (ADD ? 2 : 0); ++q) {
+      const int m = m0e + 16 * (lg + 4 * q) + l15;
+      rmk[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_k, (int)((has_mask && m < a.M) ? (unsigned)m * ((unsigned)a.Cd >> 3) + ((unsigned)n0w >> 3) : WS_OOB), 0, 0);
+    }
 #pragma unroll
     for (int i = 0; i < (ADD ? 8 : 0); ++i) {
       const int m = m0e + 16 * i + l15;
@@ -389,6 +405,7 @@ void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st) {
   a.dst_bytes = (unsigned)((size_t)a.M * a.ldd * 2);
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
+  if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   if (a.Cs == 512) {
     if (a.stats) hipLaunchKernelGGL((conv_ws_kernel<8, true, false>), dim3(n_cu), dim3(512), 0, st, a);
     else hipLaunchKernelGGL((conv_ws_kernel<8, false, false>), dim3(n_cu), dim3(512), 0, st, a);

@@ -21,10 +21,14 @@ struct ConvArgs {
   int stat_G;                     // number of statistics groups (total M / stat_Mg), filled by the launcher
   const void* addend;             // [M][ld_add] tensor added to the result before it is stored (residual gradient), or null
   int ld_add;
+  const unsigned char* add_mask;  // optional [M][Cd / VEC] bytes (VEC = elements per 16 bytes): bit e of byte (m, v) set = element v*VEC + e of the
+                                  // addend is kept, clear = it counts as zero (the ReLU mask css_bn_apply_mask wrote: the addend is then the
+                                  // gradient BEFORE that ReLU's backward, which this epilogue applies on the fly - css_conv2d_dgrad_add_masked)
   // conv_igemm_pp_kernel (conv_pp.hip), filled by the launcher:
   unsigned dst_bytes;             // bytes of dst the launch may write (buffer descriptor: rows >= M are dropped by the range check)
   FastDiv fd_hw, fd_w;            // division by Hd*Wd and Wd
   unsigned stat_bytes, add_bytes; // sizes of the stats / addend buffers (buffer descriptors)
+  unsigned mask_bytes;            // size of add_mask
   int korder;                     // order of the K steps (conv_pp.hip: issue())
   int tab_da[63], tab_kb[63], tab_tap[63];   // conv_pp64.hip: tap lists per set of valid kernel rows (7 x 9)
 };

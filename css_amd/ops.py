@@ -231,7 +231,12 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
-            if dtap is not None:
+            lazy = _take_lazy_res_grad(dtap)
+            if lazy is not None:
+                # the residual gradient arrives as (gradient at the ReLU output, ReLU bit mask): masked inside the store (_BNAct.backward)
+                call("css_conv2d_dgrad_add_masked", dyp, wt, dx, lazy[0], cp, lazy[1], n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s,
+                     stride, pad, dil, flops, dc, dev, st)
+            elif dtap is not None:
                 dtap = dtap.contiguous()
                 call("css_conv2d_dgrad_add", dyp, wt, dx, dtap, cp, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride,
                      pad, dil, flops, dc, dev, st)
@@ -239,6 +244,8 @@ class _Conv2d(torch.autograd.Function):
                 call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
                      dc, dev, st)
         elif dtap is not None:
+            if _take_lazy_res_grad(dtap) is not None:
+                raise _lib.CssHipError("a lazily masked residual gradient reached a convolution that computes no data gradient")
             dx = dtap
         if ctx.needs_input_grad[1]:
             sink = _grad_sink(weight, (cout, r, s, cin)) if (cout_pad == cout and cp == cin) else None
@@ -269,6 +276,33 @@ class _Conv2d(torch.autograd.Function):
 
 _conv_stats_out = None
 
+# Residual gradients whose ReLU backward is still to be applied: data_ptr of the gradient tensor _BNAct.backward handed to autograd for
+# `res` -> (that tensor, the ReLU bit mask).  The consumer is the tapped convolution's backward (Bottleneck.conv1), which masks the
+# addend inside its dgrad store; an entry nobody took by the end of a backward pass means a gradient went out unmasked: the trainer checks
+# (assert_no_lazy_res_grads).  CSS_BN_EAGER_DRES=1: bn_bwd_apply writes the masked copy itself (round-2 behaviour; A/B and parity tests).
+_lazy_res_grads = {}
+_lazy_dres = os.environ.get("CSS_BN_EAGER_DRES") != "1"
+
+
+def _take_lazy_res_grad(dtap):
+    if dtap is None or not _lazy_res_grads:
+        return None
+    ent = _lazy_res_grads.pop(dtap.data_ptr(), None)
+    if ent is None:
+        return None
+    g, mask = ent
+    if g.shape != dtap.shape or g.dtype != dtap.dtype or not dtap.is_contiguous():
+        raise _lib.CssHipError("lazily masked residual gradient: the tensor that arrived is not the one that was sent")
+    return g, mask
+
+
+def assert_no_lazy_res_grads():
+    """After a backward pass: every (gradient, mask) pair _BNAct.backward left for a tapped convolution was consumed."""
+    if _lazy_res_grads:
+        n = len(_lazy_res_grads)
+        _lazy_res_grads.clear()
+        raise _lib.CssHipError(f"{n} residual gradient(s) left the batch-norm backward unmasked and were never masked by a dgrad store")
+
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, bn_stats=False, tap=False):
     """``bn_stats``: the output feeds a train-mode batch norm; its statistics are then produced by the convolution epilogue
@@ -277,6 +311,8 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, bn_stats=False, tap=Fal
     instead of a separate add over both tensors."""
     out = _Conv2d.apply(x, weight, bias, stride, pad, dil, _bn_groups if bn_stats else 0, tap)
     y = out[0] if tap else out
+    if tap:
+        out[1]._css_tap = True       # bn_act(res=<this>) may then leave the ReLU backward of the residual gradient to this op's dgrad store
     if _conv_stats_out is not None:
         y._css_bnstats = _conv_stats_out
     return out
@@ -316,7 +352,8 @@ class _BNAct(torch.autograd.Function):
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None,
+                res_is_tap=False):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -383,6 +420,8 @@ class _BNAct(torch.autograd.Function):
             ctx.save_for_backward(y, out if (relu and res is not None and mask is None) else None, mean, invstd, gamma, scale, shift, count_t, mask)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
+        # the residual came out of a tapped convolution: its backward applies this layer's ReLU mask to the gradient itself
+        ctx.lazy_res = bool(res_is_tap and mask is not None and _lazy_dres)
         return out
 
     @staticmethod
@@ -420,13 +459,18 @@ class _BNAct(torch.autograd.Function):
         if sync and collectives_on():
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
-        dres = torch.empty_like(y) if has_res else None
+        lazy = ctx.lazy_res and mask is not None and ldda == c and da.is_contiguous() and da.shape == y.shape
+        dres = torch.empty_like(y) if (has_res and not lazy) else None
         if mask is not None:
             call("css_bn_bwd_apply_mask", da, ldda, mask, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, count_t, m, c, mg, dc, dev, st)
+            if lazy:
+                # no masked copy of `da` for the residual branch: `da` itself travels on, with the mask on the side (see _lazy_res_grads)
+                _lazy_res_grads[da.data_ptr()] = (da, mask)
+                dres = da
         else:
             call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
                  int(relu), mg, dc, dev, st)
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
@@ -465,7 +509,8 @@ def count_bn_batch(counter):
 def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
            groups=None, out_into=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
-                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into)
+                        _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into,
+                        bool(res is not None and getattr(res, "_css_tap", False)))
 
 
 # --------------------------------------------------------------------------

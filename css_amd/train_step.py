@@ -127,6 +127,7 @@ class MixTrainer:
         if not overlap:
             with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
                 total.backward()
+            ops.assert_no_lazy_res_grads()
             if sync:
                 dist.all_reduce(self.flat_g)     # one bucket, after backward
             return
@@ -176,6 +177,7 @@ class MixTrainer:
                 total.backward()
         finally:
             ops.set_grad_ready_callback(prev)
+        ops.assert_no_lazy_res_grads()
         if recording:                            # first step: learn the order and the report counts, reduce in one piece
             self._ready_order = list(order)
             self._span_reports = dict(counts)

@@ -74,6 +74,14 @@ CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, i
 CSS_API int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx,
                                  int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                  int device, css_stream_t stream);
+/* dx = dgrad(dy) + addend (.) mask: as css_conv2d_dgrad_add, with the ReLU backward of the residual sum applied to the addend on the fly.
+ * `addend` is the gradient that ARRIVED at relu(bn3(..) + identity) (resnet.py:135-137) and `mask` the bit mask css_bn_apply_mask wrote
+ * for that ReLU ([N*H*W][Cin / V] bytes, V = elements per 16 bytes; bit e of byte (m, v) = output element v*V + e was positive): the
+ * batch-norm backward then needs no masked copy of that gradient for the residual branch (css_bn_bwd_apply_mask with dres = NULL).
+ * Cin, lddx, ld_add multiples of V; dx and addend 16-byte aligned. */
+CSS_API int css_conv2d_dgrad_add_masked(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, const unsigned char* mask, int N,
+                                        int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R, int S, int stride, int pad,
+                                        int dil, double alg_flops, int dtype, int device, css_stream_t stream);
 /* dw: fp32 [Cout][R][S][Cin], ACCUMULATED: zero it first unless accumulating on purpose.  The pixels are reduced in slices (one
  * workgroup per weight tile and slice).  ws (optional, caller-owned, ws_bytes >= css_conv2d_wgrad_ws_bytes(N*Ho*Wo, R*S*Cin, Cout, ..)):
  * the slices' partial tiles are written there with plain stores and summed into dw in a fixed order by a second kernel - faster than

@@ -6,6 +6,8 @@ TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
+# what these profiles were measured on (checked by tests/test_host_cpu.py against the working tree)
+python3 $ROOT/scripts/source_hash.py $ROOT > $OUT/${TAG}_source_sha256.txt
 B="python3 $ROOT/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra"
 run() {   # name, counters...
   local name=$1; shift

@@ -382,7 +382,7 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
                    check=True, capture_output=True, timeout=600)
     lines = open(out).read().split("\n")
     # (KS, STATS, ADD) -> the vmcnt values of the stage wait in tile 0 / tile 1 / later tiles (conv_ws.hip: W0, W1, W2)
-    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (22, 38, 46)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (10, 26, 34)),
+    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (24, 42, 50)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (12, 30, 38)),
                               (8, 1, 0, (14, 26)), (8, 0, 0, (14, 22))):
         sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELb{ad}EEv8ConvArgs:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
@@ -410,7 +410,7 @@ def test_conv_ws_vmcnt_accounting_model():
                 continue
             nt = 2 if ks <= 4 else 1
             la = nt * ks
-            nld, nst = (8 if add else 0), 8 + (4 if stats else 0)
+            nld, nst = (10 if add else 0), 8 + (4 if stats else 0)       # addend: 8 vectors + 2 dwords of mask bytes (always requested)
             w0 = 2 * (la - 1) + nld
             w1 = w0 + (nld if nt >= 2 else 0) + nst
             w2 = w1 + (nst if nt >= 2 else 0)
@@ -467,6 +467,29 @@ def test_committed_bench_line_and_profiles_agree():
     assert n > 0
     avg_us = tot_ns / n / 1e3
     assert abs(avg_us - r["avg_launch_us"]) < 0.05 * avg_us, (avg_us, r["avg_launch_us"])
+
+
+def test_round_profiles_were_collected_from_these_sources():
+    """Evidence hygiene: the newest committed bench line and rocprof summaries describe THIS tree.
+    scripts/collect_profiles.sh stores scripts/source_hash.py's digest of the product sources (css_amd/, bench.py) next to what it
+    collects; a product change after that collection fails here until the profiles are collected again (rounds before 3 had no digest)."""
+    import glob
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lines = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9][0-9]_bench_line.json")))
+    assert lines, "no committed bench line"
+    tag = os.path.basename(lines[-1])[:3]
+    if int(tag[1:]) < 3:
+        pytest.skip("the round-3 evidence has not been collected yet")
+    spec = importlib.util.spec_from_file_location("source_hash", os.path.join(root, "scripts", "source_hash.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    recorded = open(os.path.join(root, "profiles", tag + "_source_sha256.txt")).read().split()[0]
+    assert json.loads(open(lines[-1]).read().strip().splitlines()[-1]).get("source_sha256") == recorded, "bench line and profiles come from different sources"
+    assert recorded == mod.source_hash(root), (
+        f"profiles/{tag}_* were collected from other product sources than this tree: run scripts/collect_profiles.sh {tag} and the bench "
+        "lines on the GPU again and commit them (or revert the product change)")
 
 
 def test_conv_ws_index_maps():

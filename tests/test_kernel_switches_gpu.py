@@ -76,3 +76,29 @@ def test_bn_activation_mask_switch_is_a_shipped_configuration():
                        env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-600:], r.stderr[-400:])
     assert r.returncode == 0, r.stdout[-800:]
+
+
+@pytest.mark.parametrize("env", [{"CSS_BN_PASS_ORDER": "1"}, {"CSS_BN_PASS_ORDER": "2"}, {"CSS_BN_PASS_ORDER": "4"}, {"CSS_BN_PASS_ORDER": "7"}, {"CSS_BN_PASS_ORDER": "0"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_bn_pass_order_switch_is_a_shipped_configuration(env):
+    """CSS_BN_PASS_ORDER (css_amd/csrc/bn.hip: which of the three streaming batch-norm passes walk the rows downwards): same results."""
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ops_gpu.py"), "-q", "-x", "-k", "bn_act_train", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, r.stdout[-800:]
+
+
+@pytest.mark.parametrize("env", [{"CSS_NO_P8_CONV": "1"}, {"CSS_NO_PP64_CONV": "1"}, {"CSS_NO_WS_CONV": "1"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"},
+                                 {"CSS_NO_PP64_CONV": "1", "CSS_PP_272": "1"}],
+                         ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
+def test_masked_residual_gradient_under_every_conv_fallback(env):
+    """css_conv2d_dgrad_add_masked on each kernel family the switches route it to (conv_pp64 / conv_pp / the 256x256 and 128x128 LDS-DMA
+    kernels / the register-staged kernel): tests/test_dgrad_add_masked_gpu.py in a process of its own."""
+    e = dict(os.environ)
+    e.update(env)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_dgrad_add_masked_gpu.py"), "-q", "-x", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, r.stdout[-800:]
