@@ -77,55 +77,82 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
 constexpr int S2_CH = S2_CH_V, S2_NP = 1024 / S2_CH_V;
 struct NoTail { __device__ __forceinline__ void operator()(int, int, int, int, double&, double&) const {} };
 // tail(g, c, pl, P, t0, t1): optional extra contribution of partition pl (of P) to the sums of (group g, channel c)
+// Latency is everything here (profiles/r03_bn_stage2_prefetch.txt): ONE memory round trip for the usual launch - all of a thread's partial
+// rows (up to S2_U) are requested at once, the tail's rows right behind them, and only then the first value is used (the callers fetch
+// gamma / beta / the running statistics before they call this, for the same reason); partitions are summed inside a wave with lane
+// shuffles, the 16 waves through LDS with one barrier.
+constexpr int S2_U = 12;
+__device__ __forceinline__ double s2_shfl_xor(double v, int m) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __shfl_xor(lo, m, 64);
+  hi = __shfl_xor(hi, m, 64);
+  return __hiloint2double(hi, lo);
+}
 template <typename PT, typename Rows, typename Emit, typename Tail = NoTail>
 __device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, int C, int G, Rows rows, Emit emit, Tail tail = Tail()) {
-  __shared__ double red[2][S2_NP][S2_CH];
-  const int cl = threadIdx.x & (S2_CH - 1), part = threadIdx.x / S2_CH;
+  static_assert(S2_CH == 8, "a wave = 8 partitions x 8 channels");
+  __shared__ double red[2][16][S2_CH];
+  const int cl = threadIdx.x & (S2_CH - 1), part = threadIdx.x / S2_CH, wave = threadIdx.x >> 6;
   const int c = blockIdx.x * S2_CH + cl;
-  const int GP = (G <= S2_NP && S2_NP % G == 0) ? G : 1;      // groups reduced concurrently
+  const int cc = c < C ? c : C - 1;                           // (threads past the last channel read channel C-1 and are never emitted)
+  const int GP = (G <= 16 && S2_NP % G == 0) ? G : 1;         // groups reduced concurrently (a wave's 8 partitions stay in one group)
   const int P = S2_NP / GP;                                   // partitions per group
   const int gslot = part / P, pl = part % P;
   for (int g0 = 0; g0 < G; g0 += GP) {
     const int g = g0 + gslot;
-    double a0[8], a1[8];
+    int lo, hi, extra;
+    rows(g, lo, hi, extra);
+    double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
+    // first S2_U rows of this thread: every request goes out before the first use (rows past `hi` re-read row `lo` and count as zero)
+    PT v0[S2_U], v1[S2_U];
+    const int safe = lo < hi ? lo : 0;
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a0[u] = a1[u] = 0.0;
-    if (c < C) {
-      int lo, hi, extra;
-      rows(g, lo, hi, extra);
-      int r = lo + pl;
-      for (; r + 7 * P < hi; r += 8 * P) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a0[u] += (double)partial[(size_t)(r + u * P) * 2 * C + c];
-          a1[u] += (double)partial[(size_t)(r + u * P) * 2 * C + C + c];
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        if (r + u * P < hi) {
-          a0[u] += (double)partial[(size_t)(r + u * P) * 2 * C + c];
-          a1[u] += (double)partial[(size_t)(r + u * P) * 2 * C + C + c];
-        }
-      }
-      if (pl == 0 && extra >= 0) {
-        a0[7] += (double)partial[(size_t)extra * 2 * C + c];
-        a1[7] += (double)partial[(size_t)extra * 2 * C + C + c];
-      }
-      tail(g, c, pl, P, a0[6], a1[6]);
+    for (int u = 0; u < S2_U; ++u) {
+      const int rr = lo + pl + u * P;
+      const size_t src = (size_t)(rr < hi ? rr : safe) * 2 * C + cc;
+      v0[u] = partial[src];
+      v1[u] = partial[src + C];
     }
-    red[0][part][cl] = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + ((a0[4] + a0[5]) + (a0[6] + a0[7]));
-    red[1][part][cl] = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + ((a1[4] + a1[5]) + (a1[6] + a1[7]));
+    double t0 = 0.0, t1 = 0.0;
+    tail(g, cc, pl, P, t0, t1);
+#pragma unroll
+    for (int u = 0; u < S2_U; ++u) {
+      const bool ok = lo + pl + u * P < hi;
+      a0[u & 3] += ok ? (double)v0[u] : 0.0;
+      a1[u & 3] += ok ? (double)v1[u] : 0.0;
+    }
+    for (int r = lo + pl + S2_U * P; r < hi; r += 4 * P) {      // (more than S2_U x P partial rows: the c4-sized tensors)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = r + u * P < hi;
+        const size_t src = (size_t)(ok ? r + u * P : safe) * 2 * C + cc;
+        const PT w0 = partial[src], w1 = partial[src + C];
+        a0[u] += ok ? (double)w0 : 0.0;
+        a1[u] += ok ? (double)w1 : 0.0;
+      }
+    }
+    double s0 = ((a0[0] + a0[1]) + (a0[2] + a0[3])) + t0, s1 = ((a1[0] + a1[1]) + (a1[2] + a1[3])) + t1;
+#pragma unroll
+    for (int m = 8; m < 64; m <<= 1) {                          // over the wave's 8 partitions (lane = partition * 8 + channel)
+      s0 += s2_shfl_xor(s0, m);
+      s1 += s2_shfl_xor(s1, m);
+    }
+    if ((threadIdx.x & 63) < S2_CH) {
+      red[0][wave][cl] = s0;
+      red[1][wave][cl] = s1;
+    }
     __syncthreads();
-    for (int st = P >> 1; st > 0; st >>= 1) {
-      if (pl < st) {
-        red[0][part][cl] += red[0][part + st][cl];
-        red[1][part][cl] += red[1][part + st][cl];
+    if (part == 0 && c < C) {
+      const int wpg = P / 8;                                    // waves per group
+      for (int q = 0; q < GP; ++q) {
+        double e0 = 0.0, e1 = 0.0;
+        for (int w = 0; w < wpg; ++w) {
+          e0 += red[0][q * wpg + w][cl];
+          e1 += red[1][q * wpg + w][cl];
+        }
+        emit(g0 + q, e0, e1, c);
       }
-      __syncthreads();
     }
-    if (part == 0 && c < C)
-      for (int q = 0; q < GP; ++q) emit(g0 + q, red[0][q * P][cl], red[1][q * P][cl], c);
     __syncthreads();
   }
 }
@@ -150,20 +177,46 @@ __device__ __forceinline__ void bn_finalize_one(double a0, double a1, double cou
     running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
+// the same with gamma / beta / the running statistics already in registers (fetched before the reduction: their round trip hides
+// behind the partial rows'); the running statistics are stored after every group's update
+__device__ __forceinline__ void bn_finalize_reg(double a0, double a1, double count, float gam, float bet, float& rm, float& rv, float* running_mean,
+                                                float* running_var, float momentum, float eps, float* mean_out, float* invstd_out, float* scale_out,
+                                                float* shift_out, int c) {
+  double mean = a0 / count;
+  double var = a1 / count - mean * mean;
+  if (var < 0) var = 0;
+  const float fmean = (float)mean, fvar = (float)var;
+  const float invstd = 1.0f / sqrtf(fvar + eps);
+  mean_out[c] = fmean;
+  invstd_out[c] = invstd;
+  const float sc = gam * invstd;
+  scale_out[c] = sc;
+  shift_out[c] = bet - fmean * sc;
+  if (running_mean) {
+    const double unbiased = count > 1 ? var * count / (count - 1) : var;
+    rm = (1.f - momentum) * rm + momentum * fmean;
+    rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    running_mean[c] = rm;
+    running_var[c] = rv;
+  }
+}
 // grid = ceil(C/8), block 1024.  partial is [G][nrb][2][C] (fp64); sums is [G][2][C].
 __global__ __launch_bounds__(1024) void bn_reduce_kernel(const double* __restrict__ partial, int nrb, int C, int G, double* __restrict__ sums,
                                                          float* __restrict__ g1, float* __restrict__ g0, int accumulate, double count_local) {
   double t0 = 0, t1 = 0;
   // SyncBN with per-rank pixel counts: the local count of every group rides behind the sums and is all-reduced with them
   if (sums && count_local > 0 && blockIdx.x == 0 && threadIdx.x < G) sums[(size_t)G * 2 * C + threadIdx.x] = count_local;
+  const int ce = blockIdx.x * S2_CH + (int)threadIdx.x;          // the emitting threads (0..S2_CH-1): their channel
+  float old0 = 0.f, old1 = 0.f;
+  if (accumulate && g0 && threadIdx.x < S2_CH && ce < C) { old0 = g0[ce]; old1 = g1[ce]; }      // (before the reduction: see stage2_reduce)
   stage2_reduce(
       partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
       [&](int g, double a0, double a1, int c) {
         if (sums) { sums[(size_t)g * 2 * C + c] = a0; sums[(size_t)g * 2 * C + C + c] = a1; }
         t0 += a0; t1 += a1;
         if (g == G - 1 && g0) {   // BN backward: dbeta = sum(dz), dgamma = sum(dz*xhat), summed over the groups
-          if (accumulate) { g0[c] += (float)t0; g1[c] += (float)t1; }
-          else { g0[c] = (float)t0; g1[c] = (float)t1; }
+          g0[c] = old0 + (float)t0;
+          g1[c] = old1 + (float)t1;
         }
       });
 }
@@ -172,10 +225,16 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                   float* running_mean, float* running_var, float momentum, float eps,
                                                                   float* mean_out, float* invstd_out, float* scale_out, float* shift_out, int C) {
+  const int ce = blockIdx.x * S2_CH + (int)threadIdx.x;
+  float gam = 0.f, bet = 0.f, rm = 0.f, rv = 0.f;
+  if (threadIdx.x < S2_CH && ce < C) {
+    gam = gamma[ce]; bet = beta[ce];
+    if (running_mean) { rm = running_mean[ce]; rv = running_var[ce]; }
+  }
   stage2_reduce(
       partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
       [&](int g, double a0, double a1, int c) {
-        bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+        bn_finalize_reg(a0, a1, count, gam, bet, rm, rv, running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
                         scale_out + g * C, shift_out + g * C, c);
       });
 }
@@ -199,6 +258,12 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
                                                                float* mean_out, float* invstd_out, float* scale_out, float* shift_out,
                                                                double* sums_out, int C, const bf16_t* __restrict__ y, int ldy, int BM) {
   if (sums_out && blockIdx.x == 0 && threadIdx.x < G) sums_out[(size_t)G * 2 * C + threadIdx.x] = (double)Mg;   // local count, see bn_reduce_kernel
+  const int ce = blockIdx.x * S2_CH + (int)threadIdx.x;
+  float gam = 0.f, bet = 0.f, rm = 0.f, rv = 0.f;
+  if (!sums_out && threadIdx.x < S2_CH && ce < C) {
+    gam = gamma[ce]; bet = beta[ce];
+    if (running_mean) { rm = running_mean[ce]; rv = running_var[ce]; }
+  }
   stage2_reduce(
       partial, C, G,
       [&](int g, int& lo, int& hi, int& extra) {
@@ -213,7 +278,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
           sums_out[(size_t)g * 2 * C + c] = a0;
           sums_out[(size_t)g * 2 * C + C + c] = a1;
         } else {
-          bn_finalize_one(a0, a1, count, gamma[c], beta[c], running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
+          bn_finalize_reg(a0, a1, count, gam, bet, rm, rv, running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
                           scale_out + g * C, shift_out + g * C, c);
         }
       },
