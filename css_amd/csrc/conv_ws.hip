@@ -79,6 +79,21 @@ template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_st
 #ifndef WS_PP
 #define WS_PP 0
 #endif
+// Diagnostic build only (-DWS_STAMP, scripts/ws_bench.hip): s_memtime differences summed per wave over the steady-state tiles (ti >= 2) -
+// stage wait / barrier / LDS-DMA issue / fragment reads + MFMAs / epilogue - and written at the end through a.bias as
+// [workgroup][wave][8] 64-bit ticks (slot 7: number of tiles counted).
+#ifdef WS_STAMP
+#define WS_T(var)                                                                        \
+  do {                                                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");          \
+    __builtin_amdgcn_sched_barrier(0);                                                   \
+  } while (0)
+#define WS_ACC(i, t1, t0) do { if (ti >= 2) wsum[i] += (t1) - (t0); } while (0)
+#else
+#define WS_T(var)
+#define WS_ACC(i, t1, t0)
+#endif
 
 // KS = K / 64 (stages per pixel tile).  grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 256) == 0.
 template <int KS, bool STATS, bool ADD>
@@ -272,6 +287,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     }
   };
 
+#ifdef WS_STAMP
+  unsigned long long wsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt0 = 0, wt1 = 0;
+#endif
   if constexpr (WS_PP != 0) {
     static_assert(NT == 2, "the ping-pong variant counts two tiles of look-ahead");
     // ---- ping-pong: waves 0-3 and waves 4-7 (one of each per SIMD) run half a stage apart - READ segment (last tile's epilogue,
@@ -337,18 +355,24 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    WS_T(wt0);
     if (ADD) load_addend(m0);
+    WS_T(wt1); WS_ACC(5, wt1, wt0);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       __builtin_amdgcn_sched_barrier(0);
+      WS_T(wt0);
       // my two pieces of this stage have landed (see the header for the counts)
       if (ti >= 2) ws_wait_vm<W2>();
       else if (ti == 1) ws_wait_vm<W1>();
       else ws_wait_vm<W0>();
+      WS_T(wt1); WS_ACC(0, wt1, wt0);
       __builtin_amdgcn_s_barrier();       // everybody's pieces have landed; everybody is done reading the previous stages
       asm volatile("" ::: "memory");
+      WS_T(wt0); WS_ACC(1, wt0, wt1);
       __builtin_amdgcn_sched_barrier(0);
       if (!ABL_NODMA) issue_stage();      // stage + LA into the slot read two stages ago
+      WS_T(wt1); WS_ACC(2, wt1, wt0);
       __builtin_amdgcn_sched_barrier(0);
       const unsigned char* ab = smem + cslot * STG + l15 * 128;
       // all fragment reads of the stage first (16 x ds_read_b128, back to back), then its 32 MFMAs back to back: left to itself the
@@ -368,12 +392,25 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
         if (KS <= 4) __builtin_amdgcn_sched_barrier(0);
       }
       cslot = cslot == NS - 1 ? 0 : cslot + 1;
+      WS_T(wt0); WS_ACC(3, wt0, wt1);
     }
     __builtin_amdgcn_sched_barrier(0);
+    WS_T(wt0);
     epilogue(m0);
+    WS_T(wt1); WS_ACC(4, wt1, wt0);
+#ifdef WS_STAMP
+    if (ti >= 2) wsum[7] += 1;
+#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   }
+#ifdef WS_STAMP
+  if (a.bias && lane == 0) {
+    unsigned long long* o = (unsigned long long*)a.bias + ((size_t)blockIdx.x * 8 + wave) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = wsum[i];
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // ghost pieces (stages past my last tile) must have landed before the LDS is released
 }
 
@@ -383,7 +420,11 @@ void css_conv_ws_set_enabled(int on) { g_ws_off = on ? 0 : 1; }     // (A/B timi
 bool css_conv_ws_supported(const ConvArgs& a, int n_cu) {
   if (g_ws_off < 0) g_ws_off = getenv("CSS_NO_WS_CONV") != nullptr;
   const bool off = g_ws_off != 0;
+#ifdef WS_STAMP
+  if (off || a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd) return false;      // (a.bias carries the stamp buffer)
+#else
   if (off || a.R != 1 || a.S != 1 || a.stride != 1 || a.pad != 0 || a.Hs != a.Hd || a.Ws != a.Wd || a.bias) return false;
+#endif
   if (a.Ktot != a.Cs || (a.Cs != 64 && a.Cs != 128 && a.Cs != 256 && a.Cs != 512) || a.Cd < 256 || a.Cd % 256 || a.lds % 8 || a.ldd % 8) return false;
   if (a.Cs == 512 && a.addend) return false;        // (128 registers of weights + 32 of addend + 64 accumulators + fragments: no room)
   if (a.stats && a.addend) return false;

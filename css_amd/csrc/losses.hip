@@ -239,6 +239,209 @@ __global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__
   }
 }
 
+// The same forward on 32x32 label tiles (grid: tiles_x, tiles_y, B), for K <= CES_KREG and an up-sampling factor >= 2: the tile's
+// footprint in the small map goes to LDS once (fp32, like the backward below), a pixel's K interpolated logits stay in registers for
+// the maximum, the sum and the label's own logit (the kernel above gathers every class twice from global memory with scalar
+// loads - instruction-bound, 375 us at c2 against ~0.1 ms here).  Same arithmetic per pixel, same statistics.
+constexpr int CES_KREG = 24;
+struct CesCorner { int c00, c01, c10, c11; float wy0, wy1, wx0, wx1; };
+__device__ __forceinline__ CesCorner ces_corner(int y, int x, float sh, float sw, int h, int w, int fy0, int fx0, int fw, int K) {
+  float fy = sh * (float)y, fx = sw * (float)x;
+  int y0 = (int)fy, x0 = (int)fx;
+  if (y0 > h - 1) y0 = h - 1;
+  if (x0 > w - 1) x0 = w - 1;
+  const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+  CesCorner r;
+  r.wy1 = fy - (float)y0; r.wy0 = 1.f - r.wy1; r.wx1 = fx - (float)x0; r.wx0 = 1.f - r.wx1;
+  r.c00 = ((y0 - fy0) * fw + (x0 - fx0)) * K; r.c01 = ((y0 - fy0) * fw + (x1 - fx0)) * K;
+  r.c10 = ((y1 - fy0) * fw + (x0 - fx0)) * K; r.c11 = ((y1 - fy0) * fw + (x1 - fx0)) * K;
+  return r;
+}
+// LDS footprint of the tiled kernels: CES_KREG floats per small pixel (classes >= K hold CES_NEG: they never win the maximum and their
+// exponential is 0), so the class loops have compile-time bounds and read / write 16-byte vectors.
+constexpr float CES_NEG = -1e30f;
+struct CesVec { float4 q[CES_KREG / 4]; };
+__device__ __forceinline__ void ces_interp_all(const float* __restrict__ fp, const CesCorner& q, float (&v)[CES_KREG]) {
+  const float4* p00 = reinterpret_cast<const float4*>(fp + q.c00);
+  const float4* p01 = reinterpret_cast<const float4*>(fp + q.c01);
+  const float4* p10 = reinterpret_cast<const float4*>(fp + q.c10);
+  const float4* p11 = reinterpret_cast<const float4*>(fp + q.c11);
+#pragma unroll
+  for (int j = 0; j < CES_KREG / 4; ++j) {
+    const float4 a = p00[j], b = p01[j], c = p10[j], d = p11[j];
+    v[4 * j + 0] = q.wy0 * (q.wx0 * a.x + q.wx1 * b.x) + q.wy1 * (q.wx0 * c.x + q.wx1 * d.x);
+    v[4 * j + 1] = q.wy0 * (q.wx0 * a.y + q.wx1 * b.y) + q.wy1 * (q.wx0 * c.y + q.wx1 * d.y);
+    v[4 * j + 2] = q.wy0 * (q.wx0 * a.z + q.wx1 * b.z) + q.wy1 * (q.wx0 * c.z + q.wx1 * d.z);
+    v[4 * j + 3] = q.wy0 * (q.wx0 * a.w + q.wx1 * b.w) + q.wy1 * (q.wx0 * c.w + q.wx1 * d.w);
+  }
+}
+// stage the footprint (fh x fw small pixels from (fy0, fx0) of image b) as [cell][CES_KREG] fp32
+template <typename T>
+__device__ __forceinline__ void ces_stage(float* __restrict__ fp, const T* __restrict__ small, int ld, int h, int w, int b, int fy0, int fx0, int fh,
+                                          int fw, int K, int tid) {
+  for (int i = tid; i < fh * fw * CES_KREG; i += 256) {
+    const int k = i % CES_KREG, c = i / CES_KREG, yy = c / fw, xx = c - yy * fw;
+    fp[i] = k < K ? ElemT<T>::to_f(small[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * ld + k]) : CES_NEG;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
+                                                                const int64_t* __restrict__ label, const float* __restrict__ conf, float conf_thr,
+                                                                const float* __restrict__ keep_thr, int K, int H, int W,
+                                                                double* __restrict__ stats, float* __restrict__ gtprob_out) {
+  extern __shared__ __attribute__((aligned(16))) float ces_lds[];
+  __shared__ float sacc[4];
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
+  const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
+  int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
+  fy0 = min(fy0, h - 1); fx0 = min(fx0, w - 1);
+  const int fy1 = min((int)(sh * (float)Y1) + 1, h - 1), fx1 = min((int)(sw * (float)X1) + 1, w - 1);
+  const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
+  ces_stage(ces_lds, small, ld, h, w, b, fy0, fx0, fh, fw, K, tid);
+  if (tid < 4) sacc[tid] = 0.f;
+  __syncthreads();
+  const float kthr = keep_thr ? *keep_thr : 0.f;
+  float a_s = 0.f, a_nv = 0.f, a_np = 0.f, a_nc = 0.f;
+  const int x = X0 + (tid & 31);
+#pragma unroll
+  for (int trip = 0; trip < CES_TH / 8; ++trip) {
+    const int y = Y0 + (tid >> 5) + 8 * trip;
+    if (x >= W || y >= H) continue;
+    const size_t p = ((size_t)b * H + y) * W + x;
+    const int64_t lab = label[p];
+    const CesCorner q = ces_corner(y, x, sh, sw, h, w, fy0, fx0, fw, CES_KREG);
+    float v[CES_KREG];
+    ces_interp_all(ces_lds, q, v);
+    float mx = v[0];
+#pragma unroll
+    for (int k = 1; k < CES_KREG; ++k) mx = fmaxf(mx, v[k]);
+    float se = 0.f, xg = 0.f;
+#pragma unroll
+    for (int k = 0; k < CES_KREG; ++k) {
+      se += __expf(v[k] - mx);
+      if (k == lab) xg = v[k];
+    }
+    bool valid = lab >= 0 && lab < K;
+    float loss = 0.f, gtp = 1.f;
+    if (valid) {
+      loss = logf(se) + mx - xg;
+      gtp = __expf(xg - mx) / se;
+      if (keep_thr && !(gtp <= kthr)) { valid = false; loss = 0.f; }
+    }
+    if (gtprob_out) gtprob_out[p] = (lab >= 0 && lab < K) ? gtp : 1.f;
+    if (valid) {
+      a_s += loss;
+      a_nv += 1.f;
+      if (loss > 0.f) a_np += 1.f;
+    }
+    if (conf && conf[p] >= conf_thr) a_nc += 1.f;
+  }
+  if (stats) {
+    a_s = wave_sum(a_s); a_nv = wave_sum(a_nv); a_np = wave_sum(a_np); a_nc = wave_sum(a_nc);
+    if ((tid & 63) == 0) {
+      atomicAdd(&sacc[ST_S], a_s); atomicAdd(&sacc[ST_NVALID], a_nv); atomicAdd(&sacc[ST_NPOS], a_np); atomicAdd(&sacc[ST_NCONF], a_nc);
+    }
+    __syncthreads();
+    if (tid < 4 && sacc[tid] != 0.f) atomicAdd(&stats[(size_t)b * 4 + tid], (double)sacc[tid]);
+  }
+}
+
+// Backward on the same tiles for K <= CES_KREG and an up-sampling factor in [2, 4]: per pixel ONE pass over the footprint for the K
+// interpolated logits (registers), then the adjoint of the interpolation as four read-modify-write phases (one per corner, 16-byte
+// vectors, no branch per class) into the wave's own gradient copy.  The phases stay whole instructions apart - a cell that is this lane's
+// right-hand neighbour is another lane's own cell - and within a phase the 64 lanes touch 64 different cells: the 8x8 lattice below
+// sends them to different small pixels, and a corner of weight zero (integral source coordinate: the only case in which a clamped
+// neighbour coincides with another lane's cell of the same phase) is redirected to a cell of the lane's own behind the copies.
+// (The general kernel below branches per class and corner: 21 x 4 serialized LDS round trips per pixel, 650 us at c2.)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_small_bwd_tile_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
+                                                                const int64_t* __restrict__ label, const float* __restrict__ keep_thr, int K, int H,
+                                                                int W, const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
+                                                                float* __restrict__ dsmall) {
+  extern __shared__ __attribute__((aligned(16))) float ces_lds[];
+  constexpr int FPK = CES_FP * CES_FP * CES_KREG;
+  const int tid = threadIdx.x, b = blockIdx.z, wave = tid >> 6;
+  float* sout = ces_lds + FPK + wave * FPK;
+  const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
+  const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
+  int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
+  fy0 = min(fy0, h - 1); fx0 = min(fx0, w - 1);
+  const int fy1 = min((int)(sh * (float)Y1) + 1, h - 1), fx1 = min((int)(sw * (float)X1) + 1, w - 1);
+  const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
+  const float cb = coef[b] * (*gscale);
+  if (cb == 0.f) return;                                  // (block-uniform) this image contributes nothing: e.g. no confident pseudo label in it
+  {
+    // nothing to do either when the tile holds no labeled pixel (ignore regions, unconfident pseudo labels)
+    bool any = false;
+    for (int i = tid; i < CES_TW * CES_TH; i += 256) {
+      const int x = X0 + (i & (CES_TW - 1)), y = Y0 + i / CES_TW;
+      if (x < W && y < H) {
+        const int64_t lab = label[((size_t)b * H + y) * W + x];
+        any |= lab >= 0 && lab < K;
+      }
+    }
+    if (!__syncthreads_or(any)) return;
+  }
+  ces_stage(ces_lds, small, ld, h, w, b, fy0, fx0, fh, fw, K, tid);
+  for (int i = tid; i < 4 * FPK / 4; i += 256) reinterpret_cast<float4*>(ces_lds + FPK)[i] = float4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  const float kthr = keep_thr ? *keep_thr : 0.f;
+  const int dmy = 4 * FPK - wave * FPK + (tid & 63) * CES_KREG;       // this lane's private cell (shared by the four waves: its content is never used), as an index relative to sout
+  for (int trip = 0; trip < 4; ++trip) {
+    const int phase = wave * 4 + trip, lane = tid & 63;
+    const int x = X0 + (lane & 7) * 4 + (phase & 3), y = Y0 + (lane >> 3) * 4 + (phase >> 2);
+    if (x >= W || y >= H) continue;
+    const int64_t lab = label[((size_t)b * H + y) * W + x];
+    if (!(lab >= 0 && lab < K) || cb == 0.f) continue;
+    const CesCorner q = ces_corner(y, x, sh, sw, h, w, fy0, fx0, fw, CES_KREG);
+    float v[CES_KREG];
+    ces_interp_all(ces_lds, q, v);
+    float mx = v[0], xg = 0.f;
+#pragma unroll
+    for (int k = 1; k < CES_KREG; ++k) mx = fmaxf(mx, v[k]);
+#pragma unroll
+    for (int k = 0; k < CES_KREG; ++k)
+      if (k == lab) xg = v[k];
+    float se = 0.f;
+#pragma unroll
+    for (int k = 0; k < CES_KREG; ++k) {
+      v[k] = __expf(v[k] - mx);
+      se += v[k];
+    }
+    const float loss = logf(se) + mx - xg;                         // (the forward's expressions, term by term)
+    if (keep_thr && !(__expf(xg - mx) / se <= kthr)) continue;
+    if (pos_only && !(loss > 0.f)) continue;
+    const float inv = 1.f / se;
+#pragma unroll
+    for (int k = 0; k < CES_KREG; ++k) v[k] = cb * (v[k] * inv - (k == lab ? 1.f : 0.f));      // (classes >= K: exp = 0, gradient 0)
+    const float w01 = q.wy0 * q.wx1, w10 = q.wy1 * q.wx0, w11 = q.wy1 * q.wx1;
+    const int base[4] = {q.c00, w01 != 0.f ? q.c01 : dmy, w10 != 0.f ? q.c10 : dmy, w11 != 0.f ? q.c11 : dmy};
+    const float wgt[4] = {q.wy0 * q.wx0, w01, w10, w11};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      float4* cell = reinterpret_cast<float4*>(sout + base[c]);
+      float4 r[CES_KREG / 4];
+#pragma unroll
+      for (int j = 0; j < CES_KREG / 4; ++j) r[j] = cell[j];
+#pragma unroll
+      for (int j = 0; j < CES_KREG / 4; ++j) {
+        r[j].x += wgt[c] * v[4 * j]; r[j].y += wgt[c] * v[4 * j + 1]; r[j].z += wgt[c] * v[4 * j + 2]; r[j].w += wgt[c] * v[4 * j + 3];
+        cell[j] = r[j];
+      }
+      __builtin_amdgcn_sched_barrier(0);        // (phases in program order)
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < fh * fw * K; i += 256) {
+    const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
+    const float* so = ces_lds + FPK + c * CES_KREG + k;
+    const float v = (so[0] + so[FPK]) + (so[2 * FPK] + so[3 * FPK]);
+    if (v == 0.f) continue;
+    atomicAdd(&dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k], v);
+  }
+}
+
 // grid: (tiles_x, tiles_y, B); dsmall fp32 [B][h][w][K], zeroed by the caller
 template <typename T>
 __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
@@ -373,6 +576,21 @@ int css_launch_ce_small_fwd(const void* small, int ld, int B, int h, int w, cons
   if (K > CE_MAXK || K < 1 || B <= 0) return CSS_ERR_ARG;
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const size_t P = (size_t)B * H * W;
+  static const bool no_tile = getenv("CSS_CE_NO_TILE") != nullptr;      // (A/B and parity tests: the gather kernel for every shape)
+  if (!no_tile && K <= CES_KREG && 2 * (h - 1) <= (H - 1) && 2 * (w - 1) <= (W - 1)) {
+    // up-sampling factor >= 2 (a 32x32 tile's footprint fits CES_FP^2 small pixels) and the classes fit in registers: tiled kernel
+    const dim3 g(cdiv(W, CES_TW), cdiv(H, CES_TH), B);
+    const size_t lds = (size_t)CES_FP * CES_FP * CES_KREG * sizeof(float);
+    if (dtype == CSS_BF16)
+      hipLaunchKernelGGL(ce_small_fwd_tile_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, conf, conf_thr, keep_thr, K, H,
+                         W, stats, gtprob_out);
+    else if (dtype == CSS_F32)
+      hipLaunchKernelGGL(ce_small_fwd_tile_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, conf, conf_thr, keep_thr, K, H, W,
+                         stats, gtprob_out);
+    else return CSS_ERR_DTYPE;
+    CSS_CHECK_LAUNCH();
+    return CSS_OK;
+  }
   if (dtype == CSS_BF16)
     hipLaunchKernelGGL(ce_small_fwd_kernel<bf16_t>, dim3(ce_grid(P)), dim3(256), 0, st, (const bf16_t*)small, ld, h, w, sh, sw, label, conf, conf_thr,
                        keep_thr, K, P, H, W, stats, gtprob_out);
@@ -390,6 +608,21 @@ int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, cons
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   dim3 g(cdiv(W, CES_TW), cdiv(H, CES_TH), B);
   const size_t fpk = (size_t)CES_FP * CES_FP * K * sizeof(float);
+  static const bool no_tile = getenv("CSS_CE_NO_TILE") != nullptr;
+  if (!no_tile && K <= CES_KREG && sh >= 0.2499f && sw >= 0.2499f) {
+    // factor in [2, 4], classes in registers: the tiled kernel (footprint + four per-wave gradient copies of CES_KREG floats per small
+    // pixel + one private cell per lane: 157.9 KiB of LDS)
+    const size_t lds = ((size_t)5 * CES_FP * CES_FP + 64) * CES_KREG * sizeof(float);
+    if (dtype == CSS_BF16)
+      hipLaunchKernelGGL(ce_small_bwd_tile_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
+                         gscale, pos_only, dsmall);
+    else if (dtype == CSS_F32)
+      hipLaunchKernelGGL(ce_small_bwd_tile_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
+                         gscale, pos_only, dsmall);
+    else return CSS_ERR_DTYPE;
+    CSS_CHECK_LAUNCH();
+    return CSS_OK;
+  }
   const int use_rmw = sh >= 0.2499f && sw >= 0.2499f && 5 * fpk <= 152 * 1024;   // logits + four per-wave gradient copies (133 KiB at K = 21)
   const size_t lds = (use_rmw ? 5 : 2) * fpk;
   if (dtype == CSS_BF16)

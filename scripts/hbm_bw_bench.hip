@@ -1,0 +1,75 @@
+// What one MI355X sustains on plain streams of the sizes the short-K 1x1 convolutions move (round 3): fill, read, copy, and the store
+// pattern of conv_ws_kernel's epilogue (a wave writes 64 B of each of 16 rows at a 2 KiB pitch per instruction).
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 scripts/hbm_bw_bench.hip -o build/hbm_bw_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <algorithm>
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void fill_k(u32x4* __restrict__ d, size_t n) {
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = v;
+}
+__global__ __launch_bounds__(256) void read_k(const u32x4* __restrict__ s, size_t n, u32x4* __restrict__ out) {
+  u32x4 a = {0, 0, 0, 0};
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) a ^= s[i];
+  if (a[0] == 0x12345678u) out[0] = a;
+}
+__global__ __launch_bounds__(256) void copy_k(const u32x4* __restrict__ s, u32x4* __restrict__ d, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+// rows of `pitch` bytes; a workgroup (8 waves) owns a 128-row x 512-byte panel tile: wave w writes bytes [64 w, 64 w + 64) of the panel
+// for 128 rows, 16 rows per instruction (lane = row16 * 4 + 16-byte piece) - conv_ws_kernel's epilogue
+__global__ __launch_bounds__(512) void ws_pattern_k(unsigned char* __restrict__ d, int rows, int pitch) {
+  const int panels = pitch / 512, tiles = rows / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (int t = blockIdx.x; t < tiles * panels; t += gridDim.x) {
+    const int panel = t % panels, tile = t / panels;
+    unsigned char* base = d + (size_t)tile * 128 * pitch + panel * 512 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * i + (lane & 15)) * pitch + (lane >> 4) * 16) = v;
+  }
+}
+// the same bytes with whole 512-byte panel rows per instruction pair: wave w writes rows 16 w .. 16 w + 15 of the tile, 2 rows (1 KiB) per instruction
+__global__ __launch_bounds__(512) void ws_rows_k(unsigned char* __restrict__ d, int rows, int pitch) {
+  const int panels = pitch / 512, tiles = rows / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (int t = blockIdx.x; t < tiles * panels; t += gridDim.x) {
+    const int panel = t % panels, tile = t / panels;
+    unsigned char* base = d + (size_t)tile * 128 * pitch + panel * 512;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * wave + 2 * i + (lane >> 5)) * pitch + (lane & 31) * 16) = v;
+  }
+}
+template <typename F> static double timeit(F f, int reps = 20) {
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) f();
+  std::vector<float> ts;
+  for (int r = 0; r < reps; ++r) { hipEventRecord(e0); f(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); ts.push_back(ms); }
+  std::sort(ts.begin(), ts.end());
+  return ts[ts.size() / 2] * 1e-3;
+}
+int main() {
+  const int rows = 135168, pitch = 2048;            // 277 MB: the layer-3 block output of the c2 workload (1024 channels, bf16)
+  const size_t bytes = (size_t)rows * pitch, n = bytes / 16;
+  unsigned char *a, *b; hipMalloc(&a, bytes); hipMalloc(&b, bytes); hipMemset(a, 1, bytes); hipMemset(b, 2, bytes);
+  for (int blocks : {256, 1024, 2048, 8192}) {
+    double t;
+    t = timeit([&] { hipLaunchKernelGGL(fill_k, dim3(blocks), dim3(256), 0, 0, (u32x4*)a, n); });
+    printf("fill   %5d blocks: %7.1f us  %6.2f TB/s written\n", blocks, t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(read_k, dim3(blocks), dim3(256), 0, 0, (const u32x4*)a, n, (u32x4*)b); });
+    printf("read   %5d blocks: %7.1f us  %6.2f TB/s read\n", blocks, t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(copy_k, dim3(blocks), dim3(256), 0, 0, (const u32x4*)a, (u32x4*)b, n); });
+    printf("copy   %5d blocks: %7.1f us  %6.2f TB/s read + written\n", blocks, t * 1e6, 2.0 * bytes / t / 1e12);
+  }
+  for (int blocks : {256, 512, 1024}) {
+    double t = timeit([&] { hipLaunchKernelGGL(ws_pattern_k, dim3(blocks), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern (64 B x 16 rows per instruction), %4d workgroups: %7.1f us  %6.2f TB/s written\n", blocks, t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(ws_rows_k, dim3(blocks), dim3(512), 0, 0, a, rows, pitch); });
+    printf("whole 512-byte panel rows (2 rows per instruction),     %4d workgroups: %7.1f us  %6.2f TB/s written\n", blocks, t * 1e6, bytes / t / 1e12);
+  }
+  { double t = timeit([&] { hipMemsetAsync(a, 0, bytes, 0); }); printf("hipMemsetAsync: %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12); }
+  return 0;
+}

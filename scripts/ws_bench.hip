@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <algorithm>
 
 struct Shape { const char* name; int N, H, W, Cin, Cout, ldd; };   // ldd: row pitch of the output in elements (0: Cout)
 static float bf2f(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -77,6 +78,12 @@ int main() {
           skip = true;
           break;
         }
+#ifdef WS_STAMP
+        static unsigned long long* dbg = nullptr;
+        if (!dbg) hipMalloc(&dbg, 256 * 8 * 8 * 8);
+        hipMemset(dbg, 0, 256 * 8 * 8 * 8);
+        if (v == 1) a.bias = (const float*)dbg;
+#endif
         hipMemset(dy[v], 0xFF, ny * 2);
         hipMemset(dstat[v], 0, nstat * 4);
         int rc = css_launch_conv(a, CSS_BF16, 256, 0);
@@ -90,6 +97,27 @@ int main() {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         us[v] = ms / reps * 1e3f;
+#ifdef WS_STAMP
+        if (v == 1) {
+          hipMemset(dbg, 0, 256 * 8 * 8 * 8);
+          css_launch_conv(a, CSS_BF16, 256, 0);
+          hipDeviceSynchronize();
+          std::vector<unsigned long long> h(256 * 8 * 8);
+          hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
+          static const char* nm[6] = {"stage wait (vmcnt)", "barrier", "LDS-DMA issue", "reads + MFMAs", "epilogue", "addend request"};
+          printf("    %s %s: per steady-state tile, median over the waves of all workgroups (ticks of s_memtime = 100 MHz x ?):", s.name, ep_name[ep]);
+          double tot = 0;
+          for (int q = 0; q < 6; ++q) {
+            std::vector<double> vals;
+            for (int w = 0; w < 256 * 8; ++w) if (h[w * 8 + 7]) vals.push_back((double)h[w * 8 + q] / (double)h[w * 8 + 7]);
+            std::sort(vals.begin(), vals.end());
+            const double med = vals.empty() ? 0 : vals[vals.size() / 2];
+            printf("  %s %.0f", nm[q], med);
+            tot += med;
+          }
+          printf("  = %.0f ticks per tile\n", tot);
+        }
+#endif
       }
       if (skip) continue;
       // compare

@@ -102,3 +102,14 @@ def test_masked_residual_gradient_under_every_conv_fallback(env):
                        env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-600:], r.stderr[-400:])
     assert r.returncode == 0, r.stdout[-800:]
+
+
+def test_ce_gather_kernel_switch_is_a_shipped_configuration():
+    """CSS_CE_NO_TILE=1 (css_amd/csrc/losses.hip: the cross-entropy from low-resolution logits on the gather kernel instead of the tiled
+    one): the fused-loss parity tests under that switch, in a process of its own."""
+    e = dict(os.environ)
+    e["CSS_CE_NO_TILE"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_losses_gpu.py"), "-q", "-x", "-k", "low_resolution", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, r.stdout[-800:]
