@@ -80,8 +80,8 @@ template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_st
 #define WS_PP 0
 #endif
 // Diagnostic build only (-DWS_STAMP, scripts/ws_bench.hip): s_memtime differences summed per wave over the steady-state tiles (ti >= 2) -
-// stage wait / barrier / LDS-DMA issue / fragment reads + MFMAs / epilogue - and written at the end through a.bias as
-// [workgroup][wave][8] 64-bit ticks (slot 7: number of tiles counted).
+// stage wait and barrier of a tile's first stage (slots 0, 1) and of its other stages (5, 6) / LDS-DMA issue (2) / fragment reads + MFMAs
+// (3) / epilogue (4) - and written at the end through a.bias as [workgroup][wave][8] 64-bit ticks (slot 7: number of tiles counted).
 #ifdef WS_STAMP
 #define WS_T(var)                                                                        \
   do {                                                                                   \
@@ -355,9 +355,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    WS_T(wt0);
     if (ADD) load_addend(m0);
-    WS_T(wt1); WS_ACC(5, wt1, wt0);
 #pragma unroll
     for (int k = 0; k < KS; ++k) {
       __builtin_amdgcn_sched_barrier(0);
@@ -366,10 +364,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       if (ti >= 2) ws_wait_vm<W2>();
       else if (ti == 1) ws_wait_vm<W1>();
       else ws_wait_vm<W0>();
-      WS_T(wt1); WS_ACC(0, wt1, wt0);
+      WS_T(wt1); WS_ACC(k == 0 ? 0 : 5, wt1, wt0);
       __builtin_amdgcn_s_barrier();       // everybody's pieces have landed; everybody is done reading the previous stages
       asm volatile("" ::: "memory");
-      WS_T(wt0); WS_ACC(1, wt0, wt1);
+      WS_T(wt0); WS_ACC(k == 0 ? 1 : 6, wt0, wt1);
       __builtin_amdgcn_sched_barrier(0);
       if (!ABL_NODMA) issue_stage();      // stage + LA into the slot read two stages ago
       WS_T(wt1); WS_ACC(2, wt1, wt0);

@@ -43,6 +43,21 @@ __global__ __launch_bounds__(512) void ws_rows_k(unsigned char* __restrict__ d, 
     for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * wave + 2 * i + (lane >> 5)) * pitch + (lane & 31) * 16) = v;
   }
 }
+// conv_ws_kernel's store pattern with its in-order completion rule: before a tile's stores go out, all but the stores of the last DEPTH
+// tiles must have completed (the kernel waits for LDS-DMA pieces that are older than those stores: vmcnt retires in order)
+template <int DEPTH>
+__global__ __launch_bounds__(512) void ws_depth_k(unsigned char* __restrict__ d, int rows, int pitch) {
+  const int panels = pitch / 512, tiles = rows / 128;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (int t = blockIdx.x; t < tiles * panels; t += gridDim.x) {
+    const int panel = t % panels, tile = t / panels;
+    unsigned char* base = d + (size_t)tile * 128 * pitch + panel * 512 + wave * 64;
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * DEPTH > 63 ? 63 : 8 * DEPTH) : "memory");
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * i + (lane & 15)) * pitch + (lane >> 4) * 16) = v;
+  }
+}
 template <typename F> static double timeit(F f, int reps = 20) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) f();
@@ -69,6 +84,19 @@ int main() {
     printf("conv_ws store pattern (64 B x 16 rows per instruction), %4d workgroups: %7.1f us  %6.2f TB/s written\n", blocks, t * 1e6, bytes / t / 1e12);
     t = timeit([&] { hipLaunchKernelGGL(ws_rows_k, dim3(blocks), dim3(512), 0, 0, a, rows, pitch); });
     printf("whole 512-byte panel rows (2 rows per instruction),     %4d workgroups: %7.1f us  %6.2f TB/s written\n", blocks, t * 1e6, bytes / t / 1e12);
+  }
+  {
+    double t;
+    t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<0>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern, at most 0 earlier tiles' stores in flight when a tile's go out: %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<1>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern, at most 1 earlier tile's:  %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<2>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern, at most 2 earlier tiles': %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<4>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern, at most 4 earlier tiles': %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
+    t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<7>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
+    printf("conv_ws store pattern, at most 7 earlier tiles': %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
   }
   { double t = timeit([&] { hipMemsetAsync(a, 0, bytes, 0); }); printf("hipMemsetAsync: %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12); }
   return 0;

@@ -104,10 +104,10 @@ int main() {
           hipDeviceSynchronize();
           std::vector<unsigned long long> h(256 * 8 * 8);
           hipMemcpy(h.data(), dbg, h.size() * 8, hipMemcpyDeviceToHost);
-          static const char* nm[6] = {"stage wait (vmcnt)", "barrier", "LDS-DMA issue", "reads + MFMAs", "epilogue", "addend request"};
+          static const char* nm[7] = {"stage wait k=0", "barrier k=0", "LDS-DMA issue", "reads + MFMAs", "epilogue", "stage wait k>0", "barrier k>0"};
           printf("    %s %s: per steady-state tile, median over the waves of all workgroups (ticks of s_memtime = 100 MHz x ?):", s.name, ep_name[ep]);
           double tot = 0;
-          for (int q = 0; q < 6; ++q) {
+          for (int q = 0; q < 7; ++q) {
             std::vector<double> vals;
             for (int w = 0; w < 256 * 8; ++w) if (h[w * 8 + 7]) vals.push_back((double)h[w * 8 + q] / (double)h[w * 8 + 7]);
             std::sort(vals.begin(), vals.end());
