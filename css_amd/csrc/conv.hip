@@ -1704,12 +1704,18 @@ static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
 }
 
 // rows per statistics slab pair of a forward launch (see css_conv2d_forward_bnstats): 272 when the 272-row persistent tiling is used
-int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) {
+// ONE statement of which tiling a bf16 launch takes (css_launch_conv branches on it, css_conv2d_forward_bnstats_tile_rows reports it: the
+// statistics slabs bn_reduce_slabs_kernel reads are laid out by this number, so the two must not be able to drift apart)
+enum ConvPlan { PLAN_OTHER = 0, PLAN_WS = 1, PLAN_PP272 = 2, PLAN_TILE256 = 3 };
+static ConvPlan conv_plan(const ConvArgs& a, int dtype, int n_cu) {
   static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
-  if (dtype == CSS_BF16 && !no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) return 256;   // conv_ws.hip: 128-row slabs, as the 256-row tiles
-  if (dtype == CSS_BF16 && a.Cd >= 256 && !no_dma && !no_256 && css_conv_pp_plan(a, n_cu) == 272) return 272;
-  return 256;
+  if (dtype != CSS_BF16 || no_dma || no_256) return PLAN_OTHER;
+  if (css_conv_ws_supported(a, n_cu)) return PLAN_WS;                    // conv_ws.hip: 128-row slabs, as the 256-row tiles
+  if (a.Cd >= 256 && !a.add_mask && css_conv_pp_plan(a, n_cu) == 272) return PLAN_PP272;
+  if (a.Cd >= 256) return PLAN_TILE256;
+  return PLAN_OTHER;
 }
+int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) { return conv_plan(a, dtype, n_cu) == PLAN_PP272 ? 272 : 256; }
 
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   auto P0 = [&](bool big, double share, bool ws = false) { if (prof) prof->begin(big, share, ws); };
@@ -1730,13 +1736,14 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
   if (dtype == CSS_BF16) {
     if (a.Cs % 8 || a.lds % 8 || (reinterpret_cast<uintptr_t>(a.src) & 15) || (reinterpret_cast<uintptr_t>(a.wt) & 15))
       return CSS_ERR_ARG;
-    static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
-    if (!no_dma && !no_256 && css_conv_ws_supported(a, n_cu)) {
+    static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr;
+    const ConvPlan plan = conv_plan(a, dtype, n_cu);
+    if (plan == PLAN_WS) {
       // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
       P0(true, 1.0, true);
       css_launch_conv_ws(a, n_cu, st);
       P1();
-    } else if (a.Cd >= 256 && !no_dma && !no_256 && !a.add_mask && css_conv_pp_plan(a, n_cu) == 272) {
+    } else if (plan == PLAN_PP272) {
       // 272-row tiles of the persistent kernel cover every row in whole rounds of the chip: one launch
       ConvArgs b = a;
       b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
@@ -1744,7 +1751,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
       P0(true, 1.0);
       css_launch_conv_pp(b, 272, tiles < n_cu ? tiles : n_cu, st);
       P1();
-    } else if (a.Cd >= 256 && !no_dma && !no_256) {
+    } else if (plan == PLAN_TILE256) {
       // 256x256 tiles: whole rounds of the chip on the big kernel, leftover rows on the 128x128 kernel
       const int nt_n = cdiv(a.Cd, 256), mt = cdiv(a.M, 256);
       int full_mt = mt;

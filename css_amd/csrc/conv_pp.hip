@@ -516,7 +516,7 @@ int css_conv_pp_plan(const ConvArgs& a, int n_cu) {
   if (!css_conv_pp_supported(a) || (size_t)a.M * a.ldd * 2 >= 0x7FFFFFF0ull) return 0;
   // 272-row tiling: correct (tests/test_conv_bench_scale_gpu.py runs it) but measured SLOWER than 256-row tiles + leftover launch
   // (l3 3x3: 222 vs 210 us; the 272-row variant runs ~15 % slower per row), so it is opt-in: CSS_PP_272=1
-  const bool no272 = !(getenv("CSS_PP_272") && atoi(getenv("CSS_PP_272")) == 1);
+  static const bool no272 = !(getenv("CSS_PP_272") && atoi(getenv("CSS_PP_272")) == 1);
   const int nt_n = cdiv(a.Cd, 256);
   const long t256 = (long)cdiv(a.M, 256) * nt_n, t272 = (long)cdiv(a.M, 272) * nt_n;
   const double rounds = (double)t256 / n_cu;

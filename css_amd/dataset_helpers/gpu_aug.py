@@ -121,7 +121,9 @@ def _mix(tensors, mode, rng):
     if world > 1:
         import torch.distributed as dist
         if mode != "cutout":
-            partners = [t.clone() for t in tensors]
+            # (contiguous copies: RCCL's broadcast rejects strided tensors such as channels_last images.  ~117 MB per step at c2 on
+            # the default group - the reference's gathered law, VOC.py:396-399)
+            partners = [t.clone(memory_format=torch.contiguous_format) for t in tensors]
             for t in partners:
                 dist.broadcast(t, src=0)
         if mode == "classmix":               # one mask per gathered image, drawn from that image's label map (VOC.py:412,424)

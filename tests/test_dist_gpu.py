@@ -35,7 +35,9 @@ if os.environ.get("CSS_TEST_BF16"):
 g = torch.Generator().manual_seed(1)
 x = torch.randn(4, 3, S, S, generator=g)
 lab = torch.randint(0, K, (4, S, S), generator=g)
-if world > 1:
+if os.environ.get("CSS_TEST_SAME_DATA"):
+    x, lab = x[:2], lab[:2]                  # every rank (and the single process) holds the SAME two images: a deterministic comparison
+elif world > 1:
     x, lab = x[2 * rank: 2 * rank + 2], lab[2 * rank: 2 * rank + 2]
 pred, rep = net(x.to(dev))
 large = ops.bilinear(pred.permute(0, 2, 3, 1).contiguous(), S, S, torch.float32).permute(0, 3, 1, 2)
@@ -68,13 +70,15 @@ if world > 1:
 '''
 
 
-def _run(world, out, bf16=False):
+def _run(world, out, bf16=False, same=False):
     code = WORKER % ROOT
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
         if bf16:
             env["CSS_TEST_BF16"] = "1"
+        if same:
+            env["CSS_TEST_SAME_DATA"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
     for p in procs:
         assert p.wait(timeout=600) == 0
@@ -141,6 +145,36 @@ def test_two_ranks_bf16_fused_statistics_path(tmp_path):
     assert sum(cs) / len(cs) > 0.55, cs
     rm1, rm2 = torch.tensor(r1["rm"]), torch.tensor(r2["rm"])
     assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 2e-2
+
+
+def test_two_ranks_bf16_identical_halves_equal_one_rank(tmp_path):
+    """The tight gradient gate of the bf16 path (advisor, round 2): when both ranks hold the SAME two images, SyncBN's global statistics are
+    exactly the single process's (sums and counts double), every rank computes the same gradient and their mean is that gradient - so
+    world 2 must reproduce world 1 along the WHOLE backward chain up to the order of fp32 atomic adds, although the chain is chaotic
+    between different data (test above).  A wrong count, a missed all-reduce or a scaling error anywhere in SyncBN's forward or backward
+    shows here as a factor, not as noise."""
+    import json
+    import torch
+    a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
+    _run(1, a, bf16=True, same=True)
+    _run(2, b, bf16=True, same=True)
+    r1, r2 = json.load(open(a)), json.load(open(b))
+    assert abs(r1["loss"] - r2["loss"]) < 1e-5 * abs(r1["loss"])
+    p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"])
+    assert float((p1 - p2).abs().max()) <= 1e-3 * float(p1.abs().max())
+    g1, g2 = torch.tensor(r1["grad"]).double(), torch.tensor(r2["grad"]).double()
+    cos, rel = float(torch.nn.functional.cosine_similarity(g1, g2, dim=0)), float((g1 - g2).norm() / g1.norm())
+    print("bf16, identical halves: world1 vs world2 gradient cosine", cos, "rel-L2", rel)
+    assert cos > 0.9999 and rel < 1e-2
+    for name in r1["layers"]:
+        a_, b_ = torch.tensor(r1["layers"][name]).double(), torch.tensor(r2["layers"][name]).double()
+        if float(a_.norm()) == 0.0 and float(b_.norm()) == 0.0:
+            continue
+        c_, ratio = float(torch.nn.functional.cosine_similarity(a_, b_, dim=0)), float(b_.norm() / a_.norm())
+        print(f"  {name:50s} cosine {c_:.6f} norm ratio {ratio:.6f}")
+        assert c_ > 0.999 and 0.99 < ratio < 1.01, (name, c_, ratio)
+    rm1, rm2 = torch.tensor(r1["rm"]), torch.tensor(r2["rm"])
+    assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 1e-5
 
 
 TRAINER_WORKER = r'''

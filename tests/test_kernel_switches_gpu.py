@@ -113,3 +113,14 @@ def test_ce_gather_kernel_switch_is_a_shipped_configuration():
                        env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-600:], r.stderr[-400:])
     assert r.returncode == 0, r.stdout[-800:]
+
+
+def test_eager_residual_gradient_switch_is_a_shipped_configuration():
+    """CSS_BN_EAGER_DRES=1 (css_amd/ops.py: bn_bwd_apply writes the masked residual gradient itself instead of leaving the mask to the tapped
+    convolution's dgrad store): the block-level parity tests under that switch, in a process of its own."""
+    e = dict(os.environ)
+    e["CSS_BN_EAGER_DRES"] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_blocks_gpu.py"), "-q", "-x", "-m", "gpu"],
+                       env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    print(r.stdout[-600:], r.stderr[-400:])
+    assert r.returncode == 0, r.stdout[-800:]
