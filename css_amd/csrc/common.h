@@ -82,6 +82,12 @@ template <typename T> struct Vec16 {
 // Pair view of a Vec16: the elementwise kernels do their arithmetic on float2 (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two
 // elements per instruction - same rounding as the scalar forms) and convert two elements per v_cvt_pk_bf16_f32.
 typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two floats -> two bf16 in one 32-bit word (element 0 in the low half) with ONE v_cvt_pk_bf16_f32: written as two scalar conversions the
+// compiler emits two of them plus a shift and an or (r03: 135 instead of 32 instructions in conv_ws_kernel's epilogue); same rounding
+typedef __attribute__((ext_vector_type(2))) bf16_t bf16x2_pk;
+__device__ __forceinline__ unsigned pack2_bf16(float lo, float hi) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_pk));
+}
 template <typename T> struct Pairs;
 template <> struct Pairs<float> {
   static constexpr int NP = 2;
@@ -93,7 +99,7 @@ template <> struct Pairs<bf16_t> {
   static __device__ __forceinline__ f32x2 get(const Vec16<bf16_t>& v, int p) {
     return f32x2{__builtin_bit_cast(float, v.w[p] << 16), __builtin_bit_cast(float, v.w[p] & 0xffff0000u)};
   }
-  static __device__ __forceinline__ void set(Vec16<bf16_t>& v, int p, f32x2 x) { v.e[2 * p] = (bf16_t)x[0]; v.e[2 * p + 1] = (bf16_t)x[1]; }
+  static __device__ __forceinline__ void set(Vec16<bf16_t>& v, int p, f32x2 x) { v.w[p] = pack2_bf16(x[0], x[1]); }
 };
 // x where bit `b` of bits is set, else +0 (bit test without a compare: a signed 1-bit field extract gives 0 / ~0)
 __device__ __forceinline__ float keep_if_bit(float x, unsigned bits, int b) {

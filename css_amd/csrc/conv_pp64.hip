@@ -37,12 +37,7 @@ __device__ __forceinline__ float p6_row16_sum(float v) {
 __device__ __forceinline__ void p6_swap16(unsigned& a, unsigned& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ unsigned p6_pack2(float lo, float hi) {
-  union { bf16_t h[2]; unsigned u; } t;
-  t.h[0] = (bf16_t)lo;
-  t.h[1] = (bf16_t)hi;
-  return t.u;
-}
+__device__ __forceinline__ unsigned p6_pack2(float lo, float hi) { return pack2_bf16(lo, hi); }
 __device__ __forceinline__ float p6_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float p6_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace

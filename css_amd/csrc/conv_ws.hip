@@ -53,12 +53,7 @@ __device__ __forceinline__ float ws_row16_sum(float v) {
 __device__ __forceinline__ void ws_swap16(unsigned& a, unsigned& b) {
   asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
 }
-__device__ __forceinline__ unsigned ws_pack2(float lo, float hi) {
-  union { bf16_t h[2]; unsigned u; } t;
-  t.h[0] = (bf16_t)lo;
-  t.h[1] = (bf16_t)hi;
-  return t.u;
-}
+__device__ __forceinline__ unsigned ws_pack2(float lo, float hi) { return pack2_bf16(lo, hi); }
 __device__ __forceinline__ float ws_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ __forceinline__ float ws_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 template <int N> __device__ __forceinline__ void ws_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
