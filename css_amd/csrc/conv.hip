@@ -772,8 +772,13 @@ __global__ __launch_bounds__(64 * NWM * NWN * NWK) void conv_igemm_dma_kernel(co
       for (int j = 0; j < TM; ++j) {
         T* p = Cw + (j * 32 + l31) * CSTR + nl;
         union { T e[4]; uint2 u2; } pk;
+        if constexpr (sizeof(T) == 2) {          // (one v_cvt_pk_bf16_f32 per pair: common.h, pack2_bf16)
+          pk.u2.x = pack2_bf16(acc[i][j][4 * q] + bv[0], acc[i][j][4 * q + 1] + bv[1]);
+          pk.u2.y = pack2_bf16(acc[i][j][4 * q + 2] + bv[2], acc[i][j][4 * q + 3] + bv[3]);
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) pk.e[e] = (T)(acc[i][j][4 * q + e] + bv[e]);
+          for (int e = 0; e < 4; ++e) pk.e[e] = (T)(acc[i][j][4 * q + e] + bv[e]);
+        }
         *reinterpret_cast<uint2*>(p) = pk.u2;
       }
     }
