@@ -58,6 +58,22 @@ __global__ __launch_bounds__(512) void ws_depth_k(unsigned char* __restrict__ d,
     for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * i + (lane & 15)) * pitch + (lane >> 4) * 16) = v;
   }
 }
+// conv_ws_kernel's store pattern AND its workgroup -> (panel, pixel-tile stream) map: the panels of a pixel tile on CUs of ONE XCD
+// (blockIdx & 7 = XCD), each workgroup walking its stream of tiles
+__global__ __launch_bounds__(512) void ws_map_k(unsigned char* __restrict__ d, int rows, int pitch, int same_xcd) {
+  const int np = pitch / 512, tiles = rows / 128;
+  const int G = gridDim.x, c8 = G >> 3, xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3, spx = c8 / np;
+  int panel, stream, nstreams;
+  if (same_xcd) { panel = idx8 % np; stream = xcd * spx + idx8 / np; nstreams = 8 * spx; }
+  else { const int lin = xcd * c8 + idx8; panel = lin % np; stream = lin / np; nstreams = G / np; }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const u32x4 v = {1u, 2u, 3u, 4u};
+  for (int tile = stream; tile < tiles; tile += nstreams) {
+    unsigned char* base = d + (size_t)tile * 128 * pitch + panel * 512 + wave * 64;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *(u32x4*)(base + (size_t)(16 * i + (lane & 15)) * pitch + (lane >> 4) * 16) = v;
+  }
+}
 template <typename F> static double timeit(F f, int reps = 20) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int i = 0; i < 3; ++i) f();
@@ -97,6 +113,14 @@ int main() {
     printf("conv_ws store pattern, at most 4 earlier tiles': %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
     t = timeit([&] { hipLaunchKernelGGL(ws_depth_k<7>, dim3(256), dim3(512), 0, 0, a, rows, pitch); });
     printf("conv_ws store pattern, at most 7 earlier tiles': %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12);
+  }
+  for (int pitch2 : {512, 1024, 2048, 4096}) {
+    const int rows2 = (int)(bytes / pitch2) / 128 * 128;
+    for (int same = 1; same >= 0; --same) {
+      double t = timeit([&] { hipLaunchKernelGGL(ws_map_k, dim3(256), dim3(512), 0, 0, a, rows2, pitch2, same); });
+      printf("conv_ws store pattern with conv_ws's workgroup map, row pitch %4d B (%d panels), panels of a tile on %s: %7.1f us  %6.2f TB/s\n", pitch2, pitch2 / 512,
+             same ? "ONE XCD       " : "different XCDs", t * 1e6, (double)rows2 * pitch2 / t / 1e12);
+    }
   }
   { double t = timeit([&] { hipMemsetAsync(a, 0, bytes, 0); }); printf("hipMemsetAsync: %7.1f us  %6.2f TB/s\n", t * 1e6, bytes / t / 1e12); }
   return 0;
