@@ -273,7 +273,8 @@ def rooflines(prof, dtype, workload):
             "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src, "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
             "alg_flops_per_launch": ig_fl / max(ig_n, 1)}
-    mfma_groups = {"conv_igemm_pp_kernels": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_dma256_kernel": prof["wgrad256"],
+    # (keys name the kernels that run today: the big-tile class = conv_igemm_p8_kernel + conv_ws_kernel launches, forward and dgrad)
+    mfma_groups = {"conv_igemm_p8_and_ws_kernels": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_p8_kernel": prof["wgrad256"],
                    "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
                    "conv_wgrad_all_kernels": tot("conv_wgrad_other", "wgrad256")}
     hbm_groups = {k: prof[k] for k in ("bn_apply", "bn_bwd_apply", "bn_bwd_reduce", "sgd_ema", "conv1x1_short_k_fwd", "contrast_gather", "similarity")}
