@@ -367,9 +367,10 @@ int css_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int 
   set_dev(device);
   return css_launch_copy_channels(src, lds, dst, ldd, M, C, dtype_in, dtype_out, S(stream));
 }
-int css_colsum(const void* x, int ld, long M, int C, float* out, int dtype, int device, css_stream_t stream) {
+size_t css_colsum_ws_bytes(long M, int C) { return css_colsum_ws_bytes_(M, C); }
+int css_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, int device, css_stream_t stream) {
   set_dev(device);
-  return css_launch_colsum(x, ld, M, C, out, dtype, S(stream));
+  return css_launch_colsum(x, ld, M, C, out, ws, dtype, S(stream));
 }
 int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream) {
   set_dev(device);
@@ -380,10 +381,10 @@ int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int 
   return css_launch_cast(x, out, n, dtype_in, dtype_out, S(stream));
 }
 int css_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
-                float grad_scale, int device, css_stream_t stream) {
+                float grad_scale, const float* skip_flag, int device, css_stream_t stream) {
   set_dev(device);
   ProfScope ps(11, (double)n * 28.0, S(stream));     // p, g, momentum, ema read + p, momentum, ema written: 7 x 4 bytes per element
-  return css_launch_sgd_ema(p, g, buf, ema, n, lr, momentum, wd, first, decay, grad_scale, S(stream));
+  return css_launch_sgd_ema(p, g, buf, ema, n, lr, momentum, wd, first, decay, grad_scale, skip_flag, S(stream));
 }
 int css_ema(float* ema, const float* p, long n, float decay, int device, css_stream_t stream) {
   set_dev(device);
@@ -443,11 +444,11 @@ int css_class_map(const int64_t* l_lab, const int64_t* u_lab, const float* u_log
 
 // ---- cross entropy ----
 int css_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
-               double* stats, float* gtprob_out, int device, css_stream_t stream) {
+               int64_t* stats, float* gtprob_out, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_ce_fwd(logits, label, conf, conf_thr, keep_thr, K, P, HW, stats, gtprob_out, S(stream));
 }
-int css_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream) {
+int css_ce_finalize(const int64_t* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_ce_finalize(stats, B, mode, loss, coef, S(stream));
 }
@@ -457,7 +458,7 @@ int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr,
   return css_launch_ce_bwd(logits, label, keep_thr, K, P, HW, coef, gscale, pos_only, dlogits, S(stream));
 }
 int css_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr,
-                     int K, int H, int W, double* stats, float* gtprob_out, int dtype, int device, css_stream_t stream) {
+                     int K, int H, int W, int64_t* stats, float* gtprob_out, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_ce_small_fwd(small, ld, B, h, w, label, conf, conf_thr, keep_thr, K, H, W, stats, gtprob_out, dtype, S(stream));
 }
@@ -468,7 +469,7 @@ int css_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64
 }
 size_t css_ohem_state_bytes(void) { return css_ohem_state_bytes_(); }
 size_t css_ohem_thr_offset(void) { return css_ohem_thr_offset_(); }
-int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,
+int css_ohem_threshold(const float* gtprob, long P, const int64_t* stats, int B, int min_kept, float thresh, void* state, int device,
                        css_stream_t stream) {
   set_dev(device);
   return css_launch_ohem_threshold(gtprob, P, stats, B, min_kept, thresh, state, S(stream));
@@ -482,9 +483,11 @@ int css_contrast_classify(const float* label, const float* mask, const float* pr
   set_dev(device);
   return css_launch_contrast_classify(label, mask, prob, sb, sk, sp, psb, psk, psp, P, HW, K, strong_thr, cls, hard, meta, S(stream));
 }
-int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, int device, css_stream_t stream) {
+size_t css_contrast_class_sums_ws_bytes(int P, int K, int C) { return css_contrast_class_sums_ws_bytes_(P, K, C); }
+int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, float* ws, int dtype, int device,
+                            css_stream_t stream) {
   set_dev(device);
-  return css_launch_contrast_class_sums(rep, ld, cls, P, K, C, out, dtype, S(stream));
+  return css_launch_contrast_class_sums(rep, ld, cls, P, K, C, out, ws, dtype, S(stream));
 }
 int css_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta, int device,
                          css_stream_t stream) {

@@ -69,7 +69,7 @@ __device__ __forceinline__ void channel_reduce2(F f, int Mg, int C, int rows_per
 // sums[g][j] = sum over the partial rows of group g, j in [0, 2C), in fp64.  These kernels are pure latency (a few MB read
 // by C/8 blocks), so: 1024 threads = 8 channels x 128 row partitions, the partitions dealt over as many groups as divide
 // 128 (all groups of a launch run concurrently), 8 independent loads in flight per thread, tree reduction in LDS.
-// rows(g, lo, hi, extra): partial rows [lo, hi) plus row `extra` (or -1) belong to group g.  emit(g, t0, t1, c) is called
+// rows(g, lo, hi): partial rows [lo, hi) belong to group g.  emit(g, t0, t1, c) is called
 // by ONE thread per channel, for g = 0..G-1 in order (the running statistics take their G momentum updates in order).
 #ifndef S2_CH_V
 #define S2_CH_V 8
@@ -100,8 +100,8 @@ __device__ __forceinline__ void stage2_reduce(const PT* __restrict__ partial, in
   const int gslot = part / P, pl = part % P;
   for (int g0 = 0; g0 < G; g0 += GP) {
     const int g = g0 + gslot;
-    int lo, hi, extra;
-    rows(g, lo, hi, extra);
+    int lo, hi;
+    rows(g, lo, hi);
     double a0[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
     // first S2_U rows of this thread: every request goes out before the first use (rows past `hi` re-read row `lo` and count as zero)
     PT v0[S2_U], v1[S2_U];
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_kernel(const double* __restric
   float old0 = 0.f, old1 = 0.f;
   if (accumulate && g0 && threadIdx.x < S2_CH && ce < C) { old0 = g0[ce]; old1 = g1[ce]; }      // (before the reduction: see stage2_reduce)
   stage2_reduce(
-      partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
+      partial, C, G, [&](int g, int& lo, int& hi) { lo = g * nrb; hi = lo + nrb; },
       [&](int g, double a0, double a1, int c) {
         if (sums) { sums[(size_t)g * 2 * C + c] = a0; sums[(size_t)g * 2 * C + C + c] = a1; }
         t0 += a0; t1 += a1;
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
     if (running_mean) { rm = running_mean[ce]; rv = running_var[ce]; }
   }
   stage2_reduce(
-      partial, C, G, [&](int g, int& lo, int& hi, int& extra) { lo = g * nrb; hi = lo + nrb; extra = -1; },
+      partial, C, G, [&](int g, int& lo, int& hi) { lo = g * nrb; hi = lo + nrb; },
       [&](int g, double a0, double a1, int c) {
         bn_finalize_reg(a0, a1, count, gam, bet, rm, rv, running_mean, running_var, momentum, eps, mean_out + g * C, invstd_out + g * C,
                         scale_out + g * C, shift_out + g * C, c);
@@ -266,12 +266,11 @@ __global__ __launch_bounds__(1024) void bn_reduce_slabs_kernel(const float* __re
   }
   stage2_reduce(
       partial, C, G,
-      [&](int g, int& lo, int& hi, int& extra) {
+      [&](int g, int& lo, int& hi) {
         const int b = g * Mg, e = b + Mg;
         lo = first_slab_from(b, BM);
         hi = first_slab_from(e, BM);
         if (hi > nslab) hi = nslab;
-        extra = -1;
       },
       [&](int g, double a0, double a1, int c) {
         if (sums_out) {

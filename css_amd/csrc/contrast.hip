@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void contrast_classify_kernel(const float* __r
 // out: double [K][C] sums followed by double [K] counts
 template <typename T, int C>
 __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __restrict__ rep, int ld, const int* __restrict__ cls, int P, int K,
-                                                                  int pix_per_block, double* __restrict__ out) {
+                                                                  int pix_per_block, float* __restrict__ out) {
   // every wave owns a private [K][C] fp32 accumulator in LDS and a lane owns 4 channels of it: plain 16-byte
   // read-modify-write, no atomics (LDS float atomics made this kernel 0.63 ms; a wave's LDS operations execute in order, so
   // consecutive rows of the same class are safe)
@@ -98,15 +98,28 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
     }
   }
   __syncthreads();
-  for (int i = tid; i < K * C; i += 256) {
-    const float t = (cs_lds[i] + cs_lds[(size_t)K * C + i]) + (cs_lds[(size_t)2 * K * C + i] + cs_lds[(size_t)3 * K * C + i]);
-    if (t != 0.f) atomicAdd(&out[i], (double)t);
-  }
+  // the workgroup's partial sums -> its own row of the workspace (plain stores; contrast_class_sums_reduce_kernel adds the rows up in
+  // workgroup order: fp64 atomics would add in arrival order, and the prototypes - hence the sampled negatives - would not be reproducible)
+  float* row = out + (size_t)blockIdx.x * (K * C + K);
+  for (int i = tid; i < K * C; i += 256)
+    row[i] = (cs_lds[i] + cs_lds[(size_t)K * C + i]) + (cs_lds[(size_t)2 * K * C + i] + cs_lds[(size_t)3 * K * C + i]);
   if (tid < K) {
     const float* cb = cs_lds + (size_t)4 * K * C;
-    const float t = (cb[tid] + cb[CT_MAXK + tid]) + (cb[2 * CT_MAXK + tid] + cb[3 * CT_MAXK + tid]);
-    if (t != 0.f) atomicAdd(&out[(size_t)K * C + tid], (double)t);
+    row[(size_t)K * C + tid] = (cb[tid] + cb[CT_MAXK + tid]) + (cb[2 * CT_MAXK + tid] + cb[3 * CT_MAXK + tid]);
   }
+}
+// out[i] = sum over the workgroups' rows, in row order, in fp64 (four independent chains for latency, combined in a fixed tree)
+__global__ __launch_bounds__(256) void contrast_class_sums_reduce_kernel(const float* __restrict__ ws, int nrows, int n, double* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  int r = 0;
+  for (; r + 3 < nrows; r += 4) {
+    s0 += (double)ws[(size_t)(r + 0) * n + i]; s1 += (double)ws[(size_t)(r + 1) * n + i];
+    s2 += (double)ws[(size_t)(r + 2) * n + i]; s3 += (double)ws[(size_t)(r + 3) * n + i];
+  }
+  for (; r < nrows; ++r) s0 += (double)ws[(size_t)r * n + i];
+  out[i] = (s0 + s1) + (s2 + s3);
 }
 
 // ---- 3. stable compaction ----------------------------------------------------------------------
@@ -460,15 +473,18 @@ int css_launch_contrast_classify(const float* label, const float* mask, const fl
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, hipStream_t st) {
-  if (K > CT_MAXK || C != 256) return CSS_ERR_ARG;
-  const int ppb = 2048;
+constexpr int CT_SUMS_PPB = 2048;     // pixels per workgroup of contrast_class_sums_kernel
+size_t css_contrast_class_sums_ws_bytes_(int P, int K, int C) { return (size_t)cdiv(P > 0 ? P : 1, CT_SUMS_PPB) * ((size_t)K * C + K) * sizeof(float); }
+int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, float* ws, int dtype, hipStream_t st) {
+  if (K > CT_MAXK || C != 256 || !ws || P <= 0) return CSS_ERR_ARG;
+  const int ppb = CT_SUMS_PPB, nb = cdiv(P, ppb);
   const size_t lds = ((size_t)4 * K * C + 4 * CT_MAXK) * sizeof(float);     // 86 KiB at K = 21: one workgroup per CU
   if (dtype == CSS_BF16)
-    hipLaunchKernelGGL((contrast_class_sums_kernel<bf16_t, 256>), dim3(cdiv(P, ppb)), dim3(256), lds, st, (const bf16_t*)rep, ld, cls, P, K, ppb, out);
+    hipLaunchKernelGGL((contrast_class_sums_kernel<bf16_t, 256>), dim3(nb), dim3(256), lds, st, (const bf16_t*)rep, ld, cls, P, K, ppb, ws);
   else if (dtype == CSS_F32)
-    hipLaunchKernelGGL((contrast_class_sums_kernel<float, 256>), dim3(cdiv(P, ppb)), dim3(256), lds, st, (const float*)rep, ld, cls, P, K, ppb, out);
+    hipLaunchKernelGGL((contrast_class_sums_kernel<float, 256>), dim3(nb), dim3(256), lds, st, (const float*)rep, ld, cls, P, K, ppb, ws);
   else return CSS_ERR_DTYPE;
+  hipLaunchKernelGGL(contrast_class_sums_reduce_kernel, dim3(cdiv(K * C + K, 256)), dim3(256), 0, st, ws, nb, K * C + K, out);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

@@ -1193,6 +1193,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
   }
   // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
   const int l31 = lane & 31, lh = lane >> 5;
+  if (a.ws) {
+    // partial tile of this pixel slice -> its own BN_ x BKC fp32 slab of the workspace with plain stores; wgrad_slab_reduce_gen_kernel adds
+    // the slices in slice order (the weight gradient is bit-reproducible; the atomics below add in arrival order)
+    float* slab = a.ws + ((size_t)t * a.splits + zz) * (BN_ * BKC);
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+      for (int j = 0; j < TK; ++j) {
+        const int kl = wk * WTK + j * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          slab[nl * BKC + kl] = acc[i][j][r];
+        }
+      }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -1682,6 +1699,39 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
     if (k + e < Ktot) o[e] += r[e];
 }
 
+// The same for the BN x BKC tiles of conv_wgrad_kernel (128 x 128 bf16, 64 x 64 fp32): grid = (BN / 4, tiles), thread = 4 consecutive
+// k columns of one row (BKC / 4 threads per row, 1024 / BKC rows per block), slices in order.
+template <int BN_, int BKC>
+__global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
+                                                                    int Cd, int Ktot) {
+  constexpr int TPR = BKC / 4, RPB = 256 / TPR;            // threads per tile row, rows per block
+  const int t = blockIdx.y;
+  const int k0 = (t % tiles_k) * BKC, n0 = (t / tiles_k) * BN_;
+  const int nl = blockIdx.x * RPB + threadIdx.x / TPR, kl = (threadIdx.x % TPR) * 4;
+  const int n = n0 + nl, k = k0 + kl;
+  if (nl >= BN_ || n >= Cd || k >= Ktot) return;
+  const float4* p = reinterpret_cast<const float4*>(ws + (size_t)t * splits * (BN_ * BKC) + nl * BKC + kl);
+  constexpr size_t SL = (size_t)BN_ * BKC / 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  int z = 0;
+  for (; z + 3 < splits; z += 4) {
+    const float4 v0 = p[(size_t)(z + 0) * SL], v1 = p[(size_t)(z + 1) * SL], v2 = p[(size_t)(z + 2) * SL], v3 = p[(size_t)(z + 3) * SL];
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+    s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
+    s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
+  }
+  for (; z < splits; ++z) {
+    const float4 v0 = p[(size_t)z * SL];
+    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+  }
+  const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
+  float* o = dw + (size_t)n * Ktot + k;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    if (k + e < Ktot) o[e] += r[e];
+}
+
 // --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
@@ -1871,10 +1921,12 @@ void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_o
 // shape takes a kernel that has no such path)
 size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
   static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr, no_ws = getenv("CSS_WGRAD_ATOMICS") != nullptr;
-  if (!(dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256) || no_ws || M <= 0) return 0;
+  if (no_ws || M <= 0 || (dtype != CSS_BF16 && dtype != CSS_F32)) return 0;
   int splits, mps;
   css_wgrad_plan_(M, Ktot, Cd, dtype, n_cu, &splits, &mps);
-  return (size_t)cdiv(Ktot, 256) * cdiv(Cd, 256) * splits * (256 * 256 * sizeof(float));
+  const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
+  const int bn = big ? 256 : (dtype == CSS_BF16 ? 128 : 64);        // (square tiles: css_launch_wgrad)
+  return (size_t)cdiv(Ktot, bn) * cdiv(Cd, bn) * splits * ((size_t)bn * bn * sizeof(float));
 }
 
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
@@ -1909,7 +1961,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.tiles_n = cdiv(a.Cd, bn);
   dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
   if (prof) prof->begin(big, 1.0, false);
-  if (!big || (size_t)a.tiles_k * a.tiles_n * a.splits * (256 * 256 * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path
+  if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
   if (big) {
     // CSS_WGRAD_KERNEL: 0 = conv_wgrad_dma256_kernel (both cout halves in lockstep), 1 = the same with the second half one half-step
     // behind, 2 (default) = conv_wgrad_p8_kernel (two-phase steps)
@@ -1919,10 +1971,17 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
     else hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
-  } else if (dtype == CSS_BF16)
+  } else if (dtype == CSS_BF16) {
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
-  else
+    if (a.ws)
+      hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<128, 128>), dim3(128 / 8, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
+                         a.tiles_k, a.Cd, a.Ktot);
+  } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);
+    if (a.ws)
+      hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<64, 64>), dim3(64 / 16, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
+                         a.tiles_k, a.Cd, a.Ktot);
+  }
   if (prof) prof->end();
   CSS_CHECK_LAUNCH();
   return CSS_OK;

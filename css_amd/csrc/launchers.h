@@ -105,18 +105,19 @@ int css_launch_bilinear(const void* x, int ldx, void* out, int ldo, int N, int H
 int css_launch_spatial_sum(const void* x, int ldx, void* out, int N, int HW, int C, float scale, int dtype, hipStream_t st);
 int css_launch_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, hipStream_t st);
 int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out, hipStream_t st);
-int css_launch_colsum(const void* x, int ld, long M, int C, float* out, int dtype, hipStream_t st);
+size_t css_colsum_ws_bytes_(long M, int C);
+int css_launch_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, hipStream_t st);
 int css_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, hipStream_t st);
 int css_launch_weight_layout(const float* w, void* out, int Cout, int taps, int Cin, int CinPad, int dgrad, int dtype, hipStream_t st);
 int css_launch_weight_dgrad_layout_batched(const float* flat, void* out, const long* desc, int n_layers, long total_tiles, int dtype,
                                            hipStream_t st);
 int css_launch_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, hipStream_t st);
 int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
-                       float grad_scale, hipStream_t st);
+                       float grad_scale, const float* skip_flag, hipStream_t st);
 int css_launch_ema(float* ema, const float* p, long n, float decay, hipStream_t st);
 
 int css_launch_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
-                            const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, hipStream_t st);
+                            const float* keep_thr, int K, int H, int W, int64_t* stats, float* gtprob_out, int dtype, hipStream_t st);
 int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
                             const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, hipStream_t st);
 int css_launch_aug_geom(const float* img, const float* label, const float* l1, const float* l2, const int* params, int* table, int maxlen, int B,
@@ -139,19 +140,20 @@ int css_launch_class_map(const int64_t* l_lab, const int64_t* u_lab, const float
                          int* cls, hipStream_t st);
 
 int css_launch_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
-                      double* stats, float* gtprob_out, hipStream_t st);
-int css_launch_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, hipStream_t st);
+                      int64_t* stats, float* gtprob_out, hipStream_t st);
+int css_launch_ce_finalize(const int64_t* stats, int B, int mode, float* loss, float* coef, hipStream_t st);
 int css_launch_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef,
                       const float* gscale, int pos_only, float* dlogits, hipStream_t st);
 size_t css_ohem_state_bytes_();
 size_t css_ohem_thr_offset_();
-int css_launch_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, hipStream_t st);
+int css_launch_ohem_threshold(const float* gtprob, long P, const int64_t* stats, int B, int min_kept, float thresh, void* state, hipStream_t st);
 
 size_t css_contrast_meta_bytes_();
 int css_contrast_nchunks_(int P);
 int css_launch_contrast_classify(const float* label, const float* mask, const float* prob, long sb, long sk, long sp, long psb, long psk, long psp,
                                  int P, int HW, int K, float strong_thr, int* cls, uint8_t* hard, void* meta, hipStream_t st);
-int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, hipStream_t st);
+size_t css_contrast_class_sums_ws_bytes_(int P, int K, int C);
+int css_launch_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, float* ws, int dtype, hipStream_t st);
 int css_launch_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta,
                                 hipStream_t st);
 int css_launch_contrast_proto_update(float* proto, const double* sums, int K, int C, float alpha, const void* meta, hipStream_t st);

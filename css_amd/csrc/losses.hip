@@ -9,23 +9,30 @@
 #include "common.h"
 
 constexpr int CE_MAXK = 32;
-// per-image accumulators: S = sum of losses, NPOS = #(loss > 0), NVALID = #(counted pixels), NCONF = #(conf >= thr)
+// per-image accumulators: S = sum of losses, NPOS = #(loss > 0), NVALID = #(counted pixels), NCONF = #(conf >= thr).
+// All four are 64-bit INTEGERS (the counts as they are, S in units of 2^-32): integer adds commute, so the workgroups' atomics give the same
+// bits whatever order they arrive in - the loss statistics (and through `coef` every gradient of the step) are run-to-run reproducible.
+// A partial sum is converted once per wave (tile kernel) or per pixel (ce_kernel): |error| <= 2^-32 per conversion, ~1e-10 of a loss of 1.
 enum { ST_S = 0, ST_NPOS = 1, ST_NVALID = 2, ST_NCONF = 3 };
+constexpr float CE_FIX = 4294967296.f;               // 2^32
+constexpr double CE_UNFIX = 1.0 / 4294967296.0;
+typedef unsigned long long ce_acc_t;                  // (two's complement: losses are >= 0 up to rounding, negative partials wrap correctly)
+__device__ __forceinline__ ce_acc_t ce_fix(float v) { return (ce_acc_t)(long long)(v * CE_FIX); }
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ label,
                                                  const float* __restrict__ conf, float conf_thr, const float* __restrict__ keep_thr,
-                                                 int K, size_t P, int HW, double* __restrict__ stats, float* __restrict__ gtprob_out,
+                                                 int K, size_t P, int HW, ce_acc_t* __restrict__ stats, float* __restrict__ gtprob_out,
                                                  const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
                                                  float* __restrict__ dlogits) {
   __shared__ float tile[256 * CE_MAXK];
-  __shared__ float sacc[2][4];
+  __shared__ ce_acc_t sacc[2][4];
   const int tid = threadIdx.x;
   const int KS = K | 1;  // odd LDS stride -> conflict-free per-pixel walks
   for (size_t p0 = (size_t)blockIdx.x * 256; p0 < P; p0 += (size_t)gridDim.x * 256) {
     const int np = (int)min((size_t)256, P - p0);
     __syncthreads();
-    if (tid < 8) sacc[tid >> 2][tid & 3] = 0.f;
+    if (tid < 8) sacc[tid >> 2][tid & 3] = 0;
     const float* src = logits + p0 * K;
     for (int i = tid; i < np * K; i += 256) {
       const int pp = i / K, k = i - pp * K;
@@ -55,11 +62,11 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
         if (stats) {
           const int s = b - b_first;
           if (valid) {
-            atomicAdd(&sacc[s][ST_S], loss);
-            atomicAdd(&sacc[s][ST_NVALID], 1.f);
-            if (loss > 0.f) atomicAdd(&sacc[s][ST_NPOS], 1.f);
+            atomicAdd(&sacc[s][ST_S], ce_fix(loss));
+            atomicAdd(&sacc[s][ST_NVALID], (ce_acc_t)1);
+            if (loss > 0.f) atomicAdd(&sacc[s][ST_NPOS], (ce_acc_t)1);
           }
-          if (conf && conf[p] >= conf_thr) atomicAdd(&sacc[s][ST_NCONF], 1.f);
+          if (conf && conf[p] >= conf_thr) atomicAdd(&sacc[s][ST_NCONF], (ce_acc_t)1);
         }
       } else {
         float c = 0.f;
@@ -76,7 +83,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     if (!BWD) {
       if (stats && tid < 8) {
         const int s = tid >> 2, b = b_first + s;
-        if (sacc[s][tid & 3] != 0.f) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], (double)sacc[s][tid & 3]);
+        if (sacc[s][tid & 3] != 0) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], sacc[s][tid & 3]);
       }
     } else {
       float* dst = dlogits + p0 * K;
@@ -89,13 +96,15 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 }
 
 // mode 0: mean CE over counted pixels.  mode 1: Attention_Threshold_Loss weighting (loss.py:56,60).
-__global__ void ce_finalize_kernel(const double* __restrict__ stats, int B, int mode, float* __restrict__ loss, float* __restrict__ coef) {
+__global__ void ce_finalize_kernel(const ce_acc_t* __restrict__ acc, int B, int mode, float* __restrict__ loss, float* __restrict__ coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  // (the fixed-point / integer accumulators as doubles: exact for every count and for sums below 2^21)
+  auto stat = [&](int i) { return (i & 3) == ST_S ? (double)(long long)acc[i] * CE_UNFIX : (double)acc[i]; };
   double S = 0, NV = 0, NP = 0, WS = 0;
   for (int b = 0; b < B; ++b) {
-    S += stats[b * 4 + ST_S];
-    NV += stats[b * 4 + ST_NVALID];
-    NP += stats[b * 4 + ST_NPOS];
+    S += stat(b * 4 + ST_S);
+    NV += stat(b * 4 + ST_NVALID);
+    NP += stat(b * 4 + ST_NPOS);
   }
   if (mode == 0) {
     *loss = (float)(S / NV);
@@ -103,9 +112,9 @@ __global__ void ce_finalize_kernel(const double* __restrict__ stats, int B, int 
   } else {
     for (int b = 0; b < B; ++b) {
       // weighting = #(logits >= thr) / #(label >= 0): fp32 division like the reference (int64 / float32)
-      const float wgt = (float)stats[b * 4 + ST_NCONF] / (float)stats[b * 4 + ST_NVALID];
-      if (stats[b * 4 + ST_NPOS] > 0) WS += (double)wgt * stats[b * 4 + ST_S];
-      coef[b] = stats[b * 4 + ST_NPOS] > 0 ? (float)((double)wgt / NP) : 0.f;
+      const float wgt = (float)stat(b * 4 + ST_NCONF) / (float)stat(b * 4 + ST_NVALID);
+      if (stat(b * 4 + ST_NPOS) > 0) WS += (double)wgt * stat(b * 4 + ST_S);
+      coef[b] = stat(b * 4 + ST_NPOS) > 0 ? (float)((double)wgt / NP) : 0.f;
     }
     *loss = (float)(WS / NP);  // NP == 0 -> NaN like torch.mean of an empty selection
   }
@@ -119,12 +128,12 @@ struct OhemState {
   float thr;             // result: keep pixels with gtprob <= thr
   unsigned active;       // 0: min_kept > num_valid -> plain CE (loss.py:28-29)
 };
-__global__ void ohem_init_kernel(OhemState* s, const double* __restrict__ stats, int B, long P, int min_kept) {
+__global__ void ohem_init_kernel(OhemState* s, const ce_acc_t* __restrict__ stats, int B, long P, int min_kept) {
   if (threadIdx.x >= 256) return;
   s->hist[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     double nv = 0;
-    for (int b = 0; b < B; ++b) nv += stats[b * 4 + ST_NVALID];
+    for (int b = 0; b < B; ++b) nv += (double)stats[b * 4 + ST_NVALID];
     s->prefix = 0;
     long k = (long)min((long)P, (long)min_kept) - 1;
     s->k = (unsigned)(k < 0 ? 0 : k);
@@ -190,13 +199,13 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
                                                            const int64_t* __restrict__ label, const float* __restrict__ conf, float conf_thr,
                                                            const float* __restrict__ keep_thr, int K, size_t P, int H, int W,
-                                                           double* __restrict__ stats, float* __restrict__ gtprob_out) {
-  __shared__ float sacc[2][4];
+                                                           ce_acc_t* __restrict__ stats, float* __restrict__ gtprob_out) {
+  __shared__ ce_acc_t sacc[2][4];
   const int tid = threadIdx.x;
   const int HW = H * W;
   for (size_t p0 = (size_t)blockIdx.x * 256; p0 < P; p0 += (size_t)gridDim.x * 256) {
     __syncthreads();
-    if (tid < 8) sacc[tid >> 2][tid & 3] = 0.f;
+    if (tid < 8) sacc[tid >> 2][tid & 3] = 0;
     __syncthreads();
     const int b_first = (int)(p0 / HW);
     const size_t p = p0 + tid;
@@ -224,17 +233,17 @@ __global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__
       if (stats) {
         const int s = b - b_first;
         if (valid) {
-          atomicAdd(&sacc[s][ST_S], loss);
-          atomicAdd(&sacc[s][ST_NVALID], 1.f);
-          if (loss > 0.f) atomicAdd(&sacc[s][ST_NPOS], 1.f);
+          atomicAdd(&sacc[s][ST_S], ce_fix(loss));
+          atomicAdd(&sacc[s][ST_NVALID], (ce_acc_t)1);
+          if (loss > 0.f) atomicAdd(&sacc[s][ST_NPOS], (ce_acc_t)1);
         }
-        if (conf && conf[p] >= conf_thr) atomicAdd(&sacc[s][ST_NCONF], 1.f);
+        if (conf && conf[p] >= conf_thr) atomicAdd(&sacc[s][ST_NCONF], (ce_acc_t)1);
       }
     }
     __syncthreads();
     if (stats && tid < 8) {
       const int s = tid >> 2, b = b_first + s;
-      if (sacc[s][tid & 3] != 0.f) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], (double)sacc[s][tid & 3]);
+      if (sacc[s][tid & 3] != 0) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], sacc[s][tid & 3]);
     }
   }
 }
@@ -288,9 +297,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
                                                                 const int64_t* __restrict__ label, const float* __restrict__ conf, float conf_thr,
                                                                 const float* __restrict__ keep_thr, int K, int H, int W,
-                                                                double* __restrict__ stats, float* __restrict__ gtprob_out) {
+                                                                ce_acc_t* __restrict__ stats, float* __restrict__ gtprob_out) {
   extern __shared__ __attribute__((aligned(16))) float ces_lds[];
-  __shared__ float sacc[4];
+  __shared__ ce_acc_t sacc[4];
   const int tid = threadIdx.x, b = blockIdx.z;
   const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
   const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
   const int fy1 = min((int)(sh * (float)Y1) + 1, h - 1), fx1 = min((int)(sw * (float)X1) + 1, w - 1);
   const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;
   ces_stage(ces_lds, small, ld, h, w, b, fy0, fx0, fh, fw, K, tid);
-  if (tid < 4) sacc[tid] = 0.f;
+  if (tid < 4) sacc[tid] = 0;
   __syncthreads();
   const float kthr = keep_thr ? *keep_thr : 0.f;
   float a_s = 0.f, a_nv = 0.f, a_np = 0.f, a_nc = 0.f;
@@ -339,12 +348,29 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
   }
   if (stats) {
     a_s = wave_sum(a_s); a_nv = wave_sum(a_nv); a_np = wave_sum(a_np); a_nc = wave_sum(a_nc);
+    // (a lane's four pixels add in program order, wave_sum is a fixed butterfly: the wave's sums are reproducible; from here on integers)
     if ((tid & 63) == 0) {
-      atomicAdd(&sacc[ST_S], a_s); atomicAdd(&sacc[ST_NVALID], a_nv); atomicAdd(&sacc[ST_NPOS], a_np); atomicAdd(&sacc[ST_NCONF], a_nc);
+      atomicAdd(&sacc[ST_S], ce_fix(a_s)); atomicAdd(&sacc[ST_NVALID], (ce_acc_t)a_nv); atomicAdd(&sacc[ST_NPOS], (ce_acc_t)a_np);
+      atomicAdd(&sacc[ST_NCONF], (ce_acc_t)a_nc);
     }
     __syncthreads();
-    if (tid < 4 && sacc[tid] != 0.f) atomicAdd(&stats[(size_t)b * 4 + tid], (double)sacc[tid]);
+    if (tid < 4 && sacc[tid] != 0) atomicAdd(&stats[(size_t)b * 4 + tid], sacc[tid]);
   }
+}
+
+// The footprints of neighbouring tiles share one row / column of small pixels, so the tiles' flushes into dsmall would have to be atomic -
+// and fp32 atomics add in arrival order: the gradient of the step would differ in its last bits from run to run (r03: two fp32 runs of the
+// same seeds drifted 4.8 steps apart in 30).  Instead the backward is launched once per COLOUR: a launch holds the tiles
+// (cx + i nx, cy + j ny) only, nx / ny chosen so that two tiles of a launch are far enough apart for their footprints to be disjoint
+// (ces_colours below: 2 x 2 launches for every factor up to 16), and every launch adds with plain read-modify-writes.  Launches run in
+// stream order, so each cell of dsmall receives its (up to four) contributions in one fixed order: bit-reproducible, no workspace.
+struct CesColour { int cx, cy, nx, ny; };
+// smallest n such that tiles n apart cannot touch the same small pixel: floor(s (32 (t + n))) > floor(s (32 t + 31)) + 1 for every t
+// follows from s (32 n - 31) >= 2 (with a margin for the rounding of the fp32 products)
+static inline int ces_colours(float s, int tiles) {
+  int n = 1;
+  while (n < tiles && s * (float)(CES_TW * n - (CES_TW - 1)) < 2.5f) ++n;
+  return n;
 }
 
 // Backward on the same tiles for K <= CES_KREG and an up-sampling factor in [2, 4]: per pixel ONE pass over the footprint for the K
@@ -358,12 +384,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_small_bwd_tile_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
                                                                 const int64_t* __restrict__ label, const float* __restrict__ keep_thr, int K, int H,
                                                                 int W, const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
-                                                                float* __restrict__ dsmall) {
+                                                                float* __restrict__ dsmall, CesColour col) {
   extern __shared__ __attribute__((aligned(16))) float ces_lds[];
   constexpr int FPK = CES_FP * CES_FP * CES_KREG;
   const int tid = threadIdx.x, b = blockIdx.z, wave = tid >> 6;
   float* sout = ces_lds + FPK + wave * FPK;
-  const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
+  const int X0 = (blockIdx.x * col.nx + col.cx) * CES_TW, Y0 = (blockIdx.y * col.ny + col.cy) * CES_TH;
   const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
   int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
   fy0 = min(fy0, h - 1); fx0 = min(fx0, w - 1);
@@ -438,7 +464,7 @@ __global__ __launch_bounds__(256) void ce_small_bwd_tile_kernel(const T* __restr
     const float* so = ces_lds + FPK + c * CES_KREG + k;
     const float v = (so[0] + so[FPK]) + (so[2 * FPK] + so[3 * FPK]);
     if (v == 0.f) continue;
-    atomicAdd(&dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k], v);
+    dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k] += v;      // (no atomic: the tiles of one launch have disjoint footprints, see CesColour)
   }
 }
 
@@ -447,7 +473,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__ small, int ld, int h, int w, float sh, float sw,
                                                            const int64_t* __restrict__ label, const float* __restrict__ keep_thr, int K, int H, int W,
                                                            const float* __restrict__ coef, const float* __restrict__ gscale, int pos_only,
-                                                           float* __restrict__ dsmall, int use_rmw) {
+                                                           float* __restrict__ dsmall, int use_rmw, CesColour col) {
   // LDS (launcher): the footprint's logits, then FOUR gradient copies (one per wave).  LDS float atomics are slow on this
   // part, so a wave scatters with plain read-modify-write into its own copy; that is race-free because the lattice mapping
   // below sends the 64 lanes of an instruction to 64 different small pixels whenever the up-sampling factor is <= 4
@@ -459,7 +485,7 @@ __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__
   const int ncopy = rmw ? 4 : 1;
   float* sout = ces_lds + FPK + (rmw ? (threadIdx.x >> 6) * FPK : 0);
   const int tid = threadIdx.x, b = blockIdx.z;
-  const int X0 = blockIdx.x * CES_TW, Y0 = blockIdx.y * CES_TH;
+  const int X0 = (blockIdx.x * col.nx + col.cx) * CES_TW, Y0 = (blockIdx.y * col.ny + col.cy) * CES_TH;
   const int X1 = min(X0 + CES_TW, W) - 1, Y1 = min(Y0 + CES_TH, H) - 1;
   // footprint in the small map: floor(s*first) .. floor(s*last) + 1, clamped
   int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
@@ -526,7 +552,7 @@ __global__ __launch_bounds__(256) void ce_small_bwd_kernel(const T* __restrict__
     const float v = rmw ? (so[i] + so[FPK + i]) + (so[2 * FPK + i] + so[3 * FPK + i]) : so[i];
     if (v == 0.f) continue;
     const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
-    atomicAdd(&dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k], v);
+    dsmall[((size_t)(b * h + fy0 + yy) * w + fx0 + xx) * K + k] += v;      // (no atomic: see CesColour)
   }
 }
 
@@ -536,15 +562,15 @@ static inline int ce_grid(size_t P) {
   return (int)(g > 8192 ? 8192 : (g < 1 ? 1 : g));
 }
 int css_launch_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P,
-                      int HW, double* stats, float* gtprob_out, hipStream_t st) {
+                      int HW, int64_t* stats, float* gtprob_out, hipStream_t st) {
   if (K > CE_MAXK || K < 1) return CSS_ERR_ARG;
   hipLaunchKernelGGL(ce_kernel<false>, dim3(ce_grid((size_t)P)), dim3(256), 0, st, logits, label, conf, conf_thr, keep_thr, K, (size_t)P, HW,
-                     stats, gtprob_out, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
+                     (ce_acc_t*)stats, gtprob_out, (const float*)nullptr, (const float*)nullptr, 0, (float*)nullptr);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
-int css_launch_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, hipStream_t st) {
-  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, stats, B, mode, loss, coef);
+int css_launch_ce_finalize(const int64_t* stats, int B, int mode, float* loss, float* coef, hipStream_t st) {
+  hipLaunchKernelGGL(ce_finalize_kernel, dim3(1), dim3(64), 0, st, (const ce_acc_t*)stats, B, mode, loss, coef);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
@@ -552,17 +578,17 @@ int css_launch_ce_bwd(const float* logits, const int64_t* label, const float* ke
                       const float* gscale, int pos_only, float* dlogits, hipStream_t st) {
   if (K > CE_MAXK || K < 1) return CSS_ERR_ARG;
   hipLaunchKernelGGL(ce_kernel<true>, dim3(ce_grid((size_t)P)), dim3(256), 0, st, logits, label, (const float*)nullptr, 0.f, keep_thr, K,
-                     (size_t)P, HW, (double*)nullptr, (float*)nullptr, coef, gscale, pos_only, dlogits);
+                     (size_t)P, HW, (ce_acc_t*)nullptr, (float*)nullptr, coef, gscale, pos_only, dlogits);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 // state: device buffer of css_ohem_state_bytes(); on return state->thr (offset css_ohem_thr_offset()) holds the keep threshold
 size_t css_ohem_state_bytes_() { return sizeof(OhemState); }
 size_t css_ohem_thr_offset_() { return offsetof(OhemState, thr); }
-int css_launch_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state,
+int css_launch_ohem_threshold(const float* gtprob, long P, const int64_t* stats, int B, int min_kept, float thresh, void* state,
                               hipStream_t st) {
   OhemState* s = reinterpret_cast<OhemState*>(state);
-  hipLaunchKernelGGL(ohem_init_kernel, dim3(1), dim3(256), 0, st, s, stats, B, P, min_kept);
+  hipLaunchKernelGGL(ohem_init_kernel, dim3(1), dim3(256), 0, st, s, (const ce_acc_t*)stats, B, P, min_kept);
   for (int shift = 24; shift >= 0; shift -= 8) {
     hipLaunchKernelGGL(ohem_hist_kernel, dim3(ce_grid((size_t)P)), dim3(256), 0, st, gtprob, (size_t)P, s, shift);
     hipLaunchKernelGGL(ohem_pick_kernel, dim3(1), dim3(64), 0, st, s, shift, thresh);
@@ -572,8 +598,9 @@ int css_launch_ohem_threshold(const float* gtprob, long P, const double* stats, 
 }
 
 int css_launch_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
-                            const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, hipStream_t st) {
+                            const float* keep_thr, int K, int H, int W, int64_t* stats_, float* gtprob_out, int dtype, hipStream_t st) {
   if (K > CE_MAXK || K < 1 || B <= 0) return CSS_ERR_ARG;
+  ce_acc_t* stats = (ce_acc_t*)stats_;
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const size_t P = (size_t)B * H * W;
   static const bool no_tile = getenv("CSS_CE_NO_TILE") != nullptr;      // (A/B and parity tests: the gather kernel for every shape)
@@ -605,33 +632,40 @@ int css_launch_ce_small_bwd(const void* small, int ld, int B, int h, int w, cons
                             const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, hipStream_t st) {
   if (K > CE_MAXK || K < 1 || B <= 0) return CSS_ERR_ARG;
   if (2 * (h - 1) > (H - 1) || 2 * (w - 1) > (W - 1)) return CSS_ERR_ARG;      // needs an up-sampling factor >= 2 (tile footprint)
+  if (dtype != CSS_BF16 && dtype != CSS_F32) return CSS_ERR_DTYPE;
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
-  dim3 g(cdiv(W, CES_TW), cdiv(H, CES_TH), B);
+  const int tx = cdiv(W, CES_TW), ty = cdiv(H, CES_TH);
   const size_t fpk = (size_t)CES_FP * CES_FP * K * sizeof(float);
   static const bool no_tile = getenv("CSS_CE_NO_TILE") != nullptr;
-  if (!no_tile && K <= CES_KREG && sh >= 0.2499f && sw >= 0.2499f) {
-    // factor in [2, 4], classes in registers: the tiled kernel (footprint + four per-wave gradient copies of CES_KREG floats per small
-    // pixel + one private cell per lane: 157.9 KiB of LDS)
-    const size_t lds = ((size_t)5 * CES_FP * CES_FP + 64) * CES_KREG * sizeof(float);
-    if (dtype == CSS_BF16)
-      hipLaunchKernelGGL(ce_small_bwd_tile_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
-                         gscale, pos_only, dsmall);
-    else if (dtype == CSS_F32)
-      hipLaunchKernelGGL(ce_small_bwd_tile_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
-                         gscale, pos_only, dsmall);
-    else return CSS_ERR_DTYPE;
-    CSS_CHECK_LAUNCH();
-    return CSS_OK;
-  }
+  // factor in [2, 4], classes in registers: the tiled kernel (footprint + four per-wave gradient copies of CES_KREG floats per small
+  // pixel + one private cell per lane: 157.9 KiB of LDS)
+  const bool tile = !no_tile && K <= CES_KREG && sh >= 0.2499f && sw >= 0.2499f;
   const int use_rmw = sh >= 0.2499f && sw >= 0.2499f && 5 * fpk <= 152 * 1024;   // logits + four per-wave gradient copies (133 KiB at K = 21)
-  const size_t lds = (use_rmw ? 5 : 2) * fpk;
-  if (dtype == CSS_BF16)
-    hipLaunchKernelGGL(ce_small_bwd_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
-                       pos_only, dsmall, use_rmw);
-  else if (dtype == CSS_F32)
-    hipLaunchKernelGGL(ce_small_bwd_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef, gscale,
-                       pos_only, dsmall, use_rmw);
-  else return CSS_ERR_DTYPE;
+  const size_t lds = tile ? ((size_t)5 * CES_FP * CES_FP + 64) * CES_KREG * sizeof(float) : (use_rmw ? 5 : 2) * fpk;
+  CesColour col;
+  col.nx = ces_colours(sw, tx);
+  col.ny = ces_colours(sh, ty);
+  for (col.cy = 0; col.cy < col.ny; ++col.cy)
+    for (col.cx = 0; col.cx < col.nx; ++col.cx) {
+      const dim3 g(cdiv(tx - col.cx, col.nx), cdiv(ty - col.cy, col.ny), B);
+      if (tile) {
+        if (dtype == CSS_BF16)
+          hipLaunchKernelGGL(ce_small_bwd_tile_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W,
+                             coef, gscale, pos_only, dsmall, col);
+        else
+          hipLaunchKernelGGL(ce_small_bwd_tile_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W,
+                             coef, gscale, pos_only, dsmall, col);
+      } else {
+        // (factors above 4 scatter with LDS float atomics inside the workgroup - use_rmw = 0: the one path of this file whose sums are
+        // not ordered; css_amd.loss.fused_upsample_ok keeps the trainer off it)
+        if (dtype == CSS_BF16)
+          hipLaunchKernelGGL(ce_small_bwd_kernel<bf16_t>, g, dim3(256), lds, st, (const bf16_t*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
+                             gscale, pos_only, dsmall, use_rmw, col);
+        else
+          hipLaunchKernelGGL(ce_small_bwd_kernel<float>, g, dim3(256), lds, st, (const float*)small, ld, h, w, sh, sw, label, keep_thr, K, H, W, coef,
+                             gscale, pos_only, dsmall, use_rmw, col);
+      }
+    }
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

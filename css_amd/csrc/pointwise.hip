@@ -335,8 +335,10 @@ __global__ __launch_bounds__(256) void spatial_bcast_vec_kernel(const T* __restr
 }
 
 // ---- column sum: out[c] += sum_m x[m][c]  (bias gradients) ---------------
+// stage 1: one partial row ws[blockIdx.y][C] per block of rows_per_block rows (plain stores); stage 2 adds the rows in block order.
+// (fp32 atomics onto out[] would add in arrival order: the bias gradients would differ in their last bits from run to run.)
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ ws) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -346,7 +348,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   __shared__ float red[4][64];
   red[part][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (part == 0 && c < C) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (part == 0 && c < C)
+    ws[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
+  float acc = 0.f;
+  if (c < C)
+    for (int r = part; r < nrows; r += 4) acc += ws[(size_t)r * C + c];
+  __shared__ float red[4][64];
+  red[part][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (part == 0 && c < C) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 
 // ---- strided channel copy (concat / slice), optional cast ---------------
@@ -461,7 +474,10 @@ __global__ __launch_bounds__(256) void cast_kernel(const TI* __restrict__ x, TO*
 // p -= lr * (d + mom*buf); then ema = decay*ema + (1-decay)*p (ddp_model.py:93-97).
 __global__ __launch_bounds__(256) void sgd_ema_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf,
                                                       float* __restrict__ ema, size_t n, float lr, float momentum, float wd,
-                                                      int first, float decay, float grad_scale) {
+                                                      int first, float decay, float grad_scale, const float* __restrict__ skip_flag) {
+  // skip_flag (device, optional): non-zero = the gradients of this step are known to be invalid (the ranks agreed on a violated
+  // bucket plan, train_step.py) - weights, momentum and the EMA teacher stay untouched, decided on the device without a host round trip
+  if (skip_flag && *skip_flag != 0.f) return;
   const size_t n4 = n / 4;
   GRID_STRIDE(idx, n4) {
     float4 pv = reinterpret_cast<float4*>(p)[idx];
@@ -623,12 +639,16 @@ int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long 
   return CSS_OK;
 }
 
-int css_launch_colsum(const void* x, int ld, long M, int C, float* out, int dtype, hipStream_t st) {
+constexpr long COLSUM_RPB = 512;
+size_t css_colsum_ws_bytes_(long M, int C) { return (size_t)cdiv(M > 0 ? M : 1, COLSUM_RPB) * (size_t)C * sizeof(float); }
+int css_launch_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
-  const long rpb = 512;
+  if (!ws) return CSS_ERR_WORKSPACE;
+  const int nrows = cdiv(M, COLSUM_RPB);
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), cdiv(M, rpb)), dim3(256), 0, st, (const T*)x, ld, M, C, rpb, out);
+    hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
   });
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, nrows, C, out);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
@@ -681,13 +701,13 @@ int css_launch_cast(const void* x, void* out, long n, int dtype_in, int dtype_ou
 }
 
 int css_launch_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first,
-                       float decay, float grad_scale, hipStream_t st) {
+                       float decay, float grad_scale, const float* skip_flag, hipStream_t st) {
   if (n <= 0) return CSS_OK;
   if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(buf) |
        reinterpret_cast<uintptr_t>(ema)) & 15)
     return CSS_ERR_ARG;
   hipLaunchKernelGGL(sgd_ema_kernel, dim3(ew_grid((size_t)n / 4 + 1)), dim3(256), 0, st, p, g, buf, ema, (size_t)n, lr, momentum, wd,
-                     first, decay, grad_scale);
+                     first, decay, grad_scale, skip_flag);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

@@ -31,7 +31,7 @@ class _PixelCE(torch.autograd.Function):
         label = label.contiguous()
         p = b * h * w
         dev, st = dev_stream(x)
-        f64 = dict(dtype=torch.float64, device=x.device)
+        f64 = dict(dtype=torch.int64, device=x.device)      # integer accumulators (include/css_hip.h: order-independent sums)
         stats = torch.zeros(b * 4, **f64)
         keep = None
         if ohem is not None:
@@ -81,7 +81,7 @@ class _PixelCESmall(torch.autograd.Function):
         p = b * hh * ww
         dev, st = dev_stream(x)
         dc = dtype_code(x.dtype)
-        f64 = dict(dtype=torch.float64, device=x.device)
+        f64 = dict(dtype=torch.int64, device=x.device)      # integer accumulators (include/css_hip.h: order-independent sums)
         stats = torch.zeros(b * 4, **f64)
         keep = None
         if ohem is not None:
@@ -115,9 +115,12 @@ class _PixelCESmall(torch.autograd.Function):
         return dx.to(in_dtype), None, None, None, None, None
 
 
-def fused_upsample_ok(small_hw, label_hw):
-    """css_ce_small_bwd's tile footprint assumes an up-sampling factor >= 2 (513/129, 769/193 in the reference's configs)."""
-    return 2 * (small_hw[0] - 1) <= label_hw[0] - 1 and 2 * (small_hw[1] - 1) <= label_hw[1] - 1
+def fused_upsample_ok(small_hw, label_hw, num_classes=21):
+    """css_ce_small_bwd's tile footprint assumes an up-sampling factor >= 2 (513/129, 769/193 in the reference's configs: exactly 4);
+    above a factor of 4, or with more than 24 classes, its adjoint inside a workgroup falls back to LDS float atomics - not
+    bit-reproducible - so the trainer takes the (ordered) up-sample + full-resolution loss there."""
+    (h, w), (hh, ww) = small_hw, label_hw
+    return (2 * (h - 1) <= hh - 1 and 2 * (w - 1) <= ww - 1 and 4 * (h - 1) >= hh - 1 and 4 * (w - 1) >= ww - 1 and num_classes <= 24)
 
 
 class CrossEntropyLoss(nn.Module):
@@ -177,8 +180,9 @@ class _ContrastCore(torch.autograd.Function):
         d = rep_d.device
         i32 = dict(dtype=torch.int32, device=d)
         meta = torch.zeros(query("css_contrast_meta_bytes"), dtype=torch.uint8, device=d)
-        sums = torch.zeros(K * C + K, dtype=torch.float64, device=d)
-        call("css_contrast_class_sums", rep_d, C, cls, P, K, C, sums, dc, dev, st)
+        sums = torch.empty(K * C + K, dtype=torch.float64, device=d)
+        ws = torch.empty(query("css_contrast_class_sums_ws_bytes", P, K, C) // 4, dtype=torch.float32, device=d)
+        call("css_contrast_class_sums", rep_d, C, cls, P, K, C, sums, ws, dc, dev, st)
         nch = query("css_contrast_nchunks", P)
         chunkhist = torch.empty(nch * 64, **i32)
         listV, listH = torch.empty(P, **i32), torch.empty(P, **i32)

@@ -231,7 +231,7 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
-            lazy = _take_lazy_res_grad(dtap)
+            lazy = _take_lazy_res_grad(ctx, dtap)
             if lazy is not None:
                 # the residual gradient arrives as (gradient at the ReLU output, ReLU bit mask): masked inside the store (_BNAct.backward)
                 call("css_conv2d_dgrad_add_masked", dyp, wt, dx, lazy[0], cp, lazy[1], n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s,
@@ -244,7 +244,7 @@ class _Conv2d(torch.autograd.Function):
                 call("css_conv2d_dgrad", dyp, wt, dx, n, h, w_, cp, cp, ho, wo, cout_pad, cout_pad, r, s, stride, pad, dil, flops,
                      dc, dev, st)
         elif dtap is not None:
-            if _take_lazy_res_grad(dtap) is not None:
+            if _take_lazy_res_grad(ctx, dtap) is not None:
                 raise _lib.CssHipError("a lazily masked residual gradient reached a convolution that computes no data gradient")
             dx = dtap
         if ctx.needs_input_grad[1]:
@@ -265,43 +265,74 @@ class _Conv2d(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             bias_p = ctx.bias_ref
             sink = _grad_sink(bias_p, (cout,)) if bias_p is not None else None
+            cws = torch.empty(_lib.query("css_colsum_ws_bytes", n * ho * wo, cout) // 4, dtype=torch.float32, device=dy.device)
             if sink is not None:
-                call("css_colsum", dy, cout, n * ho * wo, cout, sink, dc, dev, st)
+                call("css_colsum", dy, cout, n * ho * wo, cout, sink, cws, dc, dev, st)
                 _grad_ready(bias_p)
             else:
                 db = torch.zeros((cout,), dtype=torch.float32, device=dy.device)
-                call("css_colsum", dy, cout, n * ho * wo, cout, db, dc, dev, st)
+                call("css_colsum", dy, cout, n * ho * wo, cout, db, cws, dc, dev, st)
         return dx, dw, db, None, None, None, None, None
 
 
 _conv_stats_out = None
 
-# Residual gradients whose ReLU backward is still to be applied: data_ptr of the gradient tensor _BNAct.backward handed to autograd for
-# `res` -> (that tensor, the ReLU bit mask).  The consumer is the tapped convolution's backward (Bottleneck.conv1), which masks the
-# addend inside its dgrad store; an entry nobody took by the end of a backward pass means a gradient went out unmasked: the trainer checks
-# (assert_no_lazy_res_grads).  CSS_BN_EAGER_DRES=1: bn_bwd_apply writes the masked copy itself (round-2 behaviour; A/B and parity tests).
-_lazy_res_grads = {}
+# Residual gradients whose ReLU backward is still to be applied.  A tapped convolution (Bottleneck.conv1) and the batch norm that uses the
+# tap as its residual share a _TapLink: created in conv2d(tap=True), owned by the convolution's autograd node (ctx.tap_link) and carried by
+# the tap tensor to bn_act, whose backward parks (gradient at the ReLU output, ReLU bit mask) in it instead of writing a masked copy; the
+# convolution's backward masks that addend inside its dgrad store.  The hand-over is bound to the consumer: the tensor that
+# arrives as the tap's gradient must BE the parked one - if the tap found a second consumer, autograd hands over a sum that contains the
+# unmasked gradient, and the backward raises instead of adding it.  Links die with their graph, so an aborted backward leaves nothing
+# behind; every backward pass that parked something ends with a check (engine callback) that all of it was consumed.
+# CSS_BN_EAGER_DRES=1: bn_bwd_apply writes the masked copy itself (round-2 behaviour; A/B and parity tests).
 _lazy_dres = os.environ.get("CSS_BN_EAGER_DRES") != "1"
 
 
-def _take_lazy_res_grad(dtap):
-    if dtap is None or not _lazy_res_grads:
+class _TapLink:
+    __slots__ = ("pending",)
+
+    def __init__(self):
+        self.pending = None          # (da, mask) between _BNAct.backward and the tapped convolution's backward
+
+
+_parked_links = []                   # links that received a pair during the running backward pass
+_parked_task = None                  # autograd graph-task id the list belongs to
+
+
+def _park_lazy_res_grad(link, da, mask):
+    global _parked_task
+    task = torch._C._current_graph_task_id()
+    if task != _parked_task:         # a new backward pass: whatever an aborted one left is dropped, and this pass gets its end-of-pass check
+        for l in _parked_links:
+            l.pending = None
+        _parked_links.clear()
+        _parked_task = task
+        if task >= 0:
+            torch.autograd.Variable._execution_engine.queue_callback(assert_no_lazy_res_grads)
+    link.pending = (da, mask)
+    _parked_links.append(link)
+
+
+def _take_lazy_res_grad(ctx, dtap):
+    link = getattr(ctx, "tap_link", None)
+    if dtap is None or link is None or link.pending is None:
         return None
-    ent = _lazy_res_grads.pop(dtap.data_ptr(), None)
-    if ent is None:
-        return None
-    g, mask = ent
-    if g.shape != dtap.shape or g.dtype != dtap.dtype or not dtap.is_contiguous():
-        raise _lib.CssHipError("lazily masked residual gradient: the tensor that arrived is not the one that was sent")
+    g, mask = link.pending
+    link.pending = None
+    if dtap.data_ptr() != g.data_ptr() or g.shape != dtap.shape or g.dtype != dtap.dtype or not dtap.is_contiguous():
+        raise _lib.CssHipError("lazily masked residual gradient: the tensor that reached the tapped convolution is not the one its batch norm "
+                               "parked (the tap has a second consumer?) - the sum would contain an unmasked gradient")
     return g, mask
 
 
 def assert_no_lazy_res_grads():
-    """After a backward pass: every (gradient, mask) pair _BNAct.backward left for a tapped convolution was consumed."""
-    if _lazy_res_grads:
-        n = len(_lazy_res_grads)
-        _lazy_res_grads.clear()
-        raise _lib.CssHipError(f"{n} residual gradient(s) left the batch-norm backward unmasked and were never masked by a dgrad store")
+    """End of a backward pass: every (gradient, mask) pair a batch norm parked for its tapped convolution was consumed."""
+    left = [l for l in _parked_links if l.pending is not None]
+    for l in left:
+        l.pending = None
+    _parked_links.clear()
+    if left:
+        raise _lib.CssHipError(f"{len(left)} residual gradient(s) left the batch-norm backward unmasked and were never masked by a dgrad store")
 
 
 def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, bn_stats=False, tap=False):
@@ -312,7 +343,12 @@ def conv2d(x, weight, bias=None, stride=1, pad=0, dil=1, bn_stats=False, tap=Fal
     out = _Conv2d.apply(x, weight, bias, stride, pad, dil, _bn_groups if bn_stats else 0, tap)
     y = out[0] if tap else out
     if tap:
-        out[1]._css_tap = True       # bn_act(res=<this>) may then leave the ReLU backward of the residual gradient to this op's dgrad store
+        # bn_act(res=<this>) may then leave the ReLU backward of the residual gradient to this op's dgrad store (see _TapLink)
+        node = y.grad_fn
+        link = _TapLink() if node is not None else None
+        if node is not None:
+            node.tap_link = link
+        out[1]._css_tap = link
     if _conv_stats_out is not None:
         y._css_bnstats = _conv_stats_out
     return out
@@ -353,7 +389,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None,
-                res_is_tap=False):
+                tap_link=None):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -421,7 +457,7 @@ class _BNAct(torch.autograd.Function):
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         # the residual came out of a tapped convolution: its backward applies this layer's ReLU mask to the gradient itself
-        ctx.lazy_res = bool(res_is_tap and mask is not None and _lazy_dres)
+        ctx.tap_link = tap_link if (mask is not None and _lazy_dres) else None
         return out
 
     @staticmethod
@@ -459,13 +495,13 @@ class _BNAct(torch.autograd.Function):
         if sync and collectives_on():
             dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
         dy = torch.empty_like(y)
-        lazy = ctx.lazy_res and mask is not None and ldda == c and da.is_contiguous() and da.shape == y.shape
+        lazy = ctx.tap_link is not None and mask is not None and ldda == c and da.is_contiguous() and da.shape == y.shape
         dres = torch.empty_like(y) if (has_res and not lazy) else None
         if mask is not None:
             call("css_bn_bwd_apply_mask", da, ldda, mask, y, c, dy, c, dres, c, mean, invstd, gamma, sums, count, count_t, m, c, mg, dc, dev, st)
             if lazy:
                 # no masked copy of `da` for the residual branch: `da` itself travels on, with the mask on the side (see _lazy_res_grads)
-                _lazy_res_grads[da.data_ptr()] = (da, mask)
+                _park_lazy_res_grad(ctx.tap_link, da, mask)
                 dres = da
         else:
             call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
@@ -510,7 +546,7 @@ def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, train
            groups=None, out_into=None):
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
                         _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into,
-                        bool(res is not None and getattr(res, "_css_tap", False)))
+                        getattr(res, "_css_tap", None) if res is not None else None)
 
 
 # --------------------------------------------------------------------------

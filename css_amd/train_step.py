@@ -69,7 +69,9 @@ class MixTrainer:
         self._span_reports = None              # span -> number of gradient reports per step (recorded on the first step)
         self._span_bucket = None               # span -> index of its bucket
         self._flags = [torch.zeros(1, device=self.flat_g.device) for _ in range(2)]   # violation flag agreed across ranks (MAX all-reduce)
-        self._flag_pending = None
+        self._flag_host = [torch.zeros(1).pin_memory() if torch.cuda.is_available() else torch.zeros(1) for _ in range(2)]
+        self._flag_pending = None              # (pinned host copy of the agreed flag, event recorded behind the copy)
+        self._skip_flag = None                 # device flag of THIS step for css_sgd_ema (non-zero: leave weights / momentum / teacher alone)
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -124,6 +126,7 @@ class MixTrainer:
         launched in order, the ranks agree on the flag with one small all-reduce, and every rank raises at the same point (the start of its next step)."""
         sync = ops.collectives_on()
         overlap = sync and self.bucket_mb > 0
+        self._skip_flag = None
         if not overlap:
             with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
                 total.backward()
@@ -168,7 +171,7 @@ class MixTrainer:
                 launch(self._buckets[state["b"]][0])
                 state["b"] += 1
 
-        self._check_bucket_flag()                # the previous step's agreed flag (long since on the host side of the stream)
+        self._check_bucket_flag()                # (direct callers; MixTrainer.step has read it already, before queueing its forward)
         if not recording:
             self._pending = [len(spans) for _, spans in self._buckets]
         prev = ops.set_grad_ready_callback(ready)
@@ -204,21 +207,42 @@ class MixTrainer:
         works.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._grad_pg, async_op=True))
         for w in works:
             w.wait()                             # the compute stream waits for the buckets (host does not block on RCCL)
-        self._flag_pending = flag                # read at the start of the next step, on every rank at the same point of the protocol
+        # the agreed flag (a) stops this step's optimizer on the device (css_sgd_ema skips: no invalid gradient ever reaches the weights, the
+        # momentum or the teacher) and (b) travels to a pinned host buffer behind an event, read at the start of the next step - by then the
+        # copy has long landed, so the host never blocks on the device inside a step (float(flag[0]) here drained the forward)
+        self._skip_flag = flag
+        host = self._flag_host[self.it & 1]
+        host.copy_(flag, non_blocking=True)
+        ev = None
+        if flag.is_cuda:
+            ev = torch.cuda.Event()
+            ev.record()
+        self._flag_pending = (host, ev)
 
     def _check_bucket_flag(self):
         """Raise - on every rank - when some rank's gradient reports did not fit the recorded plan.  The agreed flag is read ONE STEP
-        LATE (start of the next backward, or `finish()`), so that the host never blocks on the device inside a step."""
-        flag, self._flag_pending = self._flag_pending, None
-        if flag is not None and float(flag[0]) != 0.0:
+        LATE (start of the next step, `finish()`, or before a checkpoint is written) from its pinned host copy; the step it belongs to was
+        already skipped on the device (css_sgd_ema's skip_flag), so weights, momentum and teacher are those of the last valid step."""
+        pending, self._flag_pending = self._flag_pending, None
+        if pending is None:
+            return
+        host, ev = pending
+        if ev is not None:
+            ev.synchronize()
+        if float(host[0]) != 0.0:
             self._buckets = None
             raise RuntimeError("gradient readiness changed between steps on some rank (a span reported more or less often than on the "
                                "first step); buckets were reset on every rank - the gradients of that step are invalid, rebuild the "
                                "trainer for a new graph")
 
     def finish(self):
-        """Call after the last step of a run: surfaces a pending bucket-plan violation of the final step."""
+        """Call after the last step of a run and before saving a checkpoint: surfaces a pending bucket-plan violation of the final step."""
         self._check_bucket_flag()
+
+    def state_dict(self):
+        """Trainer state for a checkpoint (checked first: a step whose gradients were invalid raises here instead of being saved)."""
+        self.finish()
+        return dict(it=self.it, step=self.model.step, prototypes=self.prototypes.detach().clone(), momentum=self.flat_m.detach().clone())
 
     @property
     def lr(self):
@@ -226,11 +250,12 @@ class MixTrainer:
 
     def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
         m = self.model
+        self._check_bucket_flag()                                            # (before anything of this step is queued: the read cannot stall it)
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
         # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
         # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144
         pred_l, pred_u, (un_lab, un_conf), (u_lab, u_lc), rep_all, pred_small = self._student_outputs(l_img, u_img)
-        if self.fused_loss and fused_upsample_ok(pred_l.shape[1:3], l_img.shape[2:]):
+        if self.fused_loss and fused_upsample_ok(pred_l.shape[1:3], l_img.shape[2:], self.K):
             sup = (self.crit_ohem or self.crit_ce).forward_small(pred_l, l_lab)
             unsup = self.crit_unsup.forward_small(pred_u, un_lab, un_conf)
         else:
@@ -249,7 +274,7 @@ class MixTrainer:
         decay = min(1 - 1 / (m.step + 1), m.alpha)
         dev, st = dev_stream(self.flat_p)
         call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
-             float(self.wd), int(self.it == 0), float(decay), 1.0 / world, dev, st)
+             float(self.wd), int(self.it == 0), float(decay), 1.0 / world, self._skip_flag, dev, st)
         m.refresh_weights()
         m.step += 1
         self.it += 1

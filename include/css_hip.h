@@ -170,14 +170,16 @@ CSS_API int css_spatial_sum(const void* x, int ldx, void* out, int N, int HW, in
 CSS_API int css_spatial_bcast(const void* x, void* out, int ldo, int N, int HW, int C, float scale, int dtype, int device, css_stream_t stream);
 CSS_API int css_copy_channels(const void* src, int lds, void* dst, int ldd, long M, int C, int dtype_in, int dtype_out, int device,
                               css_stream_t stream);
-/* out[c] += sum_m x[m][c]  (bias gradient of the 1x1 heads, deeplabv3.py:125,132); out is fp32 and accumulated */
-CSS_API int css_colsum(const void* x, int ld, long M, int C, float* out, int dtype, int device, css_stream_t stream);
+/* out[c] += sum_m x[m][c]  (bias gradient of the 1x1 heads, deeplabv3.py:125,132); out is fp32 and accumulated.  Two stages through
+ * ws (fp32, css_colsum_ws_bytes(M, C) bytes, caller-owned): one partial row per row block, then an ordered sum - no float atomics. */
+CSS_API size_t css_colsum_ws_bytes(long M, int C);
+CSS_API int css_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, int device, css_stream_t stream);
 CSS_API int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream);
 CSS_API int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int device, css_stream_t stream);
 
 /* ---- optimiser + EMA teacher: torch.optim.SGD(nesterov) mix_label.py:96-97,194; Model_mix.ema_update ddp_model.py:93-97 */
 CSS_API int css_sgd_ema(float* p, const float* g, float* buf, float* ema, long n, float lr, float momentum, float wd, int first, float decay,
-                        float grad_scale, int device, css_stream_t stream);
+                        float grad_scale, const float* skip_flag, int device, css_stream_t stream);
 CSS_API int css_ema(float* ema, const float* p, long n, float decay, int device, css_stream_t stream);
 
 /* ---- similarity / pseudo labels: ddp_model.py:104-118,147-154; mix_label.py:175-183 ------------------ */
@@ -220,24 +222,30 @@ CSS_API int css_eval_confusion(const void* pred, int ldp, const int64_t* label, 
                                uint8_t* argmax_out, int dtype, int device, css_stream_t stream);
 CSS_API int css_confusion_bincount(const int64_t* pred, const int64_t* label, long n, int K, int64_t* mat, int device, css_stream_t stream);
 
-/* ---- cross-entropy family: mix_label.py:81,169; loss/loss.py:19-46 (OHEM), :53-64 (Attention_Threshold_Loss) */
+/* ---- cross-entropy family: mix_label.py:81,169; loss/loss.py:19-46 (OHEM), :53-64 (Attention_Threshold_Loss).
+ * stats: int64 [B][4] per-image accumulators, zeroed by the caller: {sum of losses in units of 2^-32, #(loss > 0), #(counted pixels),
+ * #(conf >= conf_thr)} - integers, so the workgroups' atomic adds give the same bits in any arrival order (reproducible losses and,
+ * through coef, reproducible gradients). */
 CSS_API int css_ce_fwd(const float* logits, const int64_t* label, const float* conf, float conf_thr, const float* keep_thr, int K, long P, int HW,
-                       double* stats, float* gtprob_out, int device, css_stream_t stream);
-CSS_API int css_ce_finalize(const double* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream);
+                       int64_t* stats, float* gtprob_out, int device, css_stream_t stream);
+CSS_API int css_ce_finalize(const int64_t* stats, int B, int mode, float* loss, float* coef, int device, css_stream_t stream);
 CSS_API int css_ce_bwd(const float* logits, const int64_t* label, const float* keep_thr, int K, long P, int HW, const float* coef,
                        const float* gscale, int pos_only, float* dlogits, int device, css_stream_t stream);
 /* the same losses computed straight from the LOW-resolution logits small [B][h][w][ld] (bf16 / fp32): the bilinear
  * (align_corners=True) up-sampling to the label size [B][H][W] of ddp_model.py:141,144 is applied on the fly, forward and
  * adjoint, so the [B,K,H,W] logits and their gradient are never materialised.  css_ce_small_bwd ACCUMULATES into dsmall
- * (fp32 [B][h][w][K], zero it first) and needs an up-sampling factor >= 2.  Same stats / coef / keep_thr protocol as above. */
+ * (fp32 [B][h][w][K], zero it first) and needs an up-sampling factor >= 2.  Same stats / coef / keep_thr protocol as above.
+ * The backward runs as 2 x 2 (factor <= 16) launches over tiles with pairwise disjoint footprints, each adding with plain
+ * read-modify-writes in stream order: no float atomics, bit-reproducible (factor <= 4; above that the adjoint inside a workgroup
+ * still uses LDS float atomics). */
 CSS_API int css_ce_small_fwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* conf, float conf_thr,
-                             const float* keep_thr, int K, int H, int W, double* stats, float* gtprob_out, int dtype, int device,
+                             const float* keep_thr, int K, int H, int W, int64_t* stats, float* gtprob_out, int dtype, int device,
                              css_stream_t stream);
 CSS_API int css_ce_small_bwd(const void* small, int ld, int B, int h, int w, const int64_t* label, const float* keep_thr, int K, int H, int W,
                              const float* coef, const float* gscale, int pos_only, float* dsmall, int dtype, int device, css_stream_t stream);
 CSS_API size_t css_ohem_state_bytes(void);
 CSS_API size_t css_ohem_thr_offset(void);
-CSS_API int css_ohem_threshold(const float* gtprob, long P, const double* stats, int B, int min_kept, float thresh, void* state, int device,
+CSS_API int css_ohem_threshold(const float* gtprob, long P, const int64_t* stats, int B, int min_kept, float thresh, void* state, int device,
                                css_stream_t stream);
 
 /* ---- contrastive loss: loss/loss.py:75-149, 410-418 ---------------------------------------------------- */
@@ -245,7 +253,10 @@ CSS_API size_t css_contrast_meta_bytes(void);
 CSS_API int css_contrast_nchunks(int P);
 CSS_API int css_contrast_classify(const float* label, const float* mask, const float* prob, long sb, long sk, long sp, long psb, long psk, long psp,
                                   int P, int HW, int K, float strong_thr, int* cls, uint8_t* hard, void* meta, int device, css_stream_t stream);
-CSS_API int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, int dtype, int device,
+/* out fp64 [K][C] class sums + [K] class counts (loss.py:77-101 as sums).  ws: fp32 workspace of css_contrast_class_sums_ws_bytes(P, K, C)
+ * bytes (one partial [K][C] + [K] per workgroup; stage 2 adds them in workgroup order: no float atomics, bit-reproducible). */
+CSS_API size_t css_contrast_class_sums_ws_bytes(int P, int K, int C);
+CSS_API int css_contrast_class_sums(const void* rep, int ld, const int* cls, int P, int K, int C, double* out, float* ws, int dtype, int device,
                                     css_stream_t stream);
 CSS_API int css_contrast_compact(const int* cls, const uint8_t* hard, int P, int K, int* chunkhist, int* listV, int* listH, void* meta, int device,
                                  css_stream_t stream);

@@ -22,6 +22,23 @@ def pytest_configure(config):
         pass
 
 
+# Collection order (a statistical test with fitted margins stopped `-x` before 269 deterministic parity tests ran).
+# Rank 0: the oracle against the reference's golden vectors and the host logic; 1: HIP path vs oracle / golden fixtures / torch-CPU, bit-exact
+# or within a stated tolerance; 2: size-independent properties at the BASELINE sizes, multi-process and switch coverage, reproducibility;
+# 3: statistical / trajectory reports.  Inside a rank the files keep their alphabetical order.
+_RANK = {"test_oracle_golden": 0, "test_host_cpu": 0, "test_dataset_cpu": 0, "test_dist_cpu": 0,
+         "test_full_size_gpu": 2, "test_dist_gpu": 2, "test_kernel_switches_gpu": 2, "test_determinism_gpu": 2,
+         "test_bf16_trajectory_gpu": 3}
+_RANK_BY_NAME = {"test_three_steps_fp32_and_bf16_vs_oracle": 1}      # (an oracle parity test that lives in the trajectory file)
+
+
+def pytest_collection_modifyitems(session, config, items):
+    def rank(item):
+        mod = os.path.splitext(os.path.basename(str(item.fspath)))[0]
+        return _RANK_BY_NAME.get(getattr(item, "originalname", None) or item.name.split("[")[0], _RANK.get(mod, 1))
+    items.sort(key=rank)            # (stable: order inside a rank is the collection order)
+
+
 @pytest.fixture(scope="session")
 def golden():
     import numpy as np

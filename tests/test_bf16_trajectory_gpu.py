@@ -1,20 +1,18 @@
 """bf16 stays on the fp32 trajectory over many steps: the proxy this repo can offer for north_star's "mIoU within +-0.3 of the
-reference", which needs VOC and ImageNet weights that are not here.
+reference", which needs VOC and ImageNet weights that are not here (re-posed after VERDICT r03).
 
 * 3 steps at 65^2 (B=2+2): fp32 HIP path against the fp32 CPU oracle step by step with the oracle's sampler draws injected - SGD
   momentum, the EMA teacher and the prototype EMA carried across steps (/root/reference/mix_label.py:162-196,
-  generalframeworks/networks/ddp_model.py:93-97) - then the bf16 HIP path on the same steps;
-* 30 steps at 129^2, B=4+4, K=21 at the training lr (6.4e-3): once with ``set_compute_dtype(bfloat16)``, once in fp32, both on the HIP
-  path with the same seeds (weights, crops, device sampler).  Measured on MI355X: both runs take the supervised loss from 7.03 to
-  0.10-0.11; the two curves run up to one and a half steps apart in TIME (29 % apart at equal step index around step 5, where the loss
-  halves every two steps; 17 % at step 28 of another run, where it falls 7 % per step) and which one leads changes from run to run
-  (fp32 atomics in the loss backward: the order of their adds is not fixed).  Asserted: no NaN; both runs end below a tenth of the
-  initial loss; the TIME lag between the curves (for every bf16 loss: distance to the nearest step at which the piecewise-linear fp32
-  curve takes that value) stays within 8 steps (measured on three boxes: up to 2.3, 3.9 and 4.6 - one early event, a plateau left one
-  step sooner or later, shifts the rest of a curve; a second fp32 run is printed against the first as the yardstick of that spread); the
-  means of the last five steps agree within 50 % (measured 13-25 %: 4 steps of lag where the loss falls 7 % per step);
-  the contrastive loss agrees within 1 % at every step; prototype cosine >= 0.98 and cosine of the centred weight vectors >= 0.98
-  (measured 0.991-0.9997) at step 30.
+  generalframeworks/networks/ddp_model.py:93-97) - then the bf16 HIP path on the same steps.  An oracle parity test: collected with them.
+* 30 steps at 129^2, B=4+4, K=21 at the training lr (6.4e-3) - a regime that is CHAOTIC on a random-init network (|grad| ~ 1e4 |param|:
+  a last-bit difference is amplified to per cents within a few steps).  Since round 4 every reduction of the step is ordered, so a run is a
+  pure function of its inputs (tests/test_determinism_gpu.py: bit-identical twice) and the question "does bf16 differ, or does the run
+  differ" can be put properly: an ENSEMBLE of fp32 runs whose input images are perturbed by one unit in the last place (x (1 +- 2^-23),
+  the smallest perturbation there is) measures how far apart two legitimate fp32 trajectories of this problem end up; the bf16 run must
+  lie inside a fixed multiple (ENV_C = 2) of that envelope - in TIME lag between the supervised-loss curves, in the mean of the last
+  five steps, in the cosines of prototypes and weights.  No margin is a number read off runs: every bound is `ENV_C x ensemble value`.
+  Only chaos-free facts are asserted absolutely (finite, the loss falls tenfold, the contrastive loss - whose sampler is seeded and whose
+  logits are normalised - agrees to 1 %).  The full curves of all members are printed (the record of round 4: profiles/r04_trajectory_*.txt).
 """
 import math
 import os
@@ -112,42 +110,72 @@ def _lag(sf, i, b):
     return i - best
 
 
-def test_thirty_steps_bf16_tracks_fp32():
-    S, B, seed, gain, steps = 129, 4, 11, 0.25, 30
-    l_img, l_lab, u_img = _batch(S, B, 5, 16)
-    runs = {}
-    # the fp32 run twice: its own run-to-run spread (fp32 atomics in the loss backward add in no fixed order) is the yardstick printed below
-    for name, dtype in (("f32", torch.float32), ("f32_again", torch.float32), ("bf16", torch.bfloat16)):
-        tr = _trainer(S, seed, gain, dtype, float(os.environ.get("CSS_TRAJ_LR", "6.4e-3")), 256, 512)
-        np.random.seed(0)
-        torch.manual_seed(0)
-        hist = []
-        for _ in range(steps):
-            r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()))
-            hist.append({k: float(r[k]) for k in ("sup", "unsup", "contrast", "total")})
-        runs[name] = (hist, tr.prototypes.cpu().double(), tr.flat_p.detach().cpu().double())
-        del tr
-        torch.cuda.empty_cache()
-    hf, pf, wf = runs["f32"]
-    hb, pb, wb = runs["bf16"]
-    for i in range(steps):
-        print(f"step {i:2d}  fp32 sup {hf[i]['sup']:.4f} contrast {hf[i]['contrast']:.4f}   bf16 sup {hb[i]['sup']:.4f} contrast {hb[i]['contrast']:.4f}")
-    for h in (hf, hb):
-        assert all(math.isfinite(v) for d in h for k, v in d.items() if k != "unsup")        # (unsup is NaN by definition when no pixel is valid)
-        assert np.mean([d["sup"] for d in h[-3:]]) < 0.1 * h[0]["sup"], (h[0]["sup"], h[-1]["sup"])      # the supervised loss goes down
+ENV_C = 2.0           # bf16 must lie inside ENV_C x the spread of the fp32 ensemble
+N_MEMBERS = 4         # fp32 runs with 1-ulp input perturbations
+
+
+def _perturb_ulp(x, seed):
+    """x (1 +- 2^-23): every element moves by about one unit in the last place, sign from a seeded coin."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    sign = torch.randint(0, 2, x.shape, generator=g).float() * 2.0 - 1.0
+    return x * (1.0 + sign * 2.0 ** -23)
+
+
+def _thirty(dtype, l_img, l_lab, u_img, steps, S, seed, gain):
+    tr = _trainer(S, seed, gain, dtype, float(os.environ.get("CSS_TRAJ_LR", "6.4e-3")), 256, 512)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    hist = []
+    for _ in range(steps):
+        r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()))
+        hist.append({k: float(r[k]) for k in ("sup", "unsup", "contrast", "total")})
+    out = (hist, tr.prototypes.cpu().double(), tr.flat_p.detach().cpu().double())
+    del tr
+    torch.cuda.empty_cache()
+    return out
+
+
+def _metrics(base, run):
+    """Distance of ``run`` from the fp32 baseline: max |time lag| of the supervised curve, relative gap of the last-five-steps mean, worst
+    relative contrastive-loss gap, min prototype cosine, cosine of the centred weight vectors."""
+    (hf, pf, wf), (hb, pb, wb) = base, run
     sf, sb = [d["sup"] for d in hf], [d["sup"] for d in hb]
-    worst = max(abs(a - b) / a for a, b in zip(sf, sb))
     lags = [_lag(sf, i, b) for i, b in enumerate(sb)]
-    lags_ref = [_lag(sf, i, b) for i, b in enumerate(d["sup"] for d in runs["f32_again"][0])]
     tail = abs(np.mean(sb[-5:]) - np.mean(sf[-5:])) / np.mean(sf[-5:])
     worst_c = max(abs(a["contrast"] - b["contrast"]) / max(abs(a["contrast"]), 1.0) for a, b in zip(hf, hb))
     present = pf.abs().sum(1) > 0
-    cos = torch.nn.functional.cosine_similarity(pf[present], pb[present], dim=1)
+    cos = float(torch.nn.functional.cosine_similarity(pf[present], pb[present], dim=1).min())
     wcos = float(torch.nn.functional.cosine_similarity(wf - wf.mean(), wb - wb.mean(), dim=0))
-    print(f"30 steps: worst |d sup| / sup at equal step index {worst:.4f}, last five steps {tail:.4f}, contrast {worst_c:.4f}; "
-          f"prototype cosine min {float(cos.min()):.4f}; weights cosine {wcos:.6f}")
-    print("lag of the bf16 curve behind (+) / ahead of (-) the fp32 curve, in steps:", " ".join(f"{v:+.1f}" for v in lags))
-    print("the same for a second fp32 run against the first:                          ", " ".join(f"{v:+.1f}" for v in lags_ref))
-    assert max(abs(v) for v in lags) <= 8.0, lags
-    assert tail <= 0.5 and worst_c <= 0.01, (tail, worst_c)
-    assert float(cos.min()) >= 0.98 and wcos >= 0.98
+    return dict(lag=max(abs(v) for v in lags), tail=tail, contrast=worst_c, proto_cos=cos, w_cos=wcos, lags=lags)
+
+
+def test_thirty_steps_bf16_inside_fp32_ensemble():
+    S, B, seed, gain, steps = 129, 4, 11, 0.25, 30
+    l_img, l_lab, u_img = _batch(S, B, 5, 16)
+    base = _thirty(torch.float32, l_img, l_lab, u_img, steps, S, seed, gain)
+    members = [_thirty(torch.float32, _perturb_ulp(l_img, k), l_lab, _perturb_ulp(u_img, 100 + k), steps, S, seed, gain) for k in range(N_MEMBERS)]
+    bf = _thirty(torch.bfloat16, l_img, l_lab, u_img, steps, S, seed, gain)
+    names = ["fp32"] + [f"fp32+ulp{k}" for k in range(N_MEMBERS)] + ["bf16"]
+    print("supervised loss per step:", " ".join(f"{n:>10s}" for n in names))
+    for i in range(steps):
+        print(f"step {i:2d}                 ", " ".join(f"{r[0][i]['sup']:10.4f}" for r in [base] + members + [bf]))
+    print("contrastive loss per step (fp32 / bf16):", " ".join(f"{a['contrast']:.4f}/{b['contrast']:.4f}" for a, b in zip(base[0], bf[0])))
+    mm = [_metrics(base, m) for m in members]
+    mb = _metrics(base, bf)
+    for n, m in zip(names[1:], mm + [mb]):
+        print(f"{n:>10s} vs fp32: max |lag| {m['lag']:.2f} steps, last-five-steps gap {m['tail']:.3f}, contrast {m['contrast']:.4f}, "
+              f"prototype cosine {m['proto_cos']:.4f}, weights cosine {m['w_cos']:.5f}; lags " + " ".join(f"{v:+.1f}" for v in m["lags"]))
+    # chaos-free facts, asserted absolutely
+    for h, _, _ in [base, bf] + members:
+        assert all(math.isfinite(v) for d in h for k, v in d.items() if k != "unsup")        # (unsup is NaN by definition when no pixel is valid)
+        assert np.mean([d["sup"] for d in h[-3:]]) < 0.1 * h[0]["sup"], (h[0]["sup"], h[-1]["sup"])      # the supervised loss goes down
+    assert mb["contrast"] <= 0.01, mb["contrast"]
+    # everything else relative to the envelope of the fp32 ensemble (floors: half a step of lag, the resolution of the lag measure;
+    # 1e-3 on the cosines' distance from 1)
+    env = dict(lag=max(max(m["lag"] for m in mm), 0.5), tail=max(m["tail"] for m in mm),
+               proto=max(max(1.0 - m["proto_cos"] for m in mm), 1e-3), w=max(max(1.0 - m["w_cos"] for m in mm), 1e-3))
+    print(f"fp32 ensemble envelope: lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, 1 - prototype cosine {env['proto']:.4f}, "
+          f"1 - weights cosine {env['w']:.5f};  bf16 must stay inside {ENV_C} x these")
+    assert mb["lag"] <= ENV_C * env["lag"], (mb["lag"], env["lag"])
+    assert mb["tail"] <= ENV_C * env["tail"], (mb["tail"], env["tail"])
+    assert 1.0 - mb["proto_cos"] <= ENV_C * env["proto"] and 1.0 - mb["w_cos"] <= ENV_C * env["w"], (mb, env)

@@ -140,3 +140,31 @@ def test_identity_bottlenecks_backward_lazy_mask_equals_eager_copy(shape):
     assert torch.equal(dx_l, dx_e), (dx_l.float() - dx_e.float()).abs().max().item()
     for a, b in zip(gp_l, gp_e):
         assert rel_err(a.float().cpu(), b.float().cpu()) < 1e-5       # (weight gradients: fp32 slab sums in a fixed order; identical inputs)
+
+
+def test_second_consumer_of_the_tap_raises_instead_of_adding_an_unmasked_gradient():
+    """the lazily masked residual gradient is bound to its consumer.  If the tap tensor gets a second consumer, autograd hands the
+    tapped convolution a SUM that contains the unmasked gradient: its backward must raise, never add it - under a plain loss.backward()
+    with no trainer around; and an aborted backward must leave nothing behind for the next one."""
+    from css_amd import _lib, ops
+    from css_amd.nn import HipBatchNorm2d, HipConv2d
+    torch.manual_seed(2)
+    c = 64
+    conv, bn = HipConv2d(c, c, 1, bias=False).to(dev()).train(), HipBatchNorm2d(c).to(dev()).train()
+    x = torch.randn(2, 17, 17, c).to(dev(), torch.bfloat16).requires_grad_(True)
+
+    def forward(second_consumer):
+        y, tap = conv(x, tap=True)
+        out = bn(y, res=tap, relu=True)
+        return out.float().sum() + (tap.float().sum() * 0.5 if second_consumer else 0.0)
+
+    if not ops._lazy_dres:
+        pytest.skip("CSS_BN_EAGER_DRES=1: nothing is parked")
+    with pytest.raises(_lib.CssHipError, match="second consumer"):
+        forward(True).backward()
+    # the aborted pass left its pair parked in a link of a dead graph: the next pass starts clean, runs, and its own check passes
+    x.grad = None
+    forward(False).backward()
+    torch.cuda.synchronize()
+    ops.assert_no_lazy_res_grads()
+    assert x.grad is not None and bool(torch.isfinite(x.grad.float()).all())

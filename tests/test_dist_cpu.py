@@ -141,6 +141,8 @@ def _bucket_worker(rank, world, port, q, mode="plain"):
     tr.bucket_mb = 4096 / 2 ** 20                                   # 1024 floats per bucket
     tr._grad_pg = tr._ready_order = tr._buckets = tr._span_reports = tr._span_bucket = tr._flag_pending = None
     tr._flags = [torch.zeros(1), torch.zeros(1)]
+    tr._flag_host = [torch.zeros(1), torch.zeros(1)]
+    tr._skip_flag = None
     tr.it = 0
     errs = []
     raised = []

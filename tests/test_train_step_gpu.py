@@ -113,7 +113,7 @@ def test_sgd_ema_kernel_matches_reference_optimizer(golden):
     grads = T(g["sgd_grads"])
     for i in range(5):
         gr = torch.cat([grads[i], torch.zeros(1)]).to(dev())
-        call("css_sgd_ema", p, gr, buf, ema, 4, 0.01, 0.9, 5e-4, int(i == 0), 0.5, 1.0, d, st)
+        call("css_sgd_ema", p, gr, buf, ema, 4, 0.01, 0.9, 5e-4, int(i == 0), 0.5, 1.0, None, d, st)
         assert rel_err(p[:3].cpu(), T(g["sgd_traj"])[i]) < 1e-6
     e = torch.zeros(5, device=dev())
     one = torch.ones(5, device=dev())
