@@ -14,7 +14,7 @@ unlabeled synthetic crops per GPU.  Default workload c2 = BASELINE.json configs[
 DeepLabv3+, B=16, bf16.  Weak scaling: every rank owns its own B+B crops; SyncBN statistics, prototype sums and the flat gradient are
 the only exchanges (RCCL).  Rank 0 prints ONE JSON line; at N=1 it also carries
   * ``extra.c4``: 5 steps (after 3 warm-up) of the Cityscapes-shaped 769x769 workload (BASELINE configs[3] shape on one GPU),
-  * ``extra.c5``: 3 steps (after 3) of c4 with Q=1024, N=2048, forced-valid (BASELINE configs[4] shape),
+  * ``extra.c5``: 5 steps (after 3) of c4 with Q=1024, N=2048, forced-valid (BASELINE configs[4] shape),
   * ``extra.c2_forced_valid``: 5 steps (after 3) of c2 with every unlabeled pixel valid (SURVEY 8d "forced-valid": worst-case contrastive load),
   * ``cpu_baseline``: the CPU oracle timed on the host cores.
 """
@@ -42,7 +42,7 @@ PEAK_HBM = 8.0e12                  # HBM3E spec (MI355X_MICROARCH.md; 6.29 TB/s 
 
 KINDS = ((0, "conv_fwd_other"), (1, "conv_dgrad_other"), (2, "conv_wgrad_other"), (3, "contrast_gather"), (4, "similarity"),
          (5, "igemm256_fwd"), (6, "igemm256_dgrad"), (7, "wgrad256"), (8, "bn_apply"), (9, "bn_bwd_apply"), (10, "bn_bwd_reduce"),
-         (11, "sgd_ema"), (12, "conv1x1_short_k_fwd"), (13, "conv_ws_flops"), (14, "conv_ws_bytes"))
+         (11, "sgd_ema"), (12, "conv1x1_short_k_fwd"), (13, "conv_ws_flops"), (14, "conv_ws_bytes"), (15, "igemm256_bytes"))
 WORKLOADS = {
     # name: (K, S, B, backbone, sup, Q, N, BASELINE configs index)
     "c2": (21, 513, 16, "tv", "ce", 256, 512, 1),
@@ -272,7 +272,11 @@ def rooflines(prof, dtype, workload):
                                        "(the short-K 1x1 class runs on conv_ws_kernel: see kernels.conv_ws_kernel)",
             "achieved": round(ach / 1e12, 2), "peak": peak / 1e12, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
             "traffic": traffic, "traffic_source": src, "launches_per_step": ig_n, "avg_launch_us": round(ig_ms * 1e3 / max(ig_n, 1), 2),
-            "alg_flops_per_launch": ig_fl / max(ig_n, 1)}
+            "alg_flops_per_launch": ig_fl / max(ig_n, 1),
+            # algorithmic HBM bytes of the same launches (source + weights + output once each, + addend and mask): `traffic` is read against this
+            "alg_bytes_per_launch": round(prof["igemm256_bytes"][2] / max(prof["igemm256_bytes"][1], 1)),
+            "traffic_over_alg_bytes": (round(traffic / (prof["igemm256_bytes"][2] / max(prof["igemm256_bytes"][1], 1)), 3)
+                                       if traffic and prof["igemm256_bytes"][2] > 0 else None)}
     # (keys name the kernels that run today: the big-tile class = conv_igemm_p8_kernel + conv_ws_kernel launches, forward and dgrad)
     mfma_groups = {"conv_igemm_p8_and_ws_kernels": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_p8_kernel": prof["wgrad256"],
                    "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
@@ -452,9 +456,10 @@ def main():
         d4, l4, r4, k4, m4 = run_leg("c4", n4, w4, False)
         extra["c4"] = {"workload": "BASELINE configs[3] shape on one GPU: Cityscapes-shaped, deep-stem ResNet-101, 769x769, B=8+8, K=19, OHEM",
                        "value": round(2 * m4["B"] * n4 / d4, 3), "unit": "images/s", "ms_per_step": round(d4 / n4 * 1e3, 3), "steps": n4, "warmup": w4,
-                       "roofline": {k: r4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us")},
+                       "roofline": {k: r4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us",
+                                                       "alg_bytes_per_launch", "traffic_over_alg_bytes")},
                        "step_alg_tflops": round(8 * m4["B"] * m4["fwd_flop"] / (d4 / n4) / 1e12, 2), "losses": l4}
-        n5, w5 = 3, 3
+        n5, w5 = 5, 3
         d5, l5, r5, k5, m5 = run_leg("c5", n5, w5, True)
         extra["c5"] = {"workload": "BASELINE configs[4] shape on one GPU: c4 with Q=1024, N=2048 and SURVEY 8(d) forced-valid pseudo labels (the "
                                    "stress case of the contrastive gather)",

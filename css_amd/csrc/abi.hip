@@ -29,7 +29,7 @@ int cu_count(int device) {
 
 // ---- profiling ----
 struct ProfRec { hipEvent_t a, b; int kind; double work; bool alias; };   // alias: second record over the same event pair (not pooled)
-constexpr int PROF_KINDS = 15;
+constexpr int PROF_KINDS = 16;
 bool g_prof_on = false;
 std::mutex g_prof_mu;
 std::vector<ProfRec> g_prof;       // recorded this epoch
@@ -76,11 +76,13 @@ struct ConvProf : LaunchProf {
   ProfScope* cur = nullptr;
   double hbm_bytes = 0;     // > 0: an HBM-bound shape class (short-K 1x1 forward): its launches are also filed under kind 12 with their bytes
   double ws_bytes = 0;      // algorithmic bytes of the call if it runs on conv_ws_kernel (kinds 13 / 14: FLOPs / bytes of those launches)
+  double conv_bytes = 0;    // algorithmic bytes of the call (conv_alg_bytes): the persistent 256x256-tile launches are also filed under kind 15 with them
   ConvProf(int ko, int kb, double f, hipStream_t s) : kind_other(ko), kind_big(kb), flops(f), st(s) {}
   void begin(bool big, double share, bool ws) override {
     cur = new (buf) ProfScope(big ? kind_big : kind_other, flops * share, st);
     if (hbm_bytes > 0) cur->add_alias(12, hbm_bytes * share);
     if (ws) { cur->add_alias(13, flops * share); cur->add_alias(14, ws_bytes * share); }
+    else if (big) cur->add_alias(15, conv_bytes * share);
   }
   void end() override { if (cur) { cur->~ProfScope(); cur = nullptr; } }
 };
@@ -88,6 +90,12 @@ struct ConvProf : LaunchProf {
 double conv1x1_bytes(const ConvArgs& a, int dtype) {       // a 1x1 product read and written once (+ the addend)
   const double e = dtype == CSS_BF16 ? 2 : 4;
   return ((double)a.M * a.Ktot + (double)a.M * a.Cd * (a.addend ? 2 : 1) + (double)a.Cd * a.Ktot) * e;
+}
+// algorithmic HBM bytes of one convolution call: the source tensor, the weights and the output once each (+ the addend and its bit mask)
+double conv_alg_bytes(const ConvArgs& a, int dtype) {
+  const double e = dtype == CSS_BF16 ? 2 : 4;
+  return ((double)a.N * a.Hs * a.Ws * a.Cs + (double)a.Cd * a.Ktot + (double)a.M * a.Cd * (a.addend ? 2 : 1)) * e +
+         (a.add_mask ? (double)a.M * a.Cd / (dtype == CSS_BF16 ? 8 : 4) : 0.0);
 }
 double short_k_bytes(const ConvArgs& a, int dtype) {
   if (a.R != 1 || a.S != 1 || a.Ktot > 512 || a.Cd < 4 * a.Ktot) return 0;
@@ -137,6 +145,7 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   ConvProf cp(0, 5, alg_flops, S(stream));
   cp.hbm_bytes = short_k_bytes(a, dtype);
   cp.ws_bytes = conv1x1_bytes(a, dtype);
+  cp.conv_bytes = conv_alg_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
@@ -154,6 +163,7 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   ConvProf cp(0, 5, alg_flops, S(stream));
   cp.hbm_bytes = short_k_bytes(a, dtype);
   cp.ws_bytes = conv1x1_bytes(a, dtype);
+  cp.conv_bytes = conv_alg_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
@@ -180,6 +190,7 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ConvProf cp(1, 6, alg_flops, S(stream));
   cp.ws_bytes = conv1x1_bytes(a, dtype);
+  cp.conv_bytes = conv_alg_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 static int dgrad_add_impl(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, const unsigned char* mask, int N, int H, int W, int Cin,
@@ -200,6 +211,7 @@ static int dgrad_add_impl(const void* dy, const void* w_t, void* dx, const void*
   a.M = N * H * W; a.Ktot = R * Sk * Cout;
   ConvProf cp(1, 6, alg_flops, S(stream));
   cp.ws_bytes = conv1x1_bytes(a, dtype);
+  cp.conv_bytes = conv_alg_bytes(a, dtype);
   return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,

@@ -33,7 +33,9 @@ CSS_API int css_device_cu_count(int device);
  * (launches of every kernel but the 256x256 LDS-DMA ones), 3 = contrast loss gather, 4 = similarity,
  * 5 / 6 / 7 = forward / dgrad launches of the 256-channel-panel MFMA kernels (conv_igemm_pp64_kernel, conv_igemm_pp_kernel,
  * conv_igemm_dma256_kernel, conv_ws_kernel) and conv_wgrad_dma256_kernel launches; 13 / 14 = the conv_ws_kernel launches among 5 / 6
- * again, with their FLOPs (13) and with their algorithmic bytes (14: the kernel is judged against both rooflines).
+ * again, with their FLOPs (13) and with their algorithmic bytes (14: the kernel is judged against both rooflines); 15 = the OTHER
+ * launches among 5 / 6 (the persistent 256x256-tile kernels) with the call's algorithmic bytes - source, weights, output once each,
+ * + addend and mask - so that a PMC traffic figure for that kernel can be read against them.
  * alg_work of a convolution launch = the call's algorithmic FLOPs x the share of output rows that launch covers.
  * HBM-bound kernels, alg_work = algorithmic BYTES (every operand read once, every result written once):
  * 8 = bn_apply, 9 = bn_bwd_apply, 10 = bn_bwd_reduce, 11 = sgd_ema, 12 = the write-bound 1x1 forward convolutions
