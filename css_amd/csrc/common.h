@@ -122,4 +122,15 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros in hardware, so the im2col zero padding,
+// the M / Cout / K tails and the "ghost" prefetches past the last K tile need no branches, and the compiler can keep
+// exact vmcnt counts for a prefetch distance of two tiles.  (conv.hip, conv_wgrad.hip)
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+constexpr unsigned OOB = 0x80000000u;
+__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+typedef __attribute__((address_space(3))) void lds_void;
+
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -1,6 +1,8 @@
 // Implicit-GEMM convolution for NHWC activations on gfx950 (CDNA4):
-//   conv_igemm_kernel : forward and data-gradient (one kernel, two gather modes)
-//   conv_wgrad_kernel : weight gradient (split over pixels, fp32 atomic accumulate)
+//   conv_igemm_kernel     : forward and data-gradient, register-staged (fp32 parity path, channel counts that are not whole K tiles)
+//   conv_igemm_dma_kernel : the same through LDS-DMA (narrow layers, leftover rows of the persistent kernels)
+//   css_launch_conv       : the ONE dispatch over these, conv_ws.hip (short-K 1x1), conv_p8.hip / conv_pp.hip (persistent 256x256 tiles)
+// (weight gradient: conv_wgrad.hip)
 //
 // Replaces the cuDNN convolutions the reference reaches through nn.Conv2d in
 //   generalframeworks/networks/resnet.py:24-40,119-139 (Bottleneck 1x1 / 3x3 dilated),
@@ -41,17 +43,6 @@ template <> struct Mma<float> {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
   }
 };
-
-// 16-byte buffer load: out-of-range offsets (>= num_records) return zeros in hardware, so the im2col zero padding,
-// the M / Cout / K tails and the "ghost" prefetches past the last K tile need no branches, and the compiler can keep
-// exact vmcnt counts for a prefetch distance of two tiles.
-typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
-constexpr unsigned OOB = 0x80000000u;
-__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0);
-  return make_uint4(v[0], v[1], v[2], v[3]);
-}
-
 
 // Sum of v over the lanes {l : l % CV == lane % CV} of the wave, result in every lane.  row_ror DPP adds inside 16-lane
 // rows, then v_permlane16_swap / v_permlane32_swap (gfx950) exchange rows.  The swaps are inline asm: the
@@ -467,7 +458,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvArgs a) {
 //  * sync per K tile: s_waitcnt vmcnt(6) (this wave's share of tile kt has landed, tile kt+1 may be in flight) ->
 //    s_barrier (everyone's share landed, everyone left stage (kt-1)%3) -> issue tile kt+2 into that stage -> MFMAs on kt.
 // --------------------------------------------------------------------------
-typedef __attribute__((address_space(3))) void lds_void;
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
 #ifdef CSS_DMA_NOLOAD
   asm volatile("" ::"v"(off));
@@ -789,950 +779,6 @@ __global__ __launch_bounds__(64 * NWM * NWN * NWK) void conv_igemm_dma_kernel(co
 }
 
 // --------------------------------------------------------------------------
-// 256x256x32 variant of the LDS-DMA kernel for Cout >= 256: 8 waves as 2 (pixels) x 4 (channels), 128x64 outputs per wave,
-// FOUR 32 KiB LDS stages (three K tiles = 96 KiB in flight per CU, as in the 256x128x64 kernel).  Per FLOP it moves 2/3 of
-// the global->LDS bytes and 3/4 of the LDS->register bytes of that kernel - the two walls its ablations showed (loads-only
-// and compute-only ceilings) - at the price of a coarser tile grid (the launcher sends leftovers to the 128x128 kernel).
-//  * LDS rows are 32 bf16 = 64 B, unpadded; 16-byte chunk c of row r sits at position c ^ ((r >> 2) & 3) (conflict-free
-//    ds_read_b128: 16 consecutive rows of one chunk column cover all 16 slots of a 256-byte bank row).
-//  * thread t owns position t & 3 of rows (t >> 2) + 128 i; a DMA wave-instruction covers 16 rows.
-//  * sync per K tile: s_waitcnt vmcnt(8) -> s_barrier -> issue tile kt+3 -> 16 MFMAs per wave on tile kt.
-// --------------------------------------------------------------------------
-__global__ __launch_bounds__(512) void conv_igemm_dma256_kernel(const ConvArgs a) {
-  using T = bf16_t;
-  constexpr int BM = 256, BN = 256, BK = 32, VEC = 8, NST = 4;
-  constexpr int A_IT = 2, B_IT = 2;                    // DMA wave-instructions per thread per stage (rows t>>2 + 128 i)
-  constexpr int ROWB = BK * 2;                         // 64 bytes per LDS row
-  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, ST_BYTES = A_BYTES + B_BYTES;
-  constexpr int WTM = 128, WTN = 64, TM = 4, TN = 2, CSTR = WTN + VEC;
-  static_assert(8 * 64 * CSTR * 2 <= NST * ST_BYTES, "epilogue staging (one 64-row half per wave) fits");
-  // one LDS object (see conv_igemm_dma_kernel); tail: per wave [arrival counter + pad | slot | slot] for the BN statistics
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES + 8 * 12 * 64 * 4];
-  float* sstat = reinterpret_cast<float*>(smem + NST * ST_BYTES);
-  if (a.stats && threadIdx.x < 8) reinterpret_cast<int*>(sstat)[threadIdx.x * 12 * 64] = 0;   // ordered by the main loop's barriers
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  const int nt_n = (a.Cd + BN - 1) / BN;
-  const int ntiles = gridDim.x;
-  const int q8 = ntiles >> 3, r8 = ntiles & 7;
-  const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
-  const int logical = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
-  const int m0 = a.m_begin + (logical / nt_n) * BM, n0 = (logical % nt_n) * BN;
-  const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.src), 0, (int)a.src_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wt), 0, (int)a.wt_bytes, 0x00020000);
-
-  const int prow = tid >> 2;                                   // tile row of this thread's chunks (+ 128 i)
-  const int cch = (tid & 3) ^ ((tid >> 4) & 3);                // source chunk (8 channels) this thread fetches: p ^ ((r>>2)&3)
-
-  int a_base[A_IT], a_h[A_IT], a_w[A_IT];
-#pragma unroll
-  for (int i = 0; i < A_IT; ++i) {
-    const int m = m0 + prow + i * 128;
-    if (m < a.M) {
-      const int hw = a.Hd * a.Wd;
-      const int n_img = m / hw;
-      const int rem = m - n_img * hw;
-      const int hd = rem / a.Wd;
-      const int wd = rem - hd * a.Wd;
-      a_base[i] = n_img * a.Hs * a.Ws;
-      if (a.mode == 0) {
-        a_h[i] = hd * a.stride - a.pad;
-        a_w[i] = wd * a.stride - a.pad;
-      } else {
-        a_h[i] = hd + a.pad;
-        a_w[i] = wd + a.pad;
-      }
-    } else {
-      a_base[i] = 0;
-      a_h[i] = -0x40000000;
-      a_w[i] = -0x40000000;
-    }
-  }
-  unsigned b_off[B_IT];
-#pragma unroll
-  for (int i = 0; i < B_IT; ++i) {
-    const int n = n0 + prow + i * 128;
-    b_off[i] = n < a.Cd ? (unsigned)n * (unsigned)a.Ktot * 2u : OOB;
-  }
-  int kc = cch * VEC, tr = 0, ts = 0;
-  while (kc >= a.Cs) {
-    kc -= a.Cs;
-    if (++ts == a.S) { ts = 0; ++tr; }
-  }
-  int kglob = cch * VEC;
-
-  // all-padding kernel rows are skipped, block-uniformly (see conv_igemm_dma_kernel)
-  unsigned tr_mask = 0xffffffffu;
-  int nk = (a.Ktot + BK - 1) / BK;
-  if (a.Cs % BK == 0 && a.R > 1 && a.R < 32) {
-    const int hw = a.Hd * a.Wd;
-    const int mlast = min(m0 + BM, a.M) - 1;
-    const int i0 = m0 / hw, i1 = mlast / hw;
-    const int h0 = (m0 - i0 * hw) / a.Wd, h1 = (mlast - i1 * hw) / a.Wd;
-    if (i1 - i0 <= 1) {
-      const int alo = h0, ahi = i1 == i0 ? h1 : a.Hd - 1;
-      const int blo = i1 == i0 ? h0 : 0, bhi = h1;
-      tr_mask = 0;
-      int cnt = 0;
-      for (int r = 0; r < a.R; ++r) {
-        bool v;
-        if (a.mode == 0) {
-          const int o = r * a.dil - a.pad;
-          v = (alo * a.stride + o <= a.Hs - 1 && ahi * a.stride + o >= 0) || (blo * a.stride + o <= a.Hs - 1 && bhi * a.stride + o >= 0);
-        } else {
-          const int o = a.pad - r * a.dil;
-          v = (alo + o <= (a.Hs - 1) * a.stride && ahi + o >= 0) || (blo + o <= (a.Hs - 1) * a.stride && bhi + o >= 0);
-        }
-        if (v) { tr_mask |= 1u << r; ++cnt; }
-      }
-      nk = cnt * a.S * (a.Cs / BK);
-      while (tr < a.R && !((tr_mask >> tr) & 1)) { ++tr; kglob += a.S * a.Cs; }
-    }
-  }
-
-  unsigned offA[A_IT];
-  auto tap_offsets = [&]() {
-    const bool tap_ok = tr < a.R;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-      int hs, ws;
-      bool ok = tap_ok;
-      if (a.mode == 0) {
-        hs = a_h[i] + tr * a.dil;
-        ws = a_w[i] + ts * a.dil;
-      } else {
-        const int th = a_h[i] - tr * a.dil, tw = a_w[i] - ts * a.dil;
-        ok = ok && th >= 0 && tw >= 0;
-        if (a.stride == 2) {
-          ok = ok && !((th | tw) & 1);
-          hs = th >> 1;
-          ws = tw >> 1;
-        } else {
-          hs = th;
-          ws = tw;
-        }
-      }
-      ok = ok && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
-      const unsigned off = (unsigned)((a_base[i] + hs * a.Ws + ws) * a.lds + kc) * 2u;
-      offA[i] = ok ? off : OOB;
-    }
-  };
-  tap_offsets();
-  // wave-uniform LDS destinations: instruction i of wave w covers chunks [i*512 + w*64, +64) of the A (or B) image
-  auto issue = [&](int stage) {
-    unsigned char* sa = smem + stage * ST_BYTES + wave * 1024;
-    unsigned char* sb = sa + A_BYTES;
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) dma16(rs_a, sa + i * 8192, offA[i]);
-    const unsigned kb = kglob < a.Ktot ? (unsigned)kglob * 2u : OOB;
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) dma16(rs_b, sb + i * 8192, (b_off[i] | kb) & OOB ? OOB : b_off[i] + kb);
-    kglob += BK;
-    kc += BK;
-    if (kc >= a.Cs) {
-      do {
-        kc -= a.Cs;
-        if (++ts == a.S) {
-          ts = 0;
-          ++tr;
-          while (tr < a.R && !((tr_mask >> tr) & 1)) { ++tr; kglob += a.S * a.Cs; }
-        }
-      } while (kc >= a.Cs);
-      tap_offsets();
-    } else {
-#pragma unroll
-      for (int i = 0; i < A_IT; ++i) offA[i] += (offA[i] & OOB) ? 0u : (unsigned)(BK * 2);
-    }
-  };
-
-  f32x16 acc[TN][TM];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int l31 = lane & 31, lh = lane >> 5;
-  const int xr = (l31 >> 2) & 3;
-  int koff[2];                                         // swizzled byte offset of k-step ks inside a row
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) koff[ks] = (((2 * ks + lh) ^ xr) << 4);
-  const int a_row = (wm * WTM + l31) * ROWB, b_row = A_BYTES + (wn * WTN + l31) * ROWB;
-  auto compute = [&](int stage) {
-    const unsigned char* sbase = smem + stage * ST_BYTES;
-    bf16x8 fw[2][TN], fa[2][TM];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fw[ks][i] = *reinterpret_cast<const bf16x8*>(sbase + b_row + i * 32 * ROWB + koff[ks]);
-#pragma unroll
-      for (int j = 0; j < TM; ++j) fa[ks][j] = *reinterpret_cast<const bf16x8*>(sbase + a_row + j * 32 * ROWB + koff[ks]);
-    }
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][i], fa[ks][j], acc[i][j], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
-  };
-
-  issue(0);
-  issue(1);
-  issue(2);
-  int st_c = 0, st_i = 3;
-  for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    issue(st_i);                       // tile kt+3 (past the end: all-OOB = zeros into a free stage)
-    compute(st_c);
-    st_c = (st_c + 1) & 3;
-    st_i = (st_i + 1) & 3;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must land before the stages are reused below
-  __builtin_amdgcn_s_barrier();
-
-  // ---- epilogue, one 64-pixel half of the wave tile at a time: accumulators -> wave-private LDS -> 16-byte row stores
-  T* Cw = reinterpret_cast<T*>(smem) + wave * (64 * CSTR);
-#pragma unroll
-  for (int half = 0; half < 2; ++half) {
-#pragma unroll
-    for (int i = 0; i < TN; ++i) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int nl = i * 32 + 8 * q + 4 * lh;
-        float bv[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.bias) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const int n = n0 + wn * WTN + nl + e;
-            bv[e] = n < a.Cd ? a.bias[n] : 0.f;
-          }
-        }
-#pragma unroll
-        for (int jj = 0; jj < 2; ++jj) {
-          T* p = Cw + (jj * 32 + l31) * CSTR + nl;
-          union { T e[4]; uint2 u2; } pk;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) pk.e[e] = (T)(acc[i][2 * half + jj][4 * q + e] + bv[e]);
-          *reinterpret_cast<uint2*>(p) = pk.u2;
-        }
-      }
-    }
-    __syncthreads();
-    store_wave_tile<T, 64, WTN, CSTR, BN, true>(a, Cw, m0 + wm * WTM + half * 64, n0 + wn * WTN, half, lane, sstat + wave * 12 * WTN);
-    __syncthreads();
-  }
-}
-
-// --------------------------------------------------------------------------
-// Weight gradient: dW[n][k] += sum_m dY[m][n] * X(m, k)     (k = (r, s, c))
-// Both operands are contiguous along the NON-reduced index in memory, so the bf16 path
-// keeps the tiles as loaded ([pixel][channel]) and reads MFMA fragments with the gfx950
-// transposing LDS read (ds_read_b64_tr_b16); the fp32 path uses ds_read_b32.
-// --------------------------------------------------------------------------
-template <typename T> struct WgFrag;
-template <> struct WgFrag<bf16_t> {
-  static constexpr int KS = 16;
-  typedef bf16x8 frag;
-  // tile[kk][col] with row stride RS (elements). Operand element (idx = lane&31, kk = 8*(lane>>5)+j).
-  static __device__ __forceinline__ frag load(const bf16_t* tile, int RS, int kk0, int col0, int lane) {
-    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
-    const bf16_t* ad = tile + (kk0 + 8 * (g >> 1) + q) * RS + col0 + 16 * (g & 1) + 4 * p;
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad));
-    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad + 4 * RS));
-    union { struct { s16x4 a, b; } s; frag f; } u;
-    u.s.a = lo;
-    u.s.b = hi;
-    return u.f;
-  }
-  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-  }
-};
-template <> struct WgFrag<float> {
-  static constexpr int KS = 2;
-  typedef float frag;
-  static __device__ __forceinline__ frag load(const float* tile, int RS, int kk0, int col0, int lane) {
-    return tile[(kk0 + (lane >> 5)) * RS + col0 + (lane & 31)];
-  }
-  static __device__ __forceinline__ f32x16 mma(frag a, frag b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-  }
-};
-
-// BN_: output-channel tile, BKC: k-column tile, BP: pixels per iteration
-template <typename T, int BN_, int BKC, int BP>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
-  using WF = WgFrag<T>;
-  constexpr int VEC = 16 / sizeof(T);
-  constexpr int YV = BN_ / VEC, XV = BKC / VEC;        // vectors per tile row
-  constexpr int YS = BN_ + 64 / (int)sizeof(T);        // row stride: +64 B keeps the 4 rows of a tr-read on disjoint banks
-  constexpr int XS = BKC + 64 / (int)sizeof(T);
-  constexpr int Y_RPP = 256 / YV, X_RPP = 256 / XV;
-  constexpr int Y_IT = BP / Y_RPP, X_IT = BP / X_RPP;
-  constexpr int WTN = BN_ / 2, WTK = BKC / 2;          // 2x2 waves
-  constexpr int TN = WTN / 32, TK = WTK / 32;
-  static_assert(BP % Y_RPP == 0 && BP % X_RPP == 0, "mapping");
-  __shared__ __attribute__((aligned(16))) T smem[2 * BP * (YS + XS)];
-  T* Ysm = smem;                 // [2][BP][YS]
-  T* Xsm = smem + 2 * BP * YS;   // [2][BP][XS]
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wn = wave >> 1, wk = wave & 1;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; all (k-column, cout) tiles of one pixel slice
-  // are given to ONE XCD so that the slice of dY / X is fetched into a single L2 (measured before: 3.7x over-fetch).
-  const int per_z = a.tiles_k * a.tiles_n;
-  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
-  if (zz >= a.splits) return;
-  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
-  const int m_begin = zz * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
-  const T* __restrict__ x = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ dy = reinterpret_cast<const T*>(a.dy);
-
-  // X-tile column owned by this thread: fixed (tap, channel) for the whole reduction
-  const int xv = tid % XV, xrow = tid / XV;
-  const int kcol = k0 + xv * VEC;
-  const bool k_ok = kcol < a.Ktot;
-  int tap = k_ok ? kcol / a.Cs : 0;
-  const int xc = k_ok ? kcol - tap * a.Cs : 0;
-  const int tr = tap / a.S, ts = tap - tr * a.S;
-  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
-  const int yv = tid % YV, yrow = tid / YV;
-  const int ncol = n0 + yv * VEC;
-  const bool n_ok = ncol < a.Cd;
-
-  const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
-  // branch-free loads of the pixel block starting at mb (rows >= m_end, padding taps and tail columns read as zeros)
-  auto issue = [&](uint4 (&rx)[X_IT], uint4 (&ry)[Y_IT], int mb) {
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i) {
-      const int m = mb + xrow + i * X_RPP;
-      const uint32_t mm = (uint32_t)min(m, a.M - 1);
-      const uint32_t n_img = fdiv(mm, a.fd_hw);
-      const uint32_t rem = mm - n_img * a.fd_hw.d;
-      const uint32_t hd = fdiv(rem, a.fd_w);
-      const uint32_t wd = rem - hd * a.fd_w.d;
-      const int hs = (int)hd * a.stride + dh, ws = (int)wd * a.stride + dw_;
-      const bool ok = k_ok && m < m_end && (unsigned)hs < (unsigned)a.Hs && (unsigned)ws < (unsigned)a.Ws;
-      const unsigned off = (unsigned)(((int)n_img * a.Hs * a.Ws + hs * a.Ws + ws) * a.ldx + xc) * (unsigned)sizeof(T);
-      rx[i] = bload16(rs_x, ok ? off : OOB);
-    }
-#pragma unroll
-    for (int i = 0; i < Y_IT; ++i) {
-      const int m = mb + yrow + i * Y_RPP;
-      const unsigned off = (unsigned)(m * a.ldy + ncol) * (unsigned)sizeof(T);
-      ry[i] = bload16(rs_y, (n_ok && m < m_end) ? off : OOB);
-    }
-  };
-  auto store_tiles = [&](const uint4 (&rx)[X_IT], const uint4 (&ry)[Y_IT], int buf) {
-    T* Yb = Ysm + buf * BP * YS;
-    T* Xb = Xsm + buf * BP * XS;
-#pragma unroll
-    for (int i = 0; i < X_IT; ++i)
-      *reinterpret_cast<uint4*>(Xb + (xrow + i * X_RPP) * XS + xv * VEC) = rx[i];
-#pragma unroll
-    for (int i = 0; i < Y_IT; ++i)
-      *reinterpret_cast<uint4*>(Yb + (yrow + i * Y_RPP) * YS + yv * VEC) = ry[i];
-  };
-
-  f32x16 acc[TN][TK];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  auto compute = [&](int cur) {
-    const T* Yb = Ysm + cur * BP * YS;
-    const T* Xb = Xsm + cur * BP * XS;
-#pragma unroll
-    for (int ks = 0; ks < BP / WF::KS; ++ks) {
-      typename WF::frag fy[TN], fx[TK];
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fy[i] = WF::load(Yb, YS, ks * WF::KS, wn * WTN + i * 32, lane);
-#pragma unroll
-      for (int j = 0; j < TK; ++j) fx[j] = WF::load(Xb, XS, ks * WF::KS, wk * WTK + j * 32, lane);
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = WF::mma(fy[i], fx[j], acc[i][j]);
-    }
-  };
-
-  const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit <= 0) return;
-  // two pixel blocks in flight (blocks past m_end are all-OOB loads = zeros)
-  uint4 rx0[X_IT], ry0[Y_IT], rx1[X_IT], ry1[Y_IT];
-  int mb = m_begin;
-  issue(rx0, ry0, mb); mb += BP;
-  issue(rx1, ry1, mb); mb += BP;
-  store_tiles(rx0, ry0, 0);
-  __syncthreads();
-  for (int it = 0;;) {
-    issue(rx0, ry0, mb); mb += BP;
-    compute(0);
-    store_tiles(rx1, ry1, 1);
-    __syncthreads();
-    if (++it >= nit) break;
-    issue(rx1, ry1, mb); mb += BP;
-    compute(1);
-    store_tiles(rx0, ry0, 0);
-    __syncthreads();
-    if (++it >= nit) break;
-  }
-  // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
-  const int l31 = lane & 31, lh = lane >> 5;
-  if (a.ws) {
-    // partial tile of this pixel slice -> its own BN_ x BKC fp32 slab of the workspace with plain stores; wgrad_slab_reduce_gen_kernel adds
-    // the slices in slice order (the weight gradient is bit-reproducible; the atomics below add in arrival order)
-    float* slab = a.ws + ((size_t)t * a.splits + zz) * (BN_ * BKC);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        const int kl = wk * WTK + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[nl * BKC + kl] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int k = k0 + wk * WTK + j * 32 + l31;
-      if (k >= a.Ktot) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
-      }
-    }
-}
-
-// --------------------------------------------------------------------------
-// bf16 weight gradient for Cout >= 256: 256 (cout) x 256 (k columns) tile, 32 pixels per step, 8 waves (2 x 4, 128 x 64
-// each), FOUR 32 KiB LDS stages filled by LDS-DMA (three steps in flight) - half the global->LDS bytes per FLOP of the
-// 128x128 kernel above.  Tiles stay [pixel][channel] as loaded; MFMA fragments come from ds_read_b64_tr_b16.
-//  * LDS rows are 256 channels = 512 B, unpadded (a DMA wave-instruction writes 2 rows).  A transposing read touches 4
-//    consecutive rows x 64 B per half-wave, so the 64-byte block b of row r is stored at block b ^ (r & 3): the 4 rows
-//    then sit on 4 disjoint bank groups.  The swizzle is applied to the per-lane SOURCE column and on the fragment reads.
-//  * thread t owns 16-byte position t & 31 of rows (t >> 5) + 16 i: (r & 3) is the same for all of them, so its source
-//    column - and for the X tile its (tap, channel) - is fixed for the whole reduction.
-// --------------------------------------------------------------------------
-// LDS-DMA as inline asm (M0 = wave-uniform LDS base).  Used by the weight-gradient kernel: with the builtin the waitcnt
-// pass knows LDS is being written and puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 (it cannot tell that
-// the stage being read is not the one in flight), which would serialise the three-steps-in-flight pipeline.  Ordering is
-// this kernel's own job: counted s_waitcnt vmcnt + s_barrier before a stage is read, as in the forward kernels.
-__device__ __forceinline__ void dma16_asm(u32x4 rsrc, void* lds_wave_base, unsigned off) {
-  const unsigned lds_off = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lds_void*)lds_wave_base);
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(off), "s"(rsrc) : "memory");
-}
-// (the LDS byte address as a wave-uniform integer: no generic -> LDS pointer conversion, with its null check, per instruction)
-__device__ __forceinline__ void dma16_lds(u32x4 rsrc, unsigned lds_off, unsigned off) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_off), "v"(off), "s"(rsrc) : "memory");
-}
-__device__ __forceinline__ u32x4 raw_rsrc(const void* base, unsigned bytes) {
-  const unsigned long long b = reinterpret_cast<unsigned long long>(base);
-  u32x4 r = {(unsigned)b, (unsigned)(b >> 32), bytes, 0x00020000u};
-  return r;
-}
-
-__device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0, int col0, int lane) {
-  const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
-  const int R = kk0 + 8 * (g >> 1) + q, C = col0 + 16 * (g & 1) + 4 * p;
-  const unsigned char* ad = tile + R * 512 + ((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
-  typedef __attribute__((address_space(3))) s16x4 lds_v4;
-  union { struct { s16x4 a, b; } s; bf16x8 f; } u;
-  u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad));
-  u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(ad + 4 * 512));
-  return u.f;
-}
-
-// STAG (r03): the two waves of a SIMD (wn = 0 / 1) run the same program with one barrier per step, i.e. in lockstep: both read their
-// fragments, then both queue for the SIMD's one matrix pipe.  With STAG the second cout half defers the MFMAs of each step's second
-// 16-pixel half by one step (its fragments stay in registers across the barrier): after a barrier it multiplies while the first half
-// reads, then reads while the first half multiplies (MI355X_MICROARCH.md, Two waves per SIMD, item 9).  Same MFMA order per
-// accumulator, so the result is bit-identical.
-template <bool STAG>
-__global__ __launch_bounds__(512) void conv_wgrad_dma256_kernel(const WgradArgs a) {
-  constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
-  constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
-  constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 2, wk = wave & 3;
-  // XCD-aware order as in conv_wgrad_kernel: all tiles of one pixel slice run on one XCD
-  const int per_z = a.tiles_k * a.tiles_n;
-  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
-  if (zz >= a.splits) return;
-  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
-  const int m_begin = zz * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
-  const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit <= 0) return;
-
-  const int prow = tid >> 5;                                             // tile row of this thread's chunks (+ 16 i)
-  const int schunk = ((((tid & 31) >> 2) ^ (prow & 3)) << 2) | (tid & 3);  // source 16-byte column of those chunks
-  const int kcol = k0 + schunk * 8;
-  const bool k_ok = kcol < a.Ktot;
-  const int tap = k_ok ? kcol / a.Cs : 0;
-  const int xc = k_ok ? kcol - tap * a.Cs : 0;
-  const int tr = tap / a.S, ts = tap - tr * a.S;
-  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
-  const int ncol = n0 + schunk * 8;
-  const bool n_ok = ncol < a.Cd;
-
-  const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
-  // Issue side.  Every thread walks two pixel rows (prow, prow + 16) through the slice in steps of BP = 32 pixels; the step is a
-  // mixed-radix addition on (image, hd, wd) with one carry per digit, and the byte offsets into x and dy move by constants picked
-  // by the carries - a handful of full-rate VALU instructions per row where the first version re-derived (image, hd, wd) with two
-  // magic divisions, 64-bit multiply-adds and three 32-bit multiplies per row and step (~110 instructions per step and wave next to
-  // 16 MFMAs).  Rows >= m_end, padding taps and tail columns land as zeros (out-of-range offset).
-  const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;            // BP = (d_n * Hd + d_h) * Wd + d_w
-  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
-  const int xrow = a.ldx * 2;                                                       // bytes per source pixel
-  const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
-  const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;                               // no carry
-  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;                        // extra when wd / hd wrap
-  const int ystep = BP * a.ldy * 2;
-  int r_m[2], r_hs[2], r_ws[2];          // row, source coordinates of my tap (may be outside the image: padding)
-  unsigned r_xo[2], r_yo[2];             // byte offsets of my 16-byte chunk in x and dy
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m_begin + prow + i * 16;
-    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
-    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
-    const uint32_t hd = fdiv(rem, a.fd_w);
-    const uint32_t wd = rem - hd * a.fd_w.d;
-    r_m[i] = m;
-    r_hs[i] = (int)hd * a.stride + dh;
-    r_ws[i] = (int)wd * a.stride + dw_;
-    r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
-    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
-  }
-  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;   // source coordinate of the last output row / column
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
-  auto issue = [&](int stage) {          // the next pixel block of the slice -> stage; advances the walk
-    const unsigned sy = lds0 + (unsigned)stage * ST_BYTES, sx = sy + T_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) dma16_lds(rs_y, sy + i * 8192, (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool ok = k_ok && r_m[i] < m_end && (unsigned)r_hs[i] < (unsigned)a.Hs && (unsigned)r_ws[i] < (unsigned)a.Ws;
-      dma16_lds(rs_x, sx + i * 8192, ok ? r_xo[i] : OOB);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      r_m[i] += BP;
-      r_yo[i] += (unsigned)ystep;
-      int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
-      int dx = D0;
-      const bool cw = ws > ws_hi;
-      ws -= cw ? a.Wd * a.stride : 0;
-      hs += cw ? a.stride : 0;
-      dx += cw ? Dw : 0;
-      const bool ch = hs > hs_hi;
-      hs -= ch ? a.Hd * a.stride : 0;
-      dx += ch ? Dh : 0;
-      r_ws[i] = ws;
-      r_hs[i] = hs;
-      r_xo[i] += (unsigned)dx;
-    }
-  };
-
-  f32x16 acc[TN][TK];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  bf16x8 fy[2][TN], fx[2][TK];          // fragments of the two 16-pixel halves of a stage
-  auto read_frags = [&](int stage, int ks) {
-    const unsigned char* Yb = smem + stage * ST_BYTES;
-    const unsigned char* Xb = Yb + T_BYTES;
-#pragma unroll
-    for (int i = 0; i < TN; ++i) fy[ks][i] = wg_frag_sw(Yb, ks * 16, wn * WTN + i * 32, lane);
-#pragma unroll
-    for (int j = 0; j < TK; ++j) fx[ks][j] = wg_frag_sw(Xb, ks * 16, wk * WTK + j * 32, lane);
-  };
-  auto mma = [&](int ks) {
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[ks][i], fx[ks][j], acc[i][j], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
-  };
-
-  issue(0);
-  issue(1);
-  issue(2);
-  int st_c = 0, st_i = 3;
-  if (STAG && wn == 1) {
-    for (int it = 0; it < nit; ++it) {
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (it > 0) mma(1);                 // second half of the previous step (fragments kept across the barrier)
-      __builtin_amdgcn_sched_barrier(0);
-      read_frags(st_c, 0);
-      read_frags(st_c, 1);                // (must be complete before the next barrier: the stage is refilled after it)
-      __builtin_amdgcn_sched_barrier(0);
-      issue(st_i);
-      __builtin_amdgcn_sched_barrier(0);
-      mma(0);
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      st_c = (st_c + 1) & 3;
-      st_i = (st_i + 1) & 3;
-    }
-    mma(1);
-  } else
-  for (int it = 0; it < nit; ++it) {
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // fragment reads first, then the LDS-DMA issue and the walk's ALU work while the reads are in flight, then the MFMAs (issue ahead
-    // of the reads: +2 % time; a software pipeline inside the wave - reads of one 16-pixel half under the MFMAs of the other, with the
-    // barrier between them - +4 %: the two waves of a SIMD already cover each other, profiles/r02_conv_ablation.txt section 6)
-    read_frags(st_c, 0);
-    read_frags(st_c, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    issue(st_i);                        // step it+3 (past m_end: all-OOB = zeros into a free stage)
-    __builtin_amdgcn_sched_barrier(0);
-    mma(0);
-    mma(1);
-    st_c = (st_c + 1) & 3;
-    st_i = (st_i + 1) & 3;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // ghost DMAs must have landed before the workgroup's LDS is released
-  // D[row -> n][col -> k]: one 128-byte fp32 segment per half-wave per accumulator register
-  const int l31 = lane & 31, lh = lane >> 5;
-  if (a.ws) {
-    // partial tile of this pixel slice -> its own 256 x 256 fp32 slab of the workspace with PLAIN stores (wgrad_slab_reduce_kernel
-    // adds the slices up in a fixed order): fp32 atomics run at ~1.3 TB/s chip-wide (MI355X_MICROARCH.md) - 504 workgroups x
-    // 256 KiB took longer than the MFMAs of a layer-3 weight gradient - plain stores of the same shape at ~6 TB/s
-    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        const int kl = wk * WTK + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[nl * 256 + kl] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int k = k0 + wk * WTK + j * 32 + l31;
-      if (k >= a.Ktot) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
-      }
-    }
-}
-
-// --------------------------------------------------------------------------
-// conv_wgrad_p8_kernel (r03): conv_wgrad_dma256_kernel's tile, fragments, walk and epilogue on the phase structure of conv_p8.hip.
-// What the yardstick GEMM and conv_igemm_p8_kernel taught (profiles/r03_p8_phase_stamps.txt): a load segment must hold nothing but
-// the fragment reads and the LDS-DMA issue - every VALU / SALU instruction and branch in it delays the barrier its SIMD partner's MFMA
-// segment ends on - and the two waves of a SIMD alternate cleanly only when both segments are short.  So a 32-pixel step becomes two
-// phases of one 16-pixel half each:
-//     [12 ds_read_b64_tr_b16 of (stage, half h) | Y piece h + X piece h of step t+3 | s_waitcnt vmcnt(10)]  s_barrier
-//     [lgkmcnt(0) | 8 MFMAs 32x32x16, the walk of pixel row h and the next phase's offsets spread between them]   s_barrier
-// with the second cout half (= the other wave of every SIMD) one barrier behind.  A thread's two LDS-DMA rows are pixel rows
-// prow and prow + 16 of a stage, i.e. piece i IS half i, so a half is restaged two phases after its last read (the template's rule),
-// and `vmcnt(10)` (five phases' pieces stay in flight) retires the half that the NEXT phase reads.  Same MFMA order per accumulator
-// as conv_wgrad_dma256_kernel: bit-identical results.
-__global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
-  constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
-  constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
-  constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 2, wk = wave & 3;
-  const int per_z = a.tiles_k * a.tiles_n;
-  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
-  if (zz >= a.splits) return;
-  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
-  const int m_begin = zz * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
-  const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit <= 0) return;
-
-  const int prow = tid >> 5;
-  const int schunk = ((((tid & 31) >> 2) ^ (prow & 3)) << 2) | (tid & 3);
-  const int kcol = k0 + schunk * 8;
-  const bool k_ok = kcol < a.Ktot;
-  const int tap = k_ok ? kcol / a.Cs : 0;
-  const int xc = k_ok ? kcol - tap * a.Cs : 0;
-  const int tr = tap / a.S, ts = tap - tr * a.S;
-  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
-  const int ncol = n0 + schunk * 8;
-  const bool n_ok = ncol < a.Cd;
-
-  const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
-  const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;
-  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
-  const int xrow = a.ldx * 2;
-  const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
-  const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;
-  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;
-  const int ystep = BP * a.ldy * 2;
-  int r_m[2], r_hs[2], r_ws[2];
-  unsigned r_xo[2], r_yo[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m_begin + prow + i * 16;
-    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
-    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
-    const uint32_t hd = fdiv(rem, a.fd_w);
-    const uint32_t wd = rem - hd * a.fd_w.d;
-    r_m[i] = m;
-    r_hs[i] = (int)hd * a.stride + dh;
-    r_ws[i] = (int)wd * a.stride + dw_;
-    r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
-    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
-  }
-  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
-  // offsets of pixel row i as it stands (OOB: past the slice / padding / tail columns -> zeros), then the row moves on by BP pixels
-  auto row_offsets = [&](int i, unsigned& vy, unsigned& vx) {
-    vy = (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB;
-    const bool ok = k_ok && r_m[i] < m_end && (unsigned)r_hs[i] < (unsigned)a.Hs && (unsigned)r_ws[i] < (unsigned)a.Ws;
-    vx = ok ? r_xo[i] : OOB;
-    asm volatile("" : "+v"(vy), "+v"(vx));     // (pinned: the optimizer must not sink this into the load segment that uses it)
-    r_m[i] += BP;
-    r_yo[i] += (unsigned)ystep;
-    int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
-    int dx = D0;
-    const bool cw = ws > ws_hi;
-    ws -= cw ? a.Wd * a.stride : 0;
-    hs += cw ? a.stride : 0;
-    dx += cw ? Dw : 0;
-    const bool ch = hs > hs_hi;
-    hs -= ch ? a.Hd * a.stride : 0;
-    dx += ch ? Dh : 0;
-    r_ws[i] = ws;
-    r_hs[i] = hs;
-    r_xo[i] += (unsigned)dx;
-  };
-  auto stage_half = [&](int stage, int i, unsigned vy, unsigned vx) {
-    const unsigned sy = lds0 + (unsigned)stage * ST_BYTES + (unsigned)i * 8192u;
-    dma16_lds(rs_y, sy, vy);
-    dma16_lds(rs_x, sy + T_BYTES, vx);
-  };
-
-  f32x16 acc[TN][TK];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: steps 0, 1, 2 (data phases 0..5); offsets of data phase 6 ready for the first phase's issue
-  unsigned vy, vx;
-#pragma unroll
-  for (int st = 0; st < 3; ++st)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      row_offsets(i, vy, vx);
-      stage_half(st, i, vy, vx);
-    }
-  row_offsets(0, vy, vx);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // data phase 0 has landed
-  __builtin_amdgcn_s_barrier();
-  if (wn == 1) __builtin_amdgcn_s_barrier();            // the second cout half runs one barrier behind
-  asm volatile("" ::: "memory");
-
-  // LDS byte addresses of my fragment reads in the stage being multiplied (half 0; half 1 = 16 rows = + 8192), see wg_frag_sw; they move
-  // on to the next stage inside phase 1's MFMA segment
-  unsigned fad[TN + TK];
-  {
-    const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
-    const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * (g >> 1) + q) * 512u;
-#pragma unroll
-    for (int k = 0; k < TN + TK; ++k) {
-      const int C = (k < TN ? wn * WTN + k * 32 : wk * WTK + (k - TN) * 32) + 16 * (g & 1) + 4 * pp;
-      fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
-    }
-  }
-  typedef __attribute__((address_space(3))) s16x4 wgp_lds_v4;
-  auto frag = [&](unsigned ad) {
-    union { struct { s16x4 a, b; } s; bf16x8 f; } u;
-    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)ad);
-    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
-    return u.f;
-  };
-  int st_c = 0, st_i = 3;
-  for (int it = 0; it < nit; ++it) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      bf16x8 fy[TN], fx[TK];
-      // ---- load segment: fragments of half h, pieces of half h of step it+3, one counted wait ----
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fy[i] = frag(fad[i] + h * 8192);
-#pragma unroll
-      for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j] + h * 8192);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_half(st_i, h, vy, vx);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // the half the NEXT phase reads has landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- MFMA segment: 8 MFMAs + the walk of the row the next phase issues (+ the next stage's read addresses) ----
-      row_offsets(h ^ 1, vy, vx);
-      if (h == 1) {
-        const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
-#pragma unroll
-        for (int k = 0; k < TN + TK; ++k) {
-          fad[k] += d;
-          asm volatile("" : "+v"(fad[k]));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    st_c = (st_c + 1) & 3;
-    st_i = (st_i + 1) & 3;
-  }
-  if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
-  const int l31 = lane & 31, lh = lane >> 5;
-  if (a.ws) {
-    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        const int kl = wk * WTK + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[nl * 256 + kl] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int k = k0 + wk * WTK + j * 32 + l31;
-      if (k >= a.Ktot) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
-      }
-    }
-}
-
-// dw[n][k] += sum over the pixel slices of ws[tile][slice][n - n0][k - k0] (fixed order: the weight gradient is bit-reproducible).
-// grid = (64, tiles): block (bx, t) owns rows 4 bx .. 4 bx + 3 of tile t; thread = 4 consecutive k columns.
-__global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
-                                                                int Cd, int Ktot) {
-  const int t = blockIdx.y;
-  const int k0 = (t % tiles_k) * 256, n0 = (t / tiles_k) * 256;
-  const int nl = blockIdx.x * 4 + (threadIdx.x >> 6), kl = (threadIdx.x & 63) * 4;
-  const int n = n0 + nl, k = k0 + kl;
-  if (n >= Cd || k >= Ktot) return;
-  const float4* p = reinterpret_cast<const float4*>(ws + (size_t)t * splits * (256 * 256) + nl * 256 + kl);
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-  int z = 0;
-  for (; z + 3 < splits; z += 4) {        // four slabs in flight
-    const float4 v0 = p[(size_t)(z + 0) * (256 * 256 / 4)], v1 = p[(size_t)(z + 1) * (256 * 256 / 4)];
-    const float4 v2 = p[(size_t)(z + 2) * (256 * 256 / 4)], v3 = p[(size_t)(z + 3) * (256 * 256 / 4)];
-    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-    s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-    s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
-    s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
-  }
-  for (; z < splits; ++z) {
-    const float4 v0 = p[(size_t)z * (256 * 256 / 4)];
-    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-  }
-  const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
-  float* o = dw + (size_t)n * Ktot + k;
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (k + e < Ktot) o[e] += r[e];
-}
-
-// The same for the BN x BKC tiles of conv_wgrad_kernel (128 x 128 bf16, 64 x 64 fp32): grid = (BN / 4, tiles), thread = 4 consecutive
-// k columns of one row (BKC / 4 threads per row, 1024 / BKC rows per block), slices in order.
-template <int BN_, int BKC>
-__global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
-                                                                    int Cd, int Ktot) {
-  constexpr int TPR = BKC / 4, RPB = 256 / TPR;            // threads per tile row, rows per block
-  const int t = blockIdx.y;
-  const int k0 = (t % tiles_k) * BKC, n0 = (t / tiles_k) * BN_;
-  const int nl = blockIdx.x * RPB + threadIdx.x / TPR, kl = (threadIdx.x % TPR) * 4;
-  const int n = n0 + nl, k = k0 + kl;
-  if (nl >= BN_ || n >= Cd || k >= Ktot) return;
-  const float4* p = reinterpret_cast<const float4*>(ws + (size_t)t * splits * (BN_ * BKC) + nl * BKC + kl);
-  constexpr size_t SL = (size_t)BN_ * BKC / 4;
-  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
-  int z = 0;
-  for (; z + 3 < splits; z += 4) {
-    const float4 v0 = p[(size_t)(z + 0) * SL], v1 = p[(size_t)(z + 1) * SL], v2 = p[(size_t)(z + 2) * SL], v3 = p[(size_t)(z + 3) * SL];
-    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-    s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
-    s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
-    s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
-  }
-  for (; z < splits; ++z) {
-    const float4 v0 = p[(size_t)z * SL];
-    s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
-  }
-  const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
-  float* o = dw + (size_t)n * Ktot + k;
-#pragma unroll
-  for (int e = 0; e < 4; ++e)
-    if (k + e < Ktot) o[e] += r[e];
-}
-
-// --------------------------------------------------------------------------
 // host-side launchers (called from abi.cpp through these C++ entry points)
 // --------------------------------------------------------------------------
 // 128-row tiles (leftover rows of the big-tile kernels, layers with Cout <= 64): LDS-DMA instances; CSS_SMALL_DMA=0 selects the
@@ -1758,19 +804,17 @@ static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
   }
 }
 
-// rows per statistics slab pair of a forward launch (see css_conv2d_forward_bnstats): 272 when the 272-row persistent tiling is used
-// ONE statement of which tiling a bf16 launch takes (css_launch_conv branches on it, css_conv2d_forward_bnstats_tile_rows reports it: the
-// statistics slabs bn_reduce_slabs_kernel reads are laid out by this number, so the two must not be able to drift apart)
-enum ConvPlan { PLAN_OTHER = 0, PLAN_WS = 1, PLAN_PP272 = 2, PLAN_TILE256 = 3 };
+// ONE statement of which kernel family a bf16 launch takes (css_launch_conv branches on it).  Every family lays its statistics slabs out
+// per 256-row tile (two 128-row slabs): css_conv_tile_rows_ is what css_conv2d_forward_bnstats_tile_rows reports to the stage-2 kernel.
+enum ConvPlan { PLAN_OTHER = 0, PLAN_WS = 1, PLAN_TILE256 = 3 };
 static ConvPlan conv_plan(const ConvArgs& a, int dtype, int n_cu) {
   static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr, no_256 = getenv("CSS_NO_DMA256_CONV") != nullptr;
   if (dtype != CSS_BF16 || no_dma || no_256) return PLAN_OTHER;
   if (css_conv_ws_supported(a, n_cu)) return PLAN_WS;                    // conv_ws.hip: 128-row slabs, as the 256-row tiles
-  if (a.Cd >= 256 && !a.add_mask && css_conv_pp_plan(a, n_cu) == 272) return PLAN_PP272;
-  if (a.Cd >= 256) return PLAN_TILE256;
+  if (a.Cd >= 256 && css_conv_pp_plan(a, n_cu) != 0) return PLAN_TILE256;   // persistent 256x256 tiles (conv_p8.hip / conv_pp.hip)
   return PLAN_OTHER;
 }
-int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) { return conv_plan(a, dtype, n_cu) == PLAN_PP272 ? 272 : 256; }
+int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu) { (void)a; (void)dtype; (void)n_cu; return 256; }
 
 int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   auto P0 = [&](bool big, double share, bool ws = false) { if (prof) prof->begin(big, share, ws); };
@@ -1798,14 +842,6 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
       P0(true, 1.0, true);
       css_launch_conv_ws(a, n_cu, st);
       P1();
-    } else if (plan == PLAN_PP272) {
-      // 272-row tiles of the persistent kernel cover every row in whole rounds of the chip: one launch
-      ConvArgs b = a;
-      b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
-      const int tiles = cdiv(a.M, 272) * cdiv(a.Cd, 256);
-      P0(true, 1.0);
-      css_launch_conv_pp(b, 272, tiles < n_cu ? tiles : n_cu, st);
-      P1();
     } else if (plan == PLAN_TILE256) {
       // 256x256 tiles: whole rounds of the chip on the big kernel, leftover rows on the 128x128 kernel
       const int nt_n = cdiv(a.Cd, 256), mt = cdiv(a.M, 256);
@@ -1816,15 +852,13 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.M = full_mt * 256 < a.M ? full_mt * 256 : a.M;
         P0(true, (double)(b.M - b.m_begin) / a.M);
-        if (css_conv_pp_plan(b, n_cu) != 0) {
-          // second-generation kernel (conv_pp.hip): persistent, one workgroup per CU walking full_mt * nt_n tiles
+        {
+          // persistent, one workgroup per CU walking full_mt * nt_n tiles: the 8-phase K loop (conv_p8.hip) for every shape with at least
+          // three 64-channel K steps per valid kernel row, the 32-channel-step loop (conv_pp.hip) for the few below that
           b.dst_bytes = (unsigned)((size_t)b.M * b.ldd * 2);
           const int tiles = full_mt * nt_n;
-          if (css_conv_p8_supported(b)) css_launch_conv_p8(b, tiles < n_cu ? tiles : n_cu, st);        // 8-phase K loop (conv_p8.hip)
-          else if (css_conv_pp64_supported(b)) css_launch_conv_pp64(b, tiles < n_cu ? tiles : n_cu, st);   // 128-byte rows (conv_pp64.hip)
-          else css_launch_conv_pp(b, 256, tiles < n_cu ? tiles : n_cu, st);
-        } else {
-          hipLaunchKernelGGL(conv_igemm_dma256_kernel, dim3(full_mt * nt_n), dim3(512), 0, st, b);
+          if (css_conv_p8_supported(b)) css_launch_conv_p8(b, tiles < n_cu ? tiles : n_cu, st);
+          else css_launch_conv_pp(b, tiles < n_cu ? tiles : n_cu, st);
         }
         P1();
       }
@@ -1892,97 +926,3 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
   return CSS_OK;
 }
 
-// Pixel splits of the weight gradient: a multiple of 8 (one slice per XCD at a time, see the kernels) chosen so that the tiles
-// an XCD owns (tiles per slice x slices per XCD) fill its 32 CUs x resident workgroups in whole rounds, with >= 4 iterations each.
-void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out) {
-  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
-  const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
-  const int bn = dtype == CSS_BF16 ? (big ? 256 : 128) : 64, bkc = bn, bp = dtype == CSS_BF16 ? (big ? 32 : 64) : 16;
-  const int tiles = cdiv(Ktot, bkc) * cdiv(Cd, bn);
-  const int slots = (n_cu / 8) * (big ? 1 : 2);
-  int best_k = 1;
-  double best_eff = 0;
-  for (int k = 1; k <= 64; ++k) {
-    const int mps_k = cdiv(cdiv(M, 8 * k), bp) * bp;
-    if (k > 1 && mps_k < 4 * bp) break;
-    const int txcd = tiles * k;
-    const double eff = (double)txcd / ((double)cdiv(txcd, slots) * slots);
-    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = k; }
-    if (eff >= 0.93) break;
-  }
-  int splits = 8 * best_k;
-  const int mps = cdiv(cdiv(M, splits), bp) * bp;
-  splits = cdiv(M, mps);
-  *splits_out = splits;
-  *mps_out = mps;
-}
-
-// bytes of workspace that let css_launch_wgrad replace its fp32 atomics by plain partial-tile stores + an ordered reduction (0: the
-// shape takes a kernel that has no such path)
-size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
-  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr, no_ws = getenv("CSS_WGRAD_ATOMICS") != nullptr;
-  if (no_ws || M <= 0 || (dtype != CSS_BF16 && dtype != CSS_F32)) return 0;
-  int splits, mps;
-  css_wgrad_plan_(M, Ktot, Cd, dtype, n_cu, &splits, &mps);
-  const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
-  const int bn = big ? 256 : (dtype == CSS_BF16 ? 128 : 64);        // (square tiles: css_launch_wgrad)
-  return (size_t)cdiv(Ktot, bn) * cdiv(Cd, bn) * splits * ((size_t)bn * bn * sizeof(float));
-}
-
-int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
-  if (a.M <= 0) return CSS_OK;
-  a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
-  a.fd_w = make_fastdiv((uint32_t)a.Wd);
-  int bn, bkc, bp;
-  static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
-  const bool big = dtype == CSS_BF16 && a.Cd >= 256 && a.Ktot >= 256 && !no_256;   // 256x256 LDS-DMA kernel, one workgroup per CU
-  if (dtype == CSS_BF16) {
-    bn = big ? 256 : 128; bkc = big ? 256 : 128; bp = big ? 32 : 64;
-    if (a.Cs % 8 || a.ldx % 8 || a.ldy % 8 || a.Cd % 8) return CSS_ERR_ARG;
-  } else if (dtype == CSS_F32) {
-    bn = 64; bkc = 64; bp = 16;
-    if (a.Cs % 4 || a.ldx % 4 || a.ldy % 4 || a.Cd % 4) return CSS_ERR_ARG;
-  } else {
-    return CSS_ERR_DTYPE;
-  }
-  if ((reinterpret_cast<uintptr_t>(a.x) & 15) || (reinterpret_cast<uintptr_t>(a.dy) & 15)) return CSS_ERR_ARG;
-  {
-    const size_t esz = dtype == CSS_BF16 ? 2 : 4;
-    const size_t xb = (size_t)a.N * a.Hs * a.Ws * a.ldx * esz, yb = (size_t)a.M * a.ldy * esz;
-    if (xb >= 0x7FFFFFF0ull || yb >= 0x7FFFFFF0ull) return CSS_ERR_ARG;   // 32-bit buffer offsets
-    a.x_bytes = (unsigned)xb;
-    a.dy_bytes = (unsigned)yb;
-  }
-  int splits, mps;
-  css_wgrad_plan_(a.M, a.Ktot, a.Cd, dtype, n_cu, &splits, &mps);
-  a.m_per_split = mps;
-  a.splits = splits;
-  a.tiles_k = cdiv(a.Ktot, bkc);
-  a.tiles_n = cdiv(a.Cd, bn);
-  dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
-  if (prof) prof->begin(big, 1.0, false);
-  if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
-  if (big) {
-    // CSS_WGRAD_KERNEL: 0 = conv_wgrad_dma256_kernel (both cout halves in lockstep), 1 = the same with the second half one half-step
-    // behind, 2 (default) = conv_wgrad_p8_kernel (two-phase steps)
-    static const int which = getenv("CSS_WGRAD_KERNEL") ? atoi(getenv("CSS_WGRAD_KERNEL")) : (getenv("CSS_WGRAD_NOSTAGGER") ? 0 : 2);
-    if (which == 0) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<false>, g, dim3(512), 0, st, a);
-    else if (which == 1) hipLaunchKernelGGL(conv_wgrad_dma256_kernel<true>, g, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
-    if (a.ws)
-      hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
-  } else if (dtype == CSS_BF16) {
-    hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
-    if (a.ws)
-      hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<128, 128>), dim3(128 / 8, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
-                         a.tiles_k, a.Cd, a.Ktot);
-  } else {
-    hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);
-    if (a.ws)
-      hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<64, 64>), dim3(64 / 16, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
-                         a.tiles_k, a.Cd, a.Ktot);
-  }
-  if (prof) prof->end();
-  CSS_CHECK_LAUNCH();
-  return CSS_OK;
-}

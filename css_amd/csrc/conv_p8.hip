@@ -1,4 +1,4 @@
-// conv_igemm_p8_kernel: the persistent 256x256 implicit-GEMM convolution of conv_pp64.hip with its K loop rebuilt in the 8-phase
+// conv_igemm_p8_kernel: the persistent 256x256 implicit-GEMM convolution of scripts/proto/conv_pp64.hip with its K loop rebuilt in the 8-phase
 // structure of the guide's 256^2 GEMM template (cdna_hip_programming.md, "The 256^2 8-phase template").
 //
 // Why (profiles/r03_yardstick_gemm8p_vs_pp64.txt, same box, uniform random operands): scripts/gemm8p.hip - that template written from
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   const int wm = wave >> 2, wn = wave & 3;                       // pixel half (= phase group), channel quarter
   const int l15 = lane & 15, lg = lane >> 4;
 
-  // ---- tile schedule (as conv_pp.hip / conv_pp64.hip) ----
+  // ---- tile schedule (as conv_pp.hip / scripts/proto/conv_pp64.hip) ----
   const int G = gridDim.x, q8 = G >> 3, r8 = G & 7;
   const int xcd = blockIdx.x & 7, idx8 = blockIdx.x >> 3;
   const int pos = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx8;
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 
   unsigned long long src_p = (unsigned long long)a.src, wt_p = (unsigned long long)a.wt;
   int src_n = (int)a.src_bytes, wt_n = (int)a.wt_bytes;
-  asm volatile("" : "+s"(src_p), "+s"(wt_p), "+s"(src_n), "+s"(wt_n));       // (opaque copies: see conv_pp64.hip)
+  asm volatile("" : "+s"(src_p), "+s"(wt_p), "+s"(src_n), "+s"(wt_n));       // (opaque copies: see scripts/proto/conv_pp64.hip)
   const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)src_p, 0, src_n, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)wt_p, 0, wt_n, 0x00020000);
   const __amdgpu_buffer_rsrc_t rs_d = __builtin_amdgcn_make_buffer_rsrc(a.dst, 0, (int)a.dst_bytes, 0x00020000);
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   // ---- staging side -----------------------------------------------------------------------------------------------------------
   // A half-tile is 16 pieces of 1 KiB (8 rows x 128 B); thread -> piece i * 8 + wave (i = 0, 1) of every half-tile, i.e. local rows
   // 64 i + 8 wave + (lane >> 3), 16-byte position lane & 7.  The chunk stored at position p of local row r is source chunk
-  // p ^ ((r >> 1) & 7) (conflict-free ds_read_b128 of 16 consecutive rows, as conv_pp64.hip); (r >> 1) & 7 = 4 (wave & 1) + (lane >> 4)
+  // p ^ ((r >> 1) & 7) (conflict-free ds_read_b128 of 16 consecutive rows, as scripts/proto/conv_pp64.hip); (r >> 1) & 7 = 4 (wave & 1) + (lane >> 4)
   // for all four of my rows, so ONE source chunk per thread.
   //   A half h, local row r -> pixel row (r >> 6) * 128 + h * 64 + (r & 63) of the tile (piece i serves pixel half i)
   //   B half h, local row r -> channel (r >> 5) * 64 + h * 32 + (r & 31) of the tile
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     // A1 of the next K step goes out HERE, ahead of the stores (it is phase 1's piece of that step: see there and phase 4's wait)
     stage(rs_a, par ^ 1, 1, va1);
     __builtin_amdgcn_sched_barrier(0);
-    // ---------------- epilogue of tile ti (as conv_pp64.hip: no LDS, no barrier) ----------------
+    // ---------------- epilogue of tile ti (as scripts/proto/conv_pp64.hip: no LDS, no barrier) ----------------
     const int mrow0 = ct.m0 + wm * 128, n0w = ct.n0 + wn * 64;
     const int bnd = STATS ? (mrow0 / a_stat_Mg + 1) * a_stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
@@ -578,10 +578,14 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   if (nmy == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (a workgroup without a tile: only its prologue's ghost DMAs)
 }
 
-// Supported: what conv_pp64.hip supports (at least three 64-channel K steps per tile).  CSS_NO_P8_CONV=1: back to conv_pp64.hip.
+// Supported: what conv_pp.hip supports, with at most 3 x 3 taps (tap tables: 7 sets of valid kernel rows x 9 taps) and at least three
+// 64-channel K steps per valid kernel row.  CSS_NO_P8_CONV=1: every such shape back on conv_igemm_pp_kernel (A/B reference; the
+// intermediate generation conv_igemm_pp64_kernel is archived in scripts/proto/scripts/proto/conv_pp64.hip).
 bool css_conv_p8_supported(const ConvArgs& a) {
   static const bool off = getenv("CSS_NO_P8_CONV") != nullptr;
-  return !off && css_conv_pp64_supported(a);
+  if (off || !css_conv_pp_supported(a) || a.R > 3 || a.S > 3) return false;
+  const int ncs = (a.Cs + 63) / 64;
+  return ncs * a.S >= 3;
 }
 
 void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st) {
@@ -592,7 +596,9 @@ void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st) {
   if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
   if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
-  // tap lists per set of valid kernel rows (see conv_pp64.hip)
+  // tap lists: for every non-empty set v of valid kernel rows (bit r of v: row r reads something but padding for the tile), the taps
+  // (r, s) in order with the byte offset of the source pixel relative to tap (0,0), the byte offset inside a weight row, and the bit
+  // index of the tap in the per-pixel validity masks
   const int tapstep = (a.mode == 0 ? a.dil : -a.dil) * a.lds * 2;
   for (int v = 1; v < (1 << a.R); ++v) {
     int n = 0;

@@ -504,39 +504,26 @@ bool css_conv_pp_supported(const ConvArgs& a) {
   return true;
 }
 
-// Tile height for a launch of M rows x Cd channels on n_cu compute units: 272 when 256-row tiles would leave a partial round that the
-// 272-row tiling absorbs (then this kernel covers every row: no leftover launch), else 256 (whole rounds here, leftover rows on the
-// 128-row kernels of conv.hip); 0: not a shape for this kernel.
+// 256 when the persistent 256x256-tile kernels take the launch (whole rounds of the chip there, leftover rows on the 128-row kernels of
+// conv.hip); 0: not a shape for them.  (A 272-row tiling that absorbed the partial round was measured ~15 % slower per row and removed in
+// round 4; scripts/proto keeps nothing of it - it was this kernel with TI0 = 9.)
 int css_conv_pp_plan(const ConvArgs& a, int n_cu) {
+  (void)n_cu;
   if (!css_conv_pp_supported(a) || (size_t)a.M * a.ldd * 2 >= 0x7FFFFFF0ull) return 0;
-  // 272-row tiling: correct (tests/test_conv_bench_scale_gpu.py runs it) but measured SLOWER than 256-row tiles + leftover launch
-  // (l3 3x3: 222 vs 210 us; the 272-row variant runs ~15 % slower per row), so it is opt-in: CSS_PP_272=1
-  static const bool no272 = !(getenv("CSS_PP_272") && atoi(getenv("CSS_PP_272")) == 1);
-  const int nt_n = cdiv(a.Cd, 256);
-  const long t256 = (long)cdiv(a.M, 256) * nt_n, t272 = (long)cdiv(a.M, 272) * nt_n;
-  const double rounds = (double)t256 / n_cu;
-  const long k = (long)rounds;
-  if (!no272 && k >= 1 && rounds - k > 1e-9 && rounds - k < 0.6 && t272 <= k * n_cu) return 272;
   return 256;
 }
 
-void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st) {
+void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st) {
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
   a.fd_w = make_fastdiv((uint32_t)a.Wd);
   // K order (see the kernel's issue()): channel slice outer / tap inner for kernels with more than one tap
   static const int korder_env = getenv("CSS_PP_KORDER") ? atoi(getenv("CSS_PP_KORDER")) : -1;
   a.korder = korder_env >= 0 ? korder_env : (a.R * a.S > 1 ? 1 : 0);   // (measured on the harness: 1 beats 0 by 3-5 % on the 3x3 shapes, 2 loses)
-  if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, tile_rows) * 2 * a.Cd * 4);
+  if (a.stats) a.stat_bytes = (unsigned)((size_t)2 * cdiv(a.M, 256) * 2 * a.Cd * 4);
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
   if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   const dim3 g(grid), b(512);
-  if (tile_rows == 272) {
-    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<9, true, false>), g, b, 0, st, a);
-    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<9, false, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_pp_kernel<9, false, false>), g, b, 0, st, a);
-  } else {
-    if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, true, false>), g, b, 0, st, a);
-    else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, true>), g, b, 0, st, a);
-    else hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, false>), g, b, 0, st, a);
-  }
+  if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, true, false>), g, b, 0, st, a);
+  else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, true>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, false>), g, b, 0, st, a);
 }

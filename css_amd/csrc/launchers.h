@@ -30,7 +30,7 @@ struct ConvArgs {
   unsigned stat_bytes, add_bytes; // sizes of the stats / addend buffers (buffer descriptors)
   unsigned mask_bytes;            // size of add_mask
   int korder;                     // order of the K steps (conv_pp.hip: issue())
-  int tab_da[63], tab_kb[63], tab_tap[63];   // conv_pp64.hip: tap lists per set of valid kernel rows (7 x 9)
+  int tab_da[63], tab_kb[63], tab_tap[63];   // conv_p8.hip: tap lists per set of valid kernel rows (7 x 9)
 };
 
 struct WgradArgs {
@@ -59,10 +59,8 @@ int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, Laun
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 bool css_conv_pp_supported(const ConvArgs& a);
 int css_conv_pp_plan(const ConvArgs& a, int n_cu);
-void css_launch_conv_pp(ConvArgs a, int tile_rows, int grid, hipStream_t st);
+void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st);
 int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu);
-bool css_conv_pp64_supported(const ConvArgs& a);
-void css_launch_conv_pp64(ConvArgs a, int grid, hipStream_t st);
 bool css_conv_p8_supported(const ConvArgs& a);
 void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st);
 bool css_conv_ws_supported(const ConvArgs& a, int n_cu);

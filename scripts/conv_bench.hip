@@ -1,7 +1,8 @@
 // Standalone timing harness for the conv kernels (ablations via -DCSS_ABLATE_*): hipcc -O3 --offload-arch=gfx950
 #include "../css_amd/csrc/conv.hip"
+#include "../css_amd/csrc/conv_wgrad.hip"
 #include "../css_amd/csrc/conv_pp.hip"
-#include "../css_amd/csrc/conv_pp64.hip"
+#include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
 #include <cstdio>

@@ -5,8 +5,9 @@
 //   * timing: both kernels in interleaved rounds in one process (min / median over rounds), uniform random operands in [-1, 1).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics scripts/p8_bench.hip -o build/p8_bench && ./build/p8_bench
 #include "../css_amd/csrc/conv.hip"
+#include "../css_amd/csrc/conv_wgrad.hip"
 #include "../css_amd/csrc/conv_pp.hip"
-#include "../css_amd/csrc/conv_pp64.hip"
+#include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
 #define G8_NO_MAIN

@@ -3,8 +3,9 @@
 // stamps at the segment boundaries of a workgroup's first two tiles (cdna_hip_programming.md section 7, In-kernel stamps).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics -DP8_STAMP -DG8_STAMP scripts/p8_stamp.hip -o build/p8_stamp
 #include "../css_amd/csrc/conv.hip"
+#include "../css_amd/csrc/conv_wgrad.hip"
 #include "../css_amd/csrc/conv_pp.hip"
-#include "../css_amd/csrc/conv_pp64.hip"
+#include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
 #define G8_NO_MAIN

@@ -4,8 +4,9 @@
 // For every shape and every epilogue (plain, BN statistics, addend) it runs css_launch_conv twice - conv_ws switched off, then on -
 // compares the outputs (bf16 tensors element by element, statistics slabs row by row) and times 20 launches of each.
 #include "../css_amd/csrc/conv.hip"
+#include "../css_amd/csrc/conv_wgrad.hip"
 #include "../css_amd/csrc/conv_pp.hip"
-#include "../css_amd/csrc/conv_pp64.hip"
+#include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
 #include <cmath>

@@ -1,4 +1,4 @@
-"""Every environment switch the launchers read (css_amd/csrc/conv.hip, conv_pp.hip, conv_pp64.hip: kernel selection for A/B timing)
+"""Every environment switch the launchers read (css_amd/csrc/conv.hip, conv_wgrad.hip, conv_pp.hip, conv_p8.hip: kernel selection for A/B timing)
 is a shipped configuration: each one runs a bench-shape convolution (32 images of 65x65, 256 -> 256, 3x3 dilation 2: whole rounds of
 the chip + leftover rows + the fused statistics) forward, data gradient and weight gradient against torch-CPU fp32, in a process of its
 own (the switches are read once).  Shapes as in tests/test_conv_bench_scale_gpu.py; reference: generalframeworks/networks/resnet.py:119-139."""
@@ -53,7 +53,7 @@ print("ERRS", *e, es)
 assert max(e) < 2e-2 and es < 2e-3, (e, es)
 '''
 
-SWITCHES = [{}, {"CSS_NO_P8_CONV": "1"}, {"CSS_NO_SMALL_SPLITK": "1"}, {"CSS_WGRAD_KERNEL": "0"}, {"CSS_WGRAD_KERNEL": "1"}, {"CSS_NO_PP64_CONV": "1"}, {"CSS_NO_PP64_CONV": "1", "CSS_NO_PP_CONV": "1"}, {"CSS_NO_PP64_CONV": "1", "CSS_PP_272": "1"},
+SWITCHES = [{}, {"CSS_NO_P8_CONV": "1"}, {"CSS_NO_SMALL_SPLITK": "1"}, {"CSS_NO_P8_CONV": "1", "CSS_NO_PP_CONV": "1"},
             {"CSS_PP_KORDER": "0"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"}, {"CSS_WGRAD_ATOMICS": "1"},
             {"CSS_NO_DMA256_WGRAD": "1"}, {"CSS_REM_N64": "1"}, {"CSS_BN_RED_BLOCKS": "256"}]
 
@@ -90,8 +90,7 @@ def test_bn_pass_order_switch_is_a_shipped_configuration(env):
     assert r.returncode == 0, r.stdout[-800:]
 
 
-@pytest.mark.parametrize("env", [{"CSS_NO_P8_CONV": "1"}, {"CSS_NO_PP64_CONV": "1"}, {"CSS_NO_WS_CONV": "1"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"},
-                                 {"CSS_NO_PP64_CONV": "1", "CSS_PP_272": "1"}],
+@pytest.mark.parametrize("env", [{"CSS_NO_P8_CONV": "1"}, {"CSS_NO_WS_CONV": "1"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_masked_residual_gradient_under_every_conv_fallback(env):
     """css_conv2d_dgrad_add_masked on each kernel family the switches route it to (conv_pp64 / conv_pp / the 256x256 and 128x128 LDS-DMA
