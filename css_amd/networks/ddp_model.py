@@ -19,7 +19,7 @@ from .. import functional as Fn
 from .. import ops
 from .._lib import call, dev_stream
 from ..dataset_helpers.gpu_aug import (aug_mode, batch_transform, batch_transform_2, batch_transform_3, generate_cut_gather,
-                                       generate_cut_gather_2, generate_cut_gather_3)
+                                       generate_cut_gather_2, generate_cut_gather_3, prefetch_partner_image)
 from .deeplabv3.deeplabv3 import DeepLabv3Plus_with_rep
 
 
@@ -69,6 +69,13 @@ class _StudentTeacher(nn.Module):
         quantisation of the confidence maps: VOC.py:325-352) - the device restatement 'pil'.  'identity' (geometry and colours
         untouched) is for parity traces and benchmarks, which ask for it explicitly."""
         return self.config["Dataset"].get("device_aug", "pil")
+
+    def _prefetch_partner(self, u_image):
+        """With the identity in-step augmentation the image that reaches the mixing IS the input image: rank 0's batch can be on its way to
+        the other ranks while the teacher runs (gpu_aug.prefetch_partner_image); any other augmentation rescales / crops it first."""
+        if self._device_aug() != "identity":
+            return None
+        return prefetch_partner_image(u_image, self.config["Dataset"]["mix_mode"])
 
     def set_compute_dtype(self, dtype):
         self.model.set_compute_dtype(dtype)
@@ -148,13 +155,14 @@ class Model_mix(_StudentTeacher):
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self._device_aug()):
+            cfg = self.config["Dataset"]
+            pre = self._prefetch_partner(train_u_image)
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, pseudo = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
-            cfg = self.config["Dataset"]
             u_img, u_lab, u_lc, u_lr = batch_transform_2(train_u_image, pseudo, logits_cls, logits_rep, crop_size=cfg["crop_size"],
                                                          scale_size=cfg["scale_size"], augmentation=False)
-            u_img, u_lab, u_lc, u_lr = generate_cut_gather_2(u_img, u_lab, u_lc, u_lr, mode=cfg["mix_mode"])
+            u_img, u_lab, u_lc, u_lr = generate_cut_gather_2(u_img, u_lab, u_lc, u_lr, mode=cfg["mix_mode"], prefetched=pre)
             u_img, u_lab, u_lc, u_lr = batch_transform_2(u_img, u_lab, u_lc, u_lr, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                          augmentation=True)
         _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
@@ -175,13 +183,14 @@ class Model_cross(_StudentTeacher):
     def forward(self, train_l_image, train_u_image, prototypes, _want_prob=True, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self._device_aug()):
+            cfg = self.config["Dataset"]
+            pre = self._prefetch_partner(train_u_image)
             pred_u, rep_u = self._teacher_pair(train_l_image, train_u_image)
             sim, _, _ = Fn.similarity(rep_u, prototypes, self.temp, want_sim=True)
             logits_rep, labels_rep, logits_cls, labels_cls, _ = Fn.pseudo_labels(sim, pred_u, self.temp, hw)
-            cfg = self.config["Dataset"]
             a = batch_transform_3(train_u_image, labels_cls, labels_rep, logits_cls, logits_rep, crop_size=cfg["crop_size"],
                                   scale_size=cfg["scale_size"], augmentation=False)
-            a = generate_cut_gather_3(*a, mode=cfg["mix_mode"])
+            a = generate_cut_gather_3(*a, mode=cfg["mix_mode"], prefetched=pre)
             u_img, u_lab_c, u_lab_r, u_lc, u_lr = batch_transform_3(*a, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0),
                                                                     augmentation=True)
         _, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
@@ -201,6 +210,7 @@ class Model_ori_pseudo(_StudentTeacher):
     def forward(self, train_l_image, train_u_image, _small_logits=False):
         hw = train_u_image.shape[2:]
         with torch.no_grad(), aug_mode(self._device_aug()):
+            pre = self._prefetch_partner(train_u_image)
             pred_u, _ = self._teacher(train_u_image)
             raw = None if _small_logits else ops.bilinear(pred_u, hw[0], hw[1], torch.float32)   # (7th output: unused by the train body)
             # softmax + max in class space only: the pseudo-label kernel with a constant similarity map
@@ -209,7 +219,7 @@ class Model_ori_pseudo(_StudentTeacher):
             cfg = self.config["Dataset"]
             u_img, u_lab, u_lg = batch_transform(train_u_image, labels, logits, crop_size=cfg["crop_size"], scale_size=cfg["scale_size"],
                                                  augmentation=False)
-            u_img, u_lab, u_lg = generate_cut_gather(u_img, u_lab, u_lg, mode=cfg["mix_mode"])
+            u_img, u_lab, u_lg = generate_cut_gather(u_img, u_lab, u_lg, mode=cfg["mix_mode"], prefetched=pre)
             u_img, u_lab, u_lg = batch_transform(u_img, u_lab, u_lg, crop_size=cfg["crop_size"], scale_size=(1.0, 1.0), augmentation=True)
         pred_all, rep_all, pred_l_large, pred_u_large = self._student_pair(train_l_image, u_img, train_l_image.shape[2:], small=_small_logits)
         return (pred_l_large, pred_u_large, u_lab, u_lg, rep_all.permute(0, 3, 1, 2), pred_all.permute(0, 3, 1, 2),

@@ -234,8 +234,25 @@ def _mix_worker(rank, world, port, q):
     res = {}
     for mode in ("none", "cutmix", "cutout"):
         res[mode] = [o.numpy() for o in gpu_aug.generate_cut_gather_2(*ins(), mode=mode, rng=np.random.RandomState(50 + rank))]
+    # the same with rank 0's images already on their way before the "teacher" (gpu_aug.prefetch_partner_image: identity in-step augmentation)
+    img, lab, l1, l2 = ins()
+    pre = gpu_aug.prefetch_partner_image(img, "cutmix")
+    assert pre is not None and gpu_aug.prefetch_partner_image(img, "cutout") is None
+    res["cutmix_prefetched"] = [o.numpy() for o in gpu_aug.generate_cut_gather_2(img, lab, l1, l2, mode="cutmix", rng=np.random.RandomState(50 + rank),
+                                                                                 prefetched=pre)]
     img, lab, l1, l2 = ins()
     res["cutmix3"] = [o.numpy() for o in gpu_aug.generate_cut_gather_3(img, lab, lab + 1, l1, l2, mode="cutmix", rng=np.random.RandomState(50 + rank))]
+    # the packed buffer itself: ignore labels (-1) travel as byte 255 and come back as -1; float payloads bit for bit; odd sizes (alignment)
+    g = torch.Generator().manual_seed(9)
+    t_img = torch.randn(2, 3, 5, 7, generator=g) + rank
+    t_lab = torch.randint(-1, 21, (2, 5, 7), generator=g) + 0 * rank
+    t_map = torch.rand(2, 5, 7, generator=g) + rank
+    unpack, _ = gpu_aug._broadcast_packed([t_img, t_lab, t_map])
+    got = unpack()
+    g0 = torch.Generator().manual_seed(9)
+    w_img, w_lab, w_map = torch.randn(2, 3, 5, 7, generator=g0), torch.randint(-1, 21, (2, 5, 7), generator=g0), torch.rand(2, 5, 7, generator=g0)
+    assert torch.equal(got[0], w_img) and torch.equal(got[1], w_lab) and torch.equal(got[2], w_map) and got[1].dtype == torch.int64
+    assert bool((w_lab == -1).any())
     q.put((rank, res))
     dist.destroy_process_group()
 
@@ -276,6 +293,10 @@ def test_world2_cut_gather_partner_and_draws_follow_the_reference():
         for r in range(2):
             for k in range(n_out[mode]):
                 assert np.array_equal(res[r][mode][k], z[f"out_{mode}_r{r}_{k}"]), ("css_amd", mode, r, k)
+    for r in range(2):                                               # packed broadcast + prefetched images: the same bits
+        for k in range(4):
+            assert np.array_equal(res[r]["cutmix_prefetched"][k], z[f"out_cutmix_r{r}_{k}"]), ("prefetched", r, k)
+            assert res[r]["cutmix_prefetched"][k].dtype == z[f"out_cutmix_r{r}_{k}"].dtype
     # rank 1's cutmix result contains rank 0's pixels: it differs from mixing inside its own batch
     from css_amd.dataset_helpers import gpu_aug
     local = gpu_aug.generate_cut_gather_2(*[t.clone() for t in ins[1]], mode="cutmix", rng=np.random.RandomState(51))
