@@ -5,6 +5,7 @@
 //   NCHW<->NHWC image staging, dtype casts and weight re-layout, fused SGD(nesterov)+EMA
 //   (mix_label.py:96-97,194-195; ddp_model.py:93-97).
 #include "common.h"
+#include <type_traits>
 
 static inline int ew_grid(size_t total) {
   size_t b = (total + 255) / 256;
@@ -51,9 +52,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
     for (int e = 0; e < VEC; ++e) o.set(e, best[e]);
     const size_t ob = ((size_t)(n * Ho + ho) * Wo + wo) * C + cv * VEC;
     o.store(out + ob);
-    if (arg) {
+    if (arg) {          // (one VEC-byte store: ob is a multiple of VEC)
+      union { uint8_t b[VEC]; typename std::conditional<VEC == 8, uint2, uint32_t>::type w; } pk;
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) arg[ob + e] = bi[e];
+      for (int e = 0; e < VEC; ++e) pk.b[e] = bi[e];
+      *reinterpret_cast<decltype(pk.w)*>(arg + ob) = pk.w;
     }
   }
 }
@@ -89,9 +92,11 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         Vec16<T> g;
         g.load(dout + ob);
         const uint8_t want = (uint8_t)(r * ks + s);
+        union { uint8_t b[VEC]; typename std::conditional<VEC == 8, uint2, uint32_t>::type w; } pk;      // (one VEC-byte load instead of VEC)
+        pk.w = *reinterpret_cast<const decltype(pk.w)*>(arg + ob);
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          if (arg[ob + e] == want) acc[e] += g.f(e);
+          if (pk.b[e] == want) acc[e] += g.f(e);
       }
     }
     Vec16<T> o;
@@ -351,15 +356,59 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, in
   if (part == 0 && c < C)
     ws[(size_t)blockIdx.y * C + c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
-__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
+// the same on 16-byte vectors (C and ld multiples of the vector, C / VEC <= 256 and a power of two or a divisor of 256): thread = one
+// channel vector of every (256 / CV)-th row, four rows in flight
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ ws) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC, RG = 256 / CV;
+  const int cv = threadIdx.x % CV, rg = threadIdx.x / CV;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc[VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+  if (rg < RG) {
+    long r = r0 + rg;
+    for (; r + 3 * RG < r1; r += 4 * RG) {
+      Vec16<T> v0, v1, v2, v3;
+      v0.load(x + (size_t)r * ld + cv * VEC); v1.load(x + (size_t)(r + RG) * ld + cv * VEC);
+      v2.load(x + (size_t)(r + 2 * RG) * ld + cv * VEC); v3.load(x + (size_t)(r + 3 * RG) * ld + cv * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += (v0.f(e) + v1.f(e)) + (v2.f(e) + v3.f(e));
+    }
+    for (; r < r1; r += RG) {
+      Vec16<T> v0;
+      v0.load(x + (size_t)r * ld + cv * VEC);
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) acc[e] += v0.f(e);
+    }
+  }
+  __shared__ float red[256 * VEC];
+#pragma unroll
+  for (int e = 0; e < VEC; ++e) red[threadIdx.x * VEC + e] = rg < RG ? acc[e] : 0.f;
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += 256) {
+    const int v = i / VEC, e = i - v * VEC;
+    float t = 0.f;
+    for (int g = 0; g < RG; ++g) t += red[(g * CV + v) * VEC + e];        // (row groups in order)
+    ws[(size_t)blockIdx.y * C + i] = t;
+  }
+}
+// out[c] += the partial rows in row order: 16 partitions x 64 channels per block, combined in a fixed tree
+__global__ __launch_bounds__(1024) void colsum_reduce_kernel(const float* __restrict__ ws, int nrows, int C, float* __restrict__ out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63), part = threadIdx.x >> 6;
   float acc = 0.f;
   if (c < C)
-    for (int r = part; r < nrows; r += 4) acc += ws[(size_t)r * C + c];
-  __shared__ float red[4][64];
+    for (int r = part; r < nrows; r += 16) acc += ws[(size_t)r * C + c];
+  __shared__ float red[16][64];
   red[part][threadIdx.x & 63] = acc;
   __syncthreads();
-  if (part == 0 && c < C) out[c] += (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (part == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][threadIdx.x];
+    out[c] += t;
+  }
 }
 
 // ---- strided channel copy (concat / slice), optional cast ---------------
@@ -397,6 +446,22 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
     const int n = (int)(p / HW);
     const int hw = (int)(p - (size_t)n * HW);
     out[idx] = c < C ? (T)x[((size_t)n * C + c) * HW + hw] : (T)0.f;
+  }
+}
+
+// the network input (C = 3 planes, Cpad = one 16-byte vector per pixel): thread = one pixel, plane reads coalesced across the wave, one
+// 16-byte store (the element-per-thread kernel above: 70 us per 16 x 3 x 513^2 image batch, 2-byte stores and two 64-bit divisions each)
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_vec_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int HW) {
+  constexpr int VEC = 16 / sizeof(T);
+  const size_t total = (size_t)N * HW;
+  GRID_STRIDE(p, total) {
+    const int n = (int)(p / HW);
+    const int hw = (int)(p - (size_t)n * HW);
+    Vec16<T> o;
+#pragma unroll
+    for (int c = 0; c < VEC; ++c) o.set(c, c < C ? x[((size_t)n * C + c) * HW + hw] : 0.f);
+    o.store(out + p * VEC);
   }
 }
 
@@ -639,23 +704,31 @@ int css_launch_copy_channels(const void* src, int lds, void* dst, int ldd, long 
   return CSS_OK;
 }
 
-constexpr long COLSUM_RPB = 512;
+constexpr long COLSUM_RPB = 2048;
 size_t css_colsum_ws_bytes_(long M, int C) { return (size_t)cdiv(M > 0 ? M : 1, COLSUM_RPB) * (size_t)C * sizeof(float); }
 int css_launch_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, hipStream_t st) {
   if (M <= 0) return CSS_OK;
   if (!ws) return CSS_ERR_WORKSPACE;
   const int nrows = cdiv(M, COLSUM_RPB);
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
+    constexpr int VEC = 16 / sizeof(T);
+    const int CV = C / VEC;
+    if (C % VEC == 0 && ld % VEC == 0 && CV <= 256 && 256 % CV == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
+      hipLaunchKernelGGL(colsum_vec_kernel<T>, dim3(1, nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
+    else
+      hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
   });
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(256), 0, st, ws, nrows, C, out);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, ws, nrows, C, out);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
 
 int css_launch_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, hipStream_t st) {
   DISPATCH_T(dtype, {
-    hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(ew_grid((size_t)N * HW * Cpad)), dim3(256), 0, st, x, (T*)out, N, C, HW, Cpad);
+    if (Cpad * (int)sizeof(T) == 16 && C <= Cpad && (reinterpret_cast<uintptr_t>(out) & 15) == 0)
+      hipLaunchKernelGGL(nchw_to_nhwc_vec_kernel<T>, dim3(ew_grid((size_t)N * HW)), dim3(256), 0, st, x, (T*)out, N, C, HW);
+    else
+      hipLaunchKernelGGL(nchw_to_nhwc_kernel<T>, dim3(ew_grid((size_t)N * HW * Cpad)), dim3(256), 0, st, x, (T*)out, N, C, HW, Cpad);
   });
   CSS_CHECK_LAUNCH();
   return CSS_OK;

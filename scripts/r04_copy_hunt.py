@@ -19,6 +19,33 @@ for _ in range(3):
     tr.step(*batch)
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile
+# which C-ABI entry points does a step call, how often - and for the per-layer weight layout calls, for which weights
+from css_amd import _lib, ops
+import css_amd.loss.loss as L
+import css_amd.functional as F_
+import css_amd.train_step as TS
+calls = collections.Counter()
+wl = collections.Counter()
+real_call = _lib.call
+def spy(name, *a):
+    calls[name] += 1
+    if name == "css_weight_layout":
+        wl[(tuple(a[0].shape), tuple(a[1].shape), str(a[1].dtype), a[6])] += 1
+    return real_call(name, *a)
+for m in (ops, L, F_, TS, _lib):
+    if hasattr(m, "call"):
+        m.call = spy
+tr.step(*batch)
+torch.cuda.synchronize()
+for m in (ops, L, F_, TS, _lib):
+    if hasattr(m, "call"):
+        m.call = real_call
+print("--- C-ABI calls of one step")
+for k, v in calls.most_common():
+    print(f"{v:5d}  {k}")
+print("--- css_weight_layout per-layer calls (w shape, out shape, dtype, dgrad)")
+for k, v in wl.most_common(40):
+    print(f"{v:3d}  {k}")
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
     tr.step(*batch)
     torch.cuda.synchronize()
