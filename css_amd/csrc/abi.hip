@@ -302,6 +302,20 @@ int css_bn_finalize(const double* sums, int G, double count, const double* count
   set_dev(device);
   return css_launch_bn_finalize(sums, G, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
 }
+size_t css_peer_buffer_bytes(int slot_doubles) { return css_peer_buffer_bytes_(slot_doubles); }
+int css_bn_peer_finalize(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local, int G, int C,
+                         const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps, float* mean,
+                         float* invstd, float* scale, float* shift, double* count_out, int* status, long timeout_ticks, int phase, int device,
+                         css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_peer_finalize(bases, world, rank, seq, slot_doubles, local, G, C, gamma, beta, running_mean, running_var, momentum, eps, mean,
+                                     invstd, scale, shift, count_out, status, timeout_ticks, phase, S(stream));
+}
+int css_bn_peer_gather(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local, int n,
+                       double* out, int* status, long timeout_ticks, int phase, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_bn_peer_gather(bases, world, rank, seq, slot_doubles, local, n, out, status, timeout_ticks, phase, S(stream));
+}
 int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                       float* shift, int C, int device, css_stream_t stream) {
   set_dev(device);

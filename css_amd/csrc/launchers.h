@@ -163,3 +163,13 @@ int css_launch_contrast_loss(const void* rep, int ld, const float* proto, int K,
                              int Q, int N, float temp, float* loss_vq, float* gradbuf, float* loss, int dtype, hipStream_t st);
 int css_launch_contrast_scatter_grad(const float* gradbuf, const int* anchor_pix, const void* meta, int K, int Q, const float* gscale, void* drep,
                                      int ld, int dtype, hipStream_t st);
+
+// peer.hip: SyncBN statistics exchanged through peer-mapped device memory (no RCCL call)
+constexpr int CSS_PEER_DEPTH = 4;
+size_t css_peer_buffer_bytes_(int slot_doubles);
+int css_launch_bn_peer_gather(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local, int n,
+                              double* out, int* status, long long timeout, int phase, hipStream_t st);
+int css_launch_bn_peer_finalize(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local, int G,
+                                int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                                float* mean, float* invstd, float* scale, float* shift, double* count_out, int* status, long long timeout, int phase,
+                                hipStream_t st);

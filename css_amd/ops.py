@@ -11,7 +11,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import _lib
+from . import _lib, peer
 from ._lib import call, dev_stream, dtype_code
 
 BN_EPS = 1e-5
@@ -383,6 +383,20 @@ def _row_stride(t):
     return ld if ld >= t.shape[-1] else None
 
 
+def _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, dev, st):
+    """SyncBN forward: (sum, sum of squares, row count) of every rank -> global statistics, finalised.  Counts may differ per rank: they ride
+    behind the sums.  -> the [G] global counts on the device (the backward divides by them)."""
+    if peer.enabled():           # peer-mapped exchange buffers: one launch, no RCCL call (css_amd/peer.py)
+        count_t = torch.empty(g, dtype=torch.float64, device=stats.device)
+        peer.exchange(stats.device).finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, count_t)
+        return count_t
+    dist.all_reduce(stats)
+    count_t = stats[g * 2 * c:]
+    call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
+         mean, invstd, scale, shift, c, dev, st)
+    return count_t
+
+
 class _BNAct(torch.autograd.Function):
     """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
@@ -411,10 +425,7 @@ class _BNAct(torch.autograd.Function):
                 stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)     # [G][2][C] sums + [G] local row counts
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, None, None, None, None, 0.0, 0.0, None, None, None,
                      None, stats, c, y, c, fused[4], dev, st)
-                dist.all_reduce(stats)          # SyncBN: (sum, sum of squares, count) of every rank - counts may differ per rank
-                count_t = stats[g * 2 * c:]
-                call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
-                     mean, invstd, scale, shift, c, dev, st)
+                count_t = _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, dev, st)
             else:
                 call("css_bn_reduce_finalize_slabs", fused[0], m, mg, g, count, gamma, beta, running_mean, running_var,
                      float(momentum), float(eps), mean, invstd, scale, shift, None, c, y, c, fused[4], dev, st)
@@ -426,10 +437,7 @@ class _BNAct(torch.autograd.Function):
             if sync and collectives_on():
                 stats = torch.empty(g * 2 * c + g, dtype=torch.float64, device=y.device)
                 call("css_bn_reduce", partial, nrb, c, g, stats, None, None, 0, float(mg), dev, st)
-                dist.all_reduce(stats)
-                count_t = stats[g * 2 * c:]
-                call("css_bn_finalize", stats, g, 0.0, count_t, gamma, beta, running_mean, running_var, float(momentum), float(eps),
-                     mean, invstd, scale, shift, c, dev, st)
+                count_t = _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, dev, st)
             else:
                 call("css_bn_reduce_finalize", partial, nrb, g, count, gamma, beta, running_mean, running_var, float(momentum),
                      float(eps), mean, invstd, scale, shift, c, dev, st)
@@ -493,7 +501,11 @@ class _BNAct(torch.autograd.Function):
             dbeta = torch.empty(c, dtype=torch.float32, device=y.device)
             call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, 0.0, dev, st)
         if sync and collectives_on():
-            dist.all_reduce(sums)   # SyncBN backward: global sum(dz), sum(dz*xhat) per group
+            # SyncBN backward: global sum(dz), sum(dz*xhat) per group
+            if peer.enabled():
+                peer.exchange(y.device).gather(sums)
+            else:
+                dist.all_reduce(sums)
         dy = torch.empty_like(y)
         lazy = ctx.tap_link is not None and mask is not None and ldda == c and da.is_contiguous() and da.shape == y.shape
         dres = torch.empty_like(y) if (has_res and not lazy) else None

@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
-from . import ops
+from . import ops, peer
 from ._lib import call, dev_stream, dtype_code
 from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d, fused_upsample_ok
 from .scheduler.my_lr_scheduler import poly_lr
@@ -72,6 +72,7 @@ class MixTrainer:
         self._flag_host = [torch.zeros(1).pin_memory() if torch.cuda.is_available() else torch.zeros(1) for _ in range(2)]
         self._flag_pending = None              # (pinned host copy of the agreed flag, event recorded behind the copy)
         self._skip_flag = None                 # device flag of THIS step for css_sgd_ema (non-zero: leave weights / momentum / teacher alone)
+        self._peer_pending = None              # (pinned copy of the SyncBN peer-exchange status word, event) of the previous step
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -235,9 +236,32 @@ class MixTrainer:
                                "first step); buckets were reset on every rank - the gradients of that step are invalid, rebuild the "
                                "trainer for a new graph")
 
+    def _check_peer_status(self):
+        """CSS_SYNCBN=peer: an exchange of the previous step that gave up waiting for a peer (css_amd/peer.py) - read one step late from a
+        pinned copy, like the bucket flag."""
+        pending, self._peer_pending = self._peer_pending, None
+        if pending is None:
+            return
+        host, ev = pending
+        ev.synchronize()
+        if int(host[0]) != 0:
+            raise RuntimeError(f"SyncBN peer exchange {int(host[0])} of the previous step timed out waiting for a peer: its statistics were "
+                               "incomplete, the step is invalid")
+
+    def _queue_peer_status(self):
+        if not (peer.enabled() and ops.collectives_on()):
+            return
+        ex = peer.exchange(self.flat_p.device)
+        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        host.copy_(ex.status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._peer_pending = (host, ev)
+
     def finish(self):
         """Call after the last step of a run and before saving a checkpoint: surfaces a pending bucket-plan violation of the final step."""
         self._check_bucket_flag()
+        self._check_peer_status()
 
     def state_dict(self):
         """Trainer state for a checkpoint (checked first: a step whose gradients were invalid raises here instead of being saved)."""
@@ -251,6 +275,7 @@ class MixTrainer:
     def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
         m = self.model
         self._check_bucket_flag()                                            # (before anything of this step is queued: the read cannot stall it)
+        self._check_peer_status()
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
         # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
         # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144
@@ -276,6 +301,7 @@ class MixTrainer:
         call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
              float(self.wd), int(self.it == 0), float(decay), 1.0 / world, self._skip_flag, dev, st)
         m.refresh_weights()
+        self._queue_peer_status()
         m.step += 1
         self.it += 1
         return dict(sup=sup.detach(), unsup=unsup.detach(), contrast=con.detach(), total=total.detach(), pseudo=u_lab)

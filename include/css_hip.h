@@ -135,6 +135,22 @@ CSS_API int css_bn_reduce_finalize_slabs(const float* partial, int M, int Mg, in
 CSS_API int css_bn_finalize(const double* sums, int G, double count, const double* count_dev, const float* gamma, const float* beta,
                             float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                             float* shift, int C, int device, css_stream_t stream);
+/* ---- SyncBN statistics through peer-mapped device memory instead of ~350 host-issued all-reduces per step (mix_label.py:76; DESIGN.md 6b,
+ * css_amd/csrc/peer.hip).  Every rank owns one exchange buffer of css_peer_buffer_bytes(slot_doubles) bytes (zeroed once) that all ranks of
+ * the node map; bases = device array of the `world` buffer addresses AS THIS RANK SEES THEM, in rank order.  One exchange = one call per rank
+ * with the same seq (1, 2, 3, ... - the ranks run the same layers in the same order): the n local doubles are published, every peer's are
+ * awaited (bounded by timeout_ticks of the 100 MHz wall clock: on expiry status[0] = seq and the call completes with what it has - never a
+ * hang) and summed in rank order (bit-identical on all ranks).  css_bn_peer_finalize (forward): local = [G][2][C] sums + [G] local row
+ * counts as css_bn_reduce / css_bn_reduce_finalize_slabs emit them; does css_bn_finalize's work in the same launch and writes the global
+ * counts to count_out[G].  css_bn_peer_gather (backward): out[n] = the summed doubles (out may alias local).  phase 0 = whole exchange;
+ * 1 = publish only, 2 = wait + sum only (tests that play several ranks in one process). */
+CSS_API size_t css_peer_buffer_bytes(int slot_doubles);
+CSS_API int css_bn_peer_finalize(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local,
+                                 int G, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                 float eps, float* mean, float* invstd, float* scale, float* shift, double* count_out, int* status,
+                                 long timeout_ticks, int phase, int device, css_stream_t stream);
+CSS_API int css_bn_peer_gather(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local,
+                               int n, double* out, int* status, long timeout_ticks, int phase, int device, css_stream_t stream);
 CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float* running_mean, const float* running_var, float eps, float* scale,
                               float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
