@@ -46,6 +46,21 @@ template <> struct WgFrag<float> {
   }
 };
 
+// Workgroup -> (pixel slice zz, weight tile t).  Workgroups are dealt round-robin over the 8 XCDs (blockIdx & 7); XCD x takes the
+// CONTIGUOUS range [x W8, (x + 1) W8) of the work items in slice-major order (W8 = ceil(slices x tiles / 8)), so the tiles of one pixel slice
+// run at the same time on ONE XCD and its slice of dY / X is fetched into a single L2 (measured before: 3.7x over-fetch) - a slice that
+// straddles two ranges is fetched by two.  Round 4: the number of slices is no longer a multiple of 8 (css_wgrad_plan_), so a launch fills
+// whole rounds of the CHIP, not of every XCD: 9 tiles x 28 slices = 252 workgroups in one round instead of 9 x 56 in two.
+__device__ __forceinline__ bool wgrad_work_item(const WgradArgs& a, int per_z, int& zz, int& t) {
+  const int total = per_z * a.splits, w8 = (total + 7) >> 3;
+  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  const int w = xcd * w8 + j8;
+  if (j8 >= w8 || w >= total) return false;
+  zz = w / per_z;
+  t = w - zz * per_z;
+  return true;
+}
+
 // BN_: output-channel tile, BKC: k-column tile, BP: pixels per iteration
 template <typename T, int BN_, int BKC, int BP>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
@@ -65,12 +80,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave >> 1, wk = wave & 1;
-  // XCD-aware order: workgroups are dealt round-robin over the 8 XCDs; all (k-column, cout) tiles of one pixel slice
-  // are given to ONE XCD so that the slice of dY / X is fetched into a single L2 (measured before: 3.7x over-fetch).
   const int per_z = a.tiles_k * a.tiles_n;
-  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
-  if (zz >= a.splits) return;
+  int zz, t;
+  if (!wgrad_work_item(a, per_z, zz, t)) return;
   const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
   const int m_begin = zz * a.m_per_split;
   const int m_end = min(a.M, m_begin + a.m_per_split);
@@ -264,9 +276,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wn = wave >> 2, wk = wave & 3;
   const int per_z = a.tiles_k * a.tiles_n;
-  const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
-  const int zz = (j8 / per_z) * 8 + xcd, t = j8 % per_z;
-  if (zz >= a.splits) return;
+  int zz, t;
+  if (!wgrad_work_item(a, per_z, zz, t)) return;
   const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
   const int m_begin = zz * a.m_per_split;
   const int m_end = min(a.M, m_begin + a.m_per_split);
@@ -519,28 +530,33 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float*
 }
 
 
-// Pixel splits of the weight gradient: a multiple of 8 (one slice per XCD at a time, see the kernels) chosen so that the tiles
-// an XCD owns (tiles per slice x slices per XCD) fill its 32 CUs x resident workgroups in whole rounds, with >= 4 iterations each.
+// Pixel slices of the weight gradient.  Every slice stores one partial tile (a slab) per weight tile and a second kernel adds the slabs in
+// slice order, so the number of slices s trades three things: whole rounds of the chip (tiles x s workgroups on n_cu x slots places), the
+// fixed cost per workgroup (pipeline fill, 256 KiB slab store) against the length of its pixel loop, and the slab traffic (tiles x s slabs
+// written and read back - at the round-3 choice "whole rounds of every XCD" 377 MB per layer-4 3x3 launch, a fifth of its time).  The
+// estimate below (microseconds; the constants are the measured orders of magnitude, only their ratios matter) is minimised over s:
+//     rounds(s) x (steps(s) x t_step + t_fix)  +  tiles x s x t_slab,      steps = ceil(M / s / bp)
+// with at least four steps per slice.  (Any s is exact: the slabs of a tile are added in slice order whatever their number.)
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out) {
   static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
   const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
   const int bn = dtype == CSS_BF16 ? (big ? 256 : 128) : 64, bkc = bn, bp = dtype == CSS_BF16 ? (big ? 32 : 64) : 16;
   const int tiles = cdiv(Ktot, bkc) * cdiv(Cd, bn);
-  const int slots = (n_cu / 8) * (big ? 1 : 2);
-  int best_k = 1;
-  double best_eff = 0;
-  for (int k = 1; k <= 64; ++k) {
-    const int mps_k = cdiv(cdiv(M, 8 * k), bp) * bp;
-    if (k > 1 && mps_k < 4 * bp) break;
-    const int txcd = tiles * k;
-    const double eff = (double)txcd / ((double)cdiv(txcd, slots) * slots);
-    if (eff > best_eff + 1e-9) { best_eff = eff; best_k = k; }
-    if (eff >= 0.93) break;
+  const int places = n_cu * (big ? 1 : 2);
+  const double t_step = big ? 0.86 : (dtype == CSS_BF16 ? 1.1 : 1.0), t_fix = big ? 5.0 : 3.0;
+  const double t_slab = (double)bn * bkc * 4 * 2 / 4.0e6;          // a slab written and read once at ~4 TB/s
+  int best_s = 1;
+  double best = 1e300;
+  for (int s = 1; s <= 1024; ++s) {
+    const int mps = cdiv(cdiv(M, s), bp) * bp;
+    if (s > 1 && mps < 4 * bp) break;
+    if (cdiv(M, mps) != s) continue;                               // (rounding the slice length up made a slice empty: same as a smaller s)
+    const double rounds = (double)cdiv((long)tiles * s, places);
+    const double cost = rounds * ((double)(mps / bp) * t_step + t_fix) + (double)tiles * s * t_slab;
+    if (cost < best - 1e-9) { best = cost; best_s = s; }
   }
-  int splits = 8 * best_k;
-  const int mps = cdiv(cdiv(M, splits), bp) * bp;
-  splits = cdiv(M, mps);
-  *splits_out = splits;
+  const int mps = cdiv(cdiv(M, best_s), bp) * bp;
+  *splits_out = cdiv(M, mps);
   *mps_out = mps;
 }
 
@@ -586,7 +602,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.splits = splits;
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
-  dim3 g(a.tiles_k * a.tiles_n * cdiv(splits, 8) * 8);
+  dim3 g(cdiv((long)a.tiles_k * a.tiles_n * splits, 8) * 8);      // (wgrad_work_item: XCD x takes work items [x W8, (x + 1) W8))
   if (prof) prof->begin(big, 1.0, false);
   if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
   if (big) {

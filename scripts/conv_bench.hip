@@ -69,6 +69,11 @@ int main() {
     WgradArgs g{};
     g.x = dx; g.dy = dy; g.dw = dwg; g.N = s.N; g.Hs = s.H; g.Ws = s.W; g.Cs = s.Cin; g.ldx = s.Cin; g.Hd = Ho; g.Wd = Wo; g.Cd = s.Cout;
     g.ldy = s.Cout; g.R = s.R; g.S = s.R; g.stride = s.stride; g.pad = s.pad; g.dil = s.dil; g.M = a.M; g.Ktot = a.Ktot; g.m_per_split = a.M;
+    // the slab workspace the product passes (ops.py): partial tiles + ordered reduction instead of atomics (CB_NO_WS=1: the atomics path)
+    if (!getenv("CB_NO_WS")) {
+      g.ws_bytes = css_wgrad_ws_bytes_(a.M, a.Ktot, s.Cout, CSS_BF16, 256);
+      if (g.ws_bytes) hipMalloc((void**)&g.ws, g.ws_bytes);
+    }
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     const double flops = 2.0 * a.M * s.Cout * a.Ktot;

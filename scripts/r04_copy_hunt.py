@@ -46,7 +46,7 @@ for k, v in calls.most_common():
 print("--- css_weight_layout per-layer calls (w shape, out shape, dtype, dgrad)")
 for k, v in wl.most_common(40):
     print(f"{v:3d}  {k}")
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=False) as prof:
     tr.step(*batch)
     torch.cuda.synchronize()
 sites = collections.Counter()
@@ -55,7 +55,7 @@ for ev in prof.events():
     if ev.name in ("aten::copy_", "aten::_to_copy", "aten::clone", "aten::contiguous", "aten::fill_", "aten::zero_", "aten::add_", "aten::_foreach_add_"):
         frame = next((s for s in (ev.stack or []) if "css_amd" in s or "bench.py" in s), "(no css_amd frame)")
         sites[(ev.name, frame)] += 1
-        shapes[(ev.name, frame)][str(ev.input_shapes)[:80]] += 1
+        shapes[(ev.name, frame)][""] += 1
 for (name, frame), n in sites.most_common(40):
     print(f"{n:5d}  {name:18s} {frame}   {dict(shapes[(name, frame)].most_common(2))}")
 print("--- device-side summary (top 25 by count)")

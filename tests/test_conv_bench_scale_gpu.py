@@ -103,4 +103,8 @@ def test_wgrad_split_plan_at_bench_scale():
     n_cu = _lib.query("css_device_cu_count", 0)
     splits = _lib.query("css_wgrad_splits", 32 * 65 * 65, 256 * 9, 256, 1, n_cu)
     assert splits > 8, splits
-    assert _lib.query("css_wgrad_splits", 32 * 65 * 65, 2048 * 9, 256, 1, n_cu) >= 8
+    # round 4: the slices fill whole rounds of the CHIP (not of every XCD) with as few slabs as that allows
+    for ktot, cd in ((256 * 9, 256), (2048 * 9, 256), (512 * 9, 512), (1024, 256)):
+        s_ = _lib.query("css_wgrad_splits", 32 * 65 * 65, ktot, cd, 1, n_cu)
+        wgs = -(-ktot // 256) * -(-cd // 256) * s_
+        assert s_ >= 4 and wgs / n_cu - int(wgs / n_cu - 1e-9) >= 0.9, (ktot, cd, s_, wgs)
