@@ -63,6 +63,19 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
   const int p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
   constexpr int EPL = C / 64, UN = 8;
   static_assert(EPL == 4, "a lane owns one float4 of the accumulator row");
+  int cur = -1;
+  float racc[4] = {0.f, 0.f, 0.f, 0.f}, rcnt = 0.f;
+  auto flush = [&]() {
+    if (cur >= 0) {
+      float4* a4 = reinterpret_cast<float4*>(acc + cur * C + lane * EPL);
+      float4 a = *a4;
+      a.x += racc[0]; a.y += racc[1]; a.z += racc[2]; a.w += racc[3];
+      *a4 = a;
+      if (lane == 0) cnt[cur] += rcnt;
+    }
+    racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
+    rcnt = 0.f;
+  };
   for (int pb = p0 + wave; pb < p1; pb += 4 * UN) {
     int c[UN];
     float v[UN][EPL];
@@ -87,16 +100,21 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
         }
       }
     }
+    // Runs of one class (labels are piecewise constant) are summed in registers and flushed into the LDS row when the class changes: the
+    // read-modify-write chain through LDS per pixel made this kernel latency-bound at four waves per CU (300 us at c2 for 272 MB, r03).
+    // The class id is wave-uniform (every lane reads the same cls[p]), so the branch is too; the order of the adds is fixed.
 #pragma unroll
     for (int u = 0; u < UN; ++u) {
       if (c[u] < 0) continue;
-      float4* a4 = reinterpret_cast<float4*>(acc + c[u] * C + lane * EPL);
-      float4 a = *a4;
-      a.x += v[u][0]; a.y += v[u][1]; a.z += v[u][2]; a.w += v[u][3];
-      *a4 = a;
-      if (lane == 0) cnt[c[u]] += 1.f;
+      if (c[u] != cur) {
+        flush();
+        cur = c[u];
+      }
+      racc[0] += v[u][0]; racc[1] += v[u][1]; racc[2] += v[u][2]; racc[3] += v[u][3];
+      rcnt += 1.f;
     }
   }
+  flush();
   __syncthreads();
   // the workgroup's partial sums -> its own row of the workspace (plain stores; contrast_class_sums_reduce_kernel adds the rows up in
   // workgroup order: fp64 atomics would add in arrival order, and the prototypes - hence the sampled negatives - would not be reproducible)

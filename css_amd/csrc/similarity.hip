@@ -9,6 +9,7 @@
 // runs on MFMA (32x32x16 bf16 / 32x32x2 f32) with the prototypes as the "A" operand, so a lane owns one
 // pixel and 16 of the 32 padded classes; its partner lane (+32) owns the other 16.
 #include "common.h"
+#include <cstdlib>
 
 template <typename T> struct SimMma;
 template <> struct SimMma<bf16_t> {
@@ -180,6 +181,64 @@ __global__ __launch_bounds__(256) void pseudo_label_kernel(const float* __restri
   }
 }
 
+// The same on 32x32 output tiles (grid: tiles_x, tiles_y, B) for an up-sampling factor >= 2: the tile's footprint in the two small maps
+// (<= 18 x 18 cells x K) goes to LDS once, raw; a pixel's 4 corners x 2 maps x K values then come from LDS instead of 168 scalar loads from
+// L2 per pixel (the kernel above: latency-bound, 415 us at c2 for 118 MB of output).  Same expressions in the same order per pixel: bit-identical.
+constexpr int PL_T = 32, PL_FP = 18;
+template <typename T>
+__global__ __launch_bounds__(256) void pseudo_label_tile_kernel(const float* __restrict__ sim, const T* __restrict__ pred, int ldp, int h, int w, int K,
+                                                                int H, int W, float inv_temp, float sh, float sw, float* __restrict__ logits_rep,
+                                                                int64_t* __restrict__ labels_rep, float* __restrict__ logits_cls,
+                                                                int64_t* __restrict__ labels_cls, float* __restrict__ pseudo) {
+  extern __shared__ float pl_lds[];
+  const int KS = K | 1;                                   // odd cell stride: the corners of neighbouring pixels start on different banks
+  float* s_sim = pl_lds;
+  float* s_pred = pl_lds + PL_FP * PL_FP * KS;
+  const int tid = threadIdx.x, b = blockIdx.z;
+  const int X0 = blockIdx.x * PL_T, Y0 = blockIdx.y * PL_T;
+  const int X1 = min(X0 + PL_T, W) - 1, Y1 = min(Y0 + PL_T, H) - 1;
+  int fy0 = (int)(sh * (float)Y0), fx0 = (int)(sw * (float)X0);
+  fy0 = min(fy0, h - 1); fx0 = min(fx0, w - 1);
+  const int fy1 = min((int)(sh * (float)Y1) + 1, h - 1), fx1 = min((int)(sw * (float)X1) + 1, w - 1);
+  const int fh = fy1 - fy0 + 1, fw = fx1 - fx0 + 1;       // <= PL_FP by the launcher's factor check
+  for (int i = tid; i < fh * fw * K; i += 256) {
+    const int k = i % K, c = i / K, yy = c / fw, xx = c - yy * fw;
+    const size_t g = (size_t)(b * h + fy0 + yy) * w + fx0 + xx;
+    s_sim[c * KS + k] = sim[g * K + k];
+    s_pred[c * KS + k] = (float)pred[g * ldp + k];
+  }
+  __syncthreads();
+  const int x = X0 + (tid & 31);
+#pragma unroll
+  for (int trip = 0; trip < PL_T / 8; ++trip) {
+    const int y = Y0 + (tid >> 5) + 8 * trip;
+    if (x >= W || y >= H) continue;
+    const size_t idx = ((size_t)b * H + y) * W + x;
+    float fy = sh * (float)y, fx = sw * (float)x;
+    int y0 = (int)fy, x0 = (int)fx;
+    if (y0 > h - 1) y0 = h - 1;
+    if (x0 > w - 1) x0 = w - 1;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+    const float wy1 = fy - (float)y0, wy0 = 1.f - wy1, wx1 = fx - (float)x0, wx0 = 1.f - wx1;
+    const int o00 = ((y0 - fy0) * fw + (x0 - fx0)) * KS, o01 = ((y0 - fy0) * fw + (x1 - fx0)) * KS;
+    const int o10 = ((y1 - fy0) * fw + (x0 - fx0)) * KS, o11 = ((y1 - fy0) * fw + (x1 - fx0)) * KS;
+    float mr = -INFINITY, mc = -INFINITY;
+    int ar = 0, ac = 0;
+    float sr = 0.f, sc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float vr = (wy0 * (wx0 * s_sim[o00 + k] + wx1 * s_sim[o01 + k]) + wy1 * (wx0 * s_sim[o10 + k] + wx1 * s_sim[o11 + k])) * inv_temp;
+      const float vc = wy0 * (wx0 * s_pred[o00 + k] + wx1 * s_pred[o01 + k]) + wy1 * (wx0 * s_pred[o10 + k] + wx1 * s_pred[o11 + k]);
+      if (vr > mr) { sr = sr * __expf(mr - vr) + 1.f; mr = vr; ar = k; } else sr += __expf(vr - mr);
+      if (vc > mc) { sc = sc * __expf(mc - vc) + 1.f; mc = vc; ac = k; } else sc += __expf(vc - mc);
+    }
+    logits_rep[idx] = 1.f / sr;
+    labels_rep[idx] = ar;
+    logits_cls[idx] = 1.f / sc;
+    labels_cls[idx] = ac;
+    if (pseudo) pseudo[idx] = (ar == ac) ? (float)ac : 255.f;
+  }
+}
+
 // ---- class-id / validity map at embedding resolution (mix_label.py:175-183) ----------------
 // cls[p] for the labeled half:   l_lab >= 0 ? l_lab : -1                    (mask = l_lab>=0, label = onehot(relu))
 //        for the unlabeled half: (u_lab >= 0 && u_logits >= weak) ? u_lab : -1  (onehot_2 drops channel 0 = label -1)
@@ -271,6 +330,20 @@ int css_launch_pseudo_label(const float* sim, const void* pred, int ldp, int B, 
                             hipStream_t st) {
   const float sh = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sw = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
   const size_t total = (size_t)B * H * W;
+  static const bool no_tile = getenv("CSS_PSEUDO_NO_TILE") != nullptr;       // (A/B and parity tests: the gather kernel for every shape)
+  if (!no_tile && B > 0 && K <= 32 && 2 * (h - 1) <= (H - 1) && 2 * (w - 1) <= (W - 1) && (dtype == CSS_BF16 || dtype == CSS_F32)) {
+    // up-sampling factor >= 2: a 32 x 32 tile's footprint fits PL_FP^2 cells
+    const dim3 g(cdiv(W, PL_T), cdiv(H, PL_T), B);
+    const size_t lds = (size_t)2 * PL_FP * PL_FP * (K | 1) * sizeof(float);
+    if (dtype == CSS_BF16)
+      hipLaunchKernelGGL(pseudo_label_tile_kernel<bf16_t>, g, dim3(256), lds, st, sim, (const bf16_t*)pred, ldp, h, w, K, H, W, 1.f / temp, sh, sw,
+                         logits_rep, labels_rep, logits_cls, labels_cls, pseudo);
+    else
+      hipLaunchKernelGGL(pseudo_label_tile_kernel<float>, g, dim3(256), lds, st, sim, (const float*)pred, ldp, h, w, K, H, W, 1.f / temp, sh, sw,
+                         logits_rep, labels_rep, logits_cls, labels_cls, pseudo);
+    CSS_CHECK_LAUNCH();
+    return CSS_OK;
+  }
   int grid = (int)((total + 255) / 256);
   if (grid > 16384) grid = 16384;
   if (dtype == CSS_BF16)

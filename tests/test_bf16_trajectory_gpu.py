@@ -11,8 +11,12 @@ reference", which needs VOC and ImageNet weights that are not here (VERDICT r02,
   the smallest perturbation there is) measures how far apart two legitimate fp32 trajectories of this problem end up; the bf16 run must
   lie inside a fixed multiple (ENV_C = 2) of that envelope - in TIME lag between the supervised-loss curves, in the mean of the last
   five steps, in the cosines of prototypes and weights.  No margin is a number read off runs: every bound is `ENV_C x ensemble value`.
-  Only chaos-free facts are asserted absolutely (finite, the loss falls tenfold, the contrastive loss - whose sampler is seeded and whose
-  logits are normalised - agrees to 1 %).  The full curves of all members are printed (the record of round 4: profiles/r04_trajectory_*.txt).
+  Asserted absolutely: every run is finite, and the MEDIAN run of the ten (fp32, eight perturbed fp32, bf16) takes the supervised loss below a
+  tenth of its start - a single run may not: in the second deterministic "universe" of round 4 (same test, weight gradients summed in
+  another fixed order) the member fp32+ulp3 bounced back to 7.3 at step 9 and ended at 1.8, 21 steps behind the base run, which is exactly what
+  the envelope is for.  Eight members: bf16 fails only if it lies outside TWICE the worst of eight legitimate fp32 runs; with the lags seen so
+  far (2.4 - 21 steps over ten fp32 runs, bf16 2.6 and 2.55) that is a per-cent-level event under "bf16 behaves like fp32", not a coin flip.
+  The full curves of all members are printed (the records of round 4: profiles/r04_determinism_and_trajectory_ensemble.txt, r04_trajectory_universe2.txt).
 """
 import math
 import os
@@ -111,7 +115,7 @@ def _lag(sf, i, b):
 
 
 ENV_C = 2.0           # bf16 must lie inside ENV_C x the spread of the fp32 ensemble
-N_MEMBERS = 4         # fp32 runs with 1-ulp input perturbations
+N_MEMBERS = 8         # fp32 runs with 1-ulp input perturbations
 
 
 def _perturb_ulp(x, seed):
@@ -165,17 +169,20 @@ def test_thirty_steps_bf16_inside_fp32_ensemble():
     for n, m in zip(names[1:], mm + [mb]):
         print(f"{n:>10s} vs fp32: max |lag| {m['lag']:.2f} steps, last-five-steps gap {m['tail']:.3f}, contrast {m['contrast']:.4f}, "
               f"prototype cosine {m['proto_cos']:.4f}, weights cosine {m['w_cos']:.5f}; lags " + " ".join(f"{v:+.1f}" for v in m["lags"]))
-    # chaos-free facts, asserted absolutely
-    for h, _, _ in [base, bf] + members:
+    # asserted absolutely: finite everywhere; the median run learns (a single run may take an excursion - that is what the envelope is for)
+    runs = [base, bf] + members
+    for h, _, _ in runs:
         assert all(math.isfinite(v) for d in h for k, v in d.items() if k != "unsup")        # (unsup is NaN by definition when no pixel is valid)
-        assert np.mean([d["sup"] for d in h[-3:]]) < 0.1 * h[0]["sup"], (h[0]["sup"], h[-1]["sup"])      # the supervised loss goes down
-    assert mb["contrast"] <= 0.01, mb["contrast"]
+    ends = sorted(np.mean([d["sup"] for d in h[-3:]]) / h[0]["sup"] for h, _, _ in runs)
+    print("mean of the last three supervised losses over the first, per run, sorted:", " ".join(f"{e:.4f}" for e in ends))
+    assert ends[len(ends) // 2] < 0.1, ends
     # everything else relative to the envelope of the fp32 ensemble (floors: half a step of lag, the resolution of the lag measure;
-    # 1e-3 on the cosines' distance from 1)
-    env = dict(lag=max(max(m["lag"] for m in mm), 0.5), tail=max(m["tail"] for m in mm),
+    # 1e-3 on the cosines' distance from 1; 0.5 % on the contrastive loss, whose sampler is seeded and whose logits are normalised)
+    env = dict(lag=max(max(m["lag"] for m in mm), 0.5), tail=max(m["tail"] for m in mm), contrast=max(max(m["contrast"] for m in mm), 5e-3),
                proto=max(max(1.0 - m["proto_cos"] for m in mm), 1e-3), w=max(max(1.0 - m["w_cos"] for m in mm), 1e-3))
-    print(f"fp32 ensemble envelope: lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, 1 - prototype cosine {env['proto']:.4f}, "
-          f"1 - weights cosine {env['w']:.5f};  bf16 must stay inside {ENV_C} x these")
+    print(f"fp32 ensemble envelope: lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, contrast {env['contrast']:.4f}, 1 - prototype cosine "
+          f"{env['proto']:.4f}, 1 - weights cosine {env['w']:.5f};  bf16 must stay inside {ENV_C} x these")
     assert mb["lag"] <= ENV_C * env["lag"], (mb["lag"], env["lag"])
     assert mb["tail"] <= ENV_C * env["tail"], (mb["tail"], env["tail"])
+    assert mb["contrast"] <= ENV_C * env["contrast"], (mb["contrast"], env["contrast"])
     assert 1.0 - mb["proto_cos"] <= ENV_C * env["proto"] and 1.0 - mb["w_cos"] <= ENV_C * env["w"], (mb, env)

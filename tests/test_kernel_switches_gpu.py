@@ -114,6 +114,41 @@ def test_ce_gather_kernel_switch_is_a_shipped_configuration():
     assert r.returncode == 0, r.stdout[-800:]
 
 
+PSEUDO_WORKER = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+from css_amd import functional as Fn
+torch.manual_seed(2)
+dev = torch.device("cuda:0")
+out = []
+for (B, h, H, K, dt) in ((4, 129, 513, 21, torch.bfloat16), (2, 97, 385, 19, torch.float32), (3, 17, 65, 21, torch.bfloat16), (1, 33, 70, 5, torch.float32)):
+    sim = (torch.rand(B, h, h, K, device=dev) * 2 - 1).contiguous()
+    pred = (torch.randn(B, h, h, K, device=dev) * 3).to(dt).contiguous()
+    out.append([t.cpu() for t in Fn.pseudo_labels(sim, pred, 0.5, (H, H))])
+torch.save(out, sys.argv[1])
+'''
+
+
+def test_pseudo_label_tile_kernel_equals_the_gather_kernel(tmp_path):
+    """css_pseudo_label on 32 x 32 tiles with the footprint staged in LDS (round 4) against the per-pixel gather kernel it replaces
+    (CSS_PSEUDO_NO_TILE=1, a process of its own: the switch is read once): confidences, arg-max maps and the agreement map bit for bit, at the
+    c2 / c4 launch geometries, a small one and a non-integer factor (ddp_model.py:111-118)."""
+    import torch
+    res = []
+    for sw in ("0", "1"):
+        e = dict(os.environ)
+        if sw == "1":
+            e["CSS_PSEUDO_NO_TILE"] = "1"
+        out = str(tmp_path / f"p{sw}.pt")
+        r = subprocess.run([sys.executable, "-c", PSEUDO_WORKER % ROOT, out], env=e, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-800:]
+        res.append(torch.load(out))
+    for a, b in zip(*res):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and torch.equal(x, y), (x.shape, float((x.double() - y.double()).abs().max()))
+
+
 def test_eager_residual_gradient_switch_is_a_shipped_configuration():
     """CSS_BN_EAGER_DRES=1 (css_amd/ops.py: bn_bwd_apply writes the masked residual gradient itself instead of leaving the mask to the tapped
     convolution's dgrad store): the block-level parity tests under that switch, in a process of its own."""
