@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
   if (lane < CT_MAXK) cnt[lane] = 0.f;
   __syncthreads();
   const int p0 = blockIdx.x * pix_per_block, p1 = min(P, p0 + pix_per_block);
-  constexpr int EPL = C / 64, UN = 8;
+  constexpr int EPL = C / 64, UN = 16;
   static_assert(EPL == 4, "a lane owns one float4 of the accumulator row");
   int cur = -1;
   float racc[4] = {0.f, 0.f, 0.f, 0.f}, rcnt = 0.f;
@@ -76,42 +76,44 @@ __global__ __launch_bounds__(256) void contrast_class_sums_kernel(const T* __res
     racc[0] = racc[1] = racc[2] = racc[3] = 0.f;
     rcnt = 0.f;
   };
-  for (int pb = p0 + wave; pb < p1; pb += 4 * UN) {
-    int c[UN];
-    float v[UN][EPL];
+  // A wave takes 64 consecutive pixels at a time: ONE load fetches their class ids (lane i: pixel pb + i; the ids reach the loop as
+  // wave-uniform scalars through v_readlane), then the rows go out UN = 16 at a time - 8 KiB in flight per wave, 32 KiB per CU (the first
+  // form had 8 rows and 8 same-address class loads in flight per wave and ran at 0.9 TB/s).
+  for (int pb = p0 + wave * 64; pb < p1; pb += 4 * 64) {
+    const int ci = pb + lane < p1 ? cls[pb + lane] : -1;
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int p = pb + 4 * u;
-      c[u] = p < p1 ? cls[p] : -1;
-    }
+    for (int u0 = 0; u0 < 64; u0 += UN) {
+      int c[UN];
+      float v[UN][EPL];
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      const int p = pb + 4 * u;
-      if (c[u] >= 0) {
-        const T* row = rep + (size_t)p * ld + lane * EPL;
-        if constexpr (sizeof(T) == 2) {
-          union { uint2 u2; T e[EPL]; } pk;
-          pk.u2 = *reinterpret_cast<const uint2*>(row);
+      for (int u = 0; u < UN; ++u) c[u] = __builtin_amdgcn_readlane(ci, u0 + u);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) v[u][e] = (float)pk.e[e];
-        } else {
+      for (int u = 0; u < UN; ++u) {
+        if (c[u] >= 0) {
+          const T* row = rep + (size_t)(pb + u0 + u) * ld + lane * EPL;
+          if constexpr (sizeof(T) == 2) {
+            union { uint2 u2; T e[EPL]; } pk;
+            pk.u2 = *reinterpret_cast<const uint2*>(row);
 #pragma unroll
-          for (int e = 0; e < EPL; ++e) v[u][e] = (float)row[e];
+            for (int e = 0; e < EPL; ++e) v[u][e] = (float)pk.e[e];
+          } else {
+#pragma unroll
+            for (int e = 0; e < EPL; ++e) v[u][e] = (float)row[e];
+          }
         }
       }
-    }
-    // Runs of one class (labels are piecewise constant) are summed in registers and flushed into the LDS row when the class changes: the
-    // read-modify-write chain through LDS per pixel made this kernel latency-bound at four waves per CU (300 us at c2 for 272 MB, r03).
-    // The class id is wave-uniform (every lane reads the same cls[p]), so the branch is too; the order of the adds is fixed.
+      // Runs of one class (labels are piecewise constant) are summed in registers and flushed into the LDS row when the class changes;
+      // the class id is wave-uniform, so the branch is too; the order of the adds is fixed.
 #pragma unroll
-    for (int u = 0; u < UN; ++u) {
-      if (c[u] < 0) continue;
-      if (c[u] != cur) {
-        flush();
-        cur = c[u];
+      for (int u = 0; u < UN; ++u) {
+        if (c[u] < 0) continue;
+        if (c[u] != cur) {
+          flush();
+          cur = c[u];
+        }
+        racc[0] += v[u][0]; racc[1] += v[u][1]; racc[2] += v[u][2]; racc[3] += v[u][3];
+        rcnt += 1.f;
       }
-      racc[0] += v[u][0]; racc[1] += v[u][1]; racc[2] += v[u][2]; racc[3] += v[u][3];
-      rcnt += 1.f;
     }
   }
   flush();

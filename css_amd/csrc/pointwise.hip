@@ -344,6 +344,31 @@ __global__ __launch_bounds__(256) void spatial_bcast_vec_kernel(const T* __restr
 // (fp32 atomics onto out[] would add in arrival order: the bias gradients would differ in their last bits from run to run.)
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ ws) {
+  // C <= 256 (the class logits: C = 21 / 19): RG = 256 / C rows per pass, thread t = (row t / C, channel t % C) - with ld == C the RG x C
+  // threads of a pass read one contiguous run (the per-64-channel form left 43 of 64 lanes idle at C = 21: 197 us for 22 MB)
+  const int RG = 256 / C, tid = threadIdx.x;
+  const int c = tid % C, rg = tid / C;
+  const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+  float acc = 0.f;
+  if (rg < RG) {
+    long r = r0 + rg;
+    for (; r + 3 * RG < r1; r += 4 * RG)        // four rows in flight
+      acc += ((float)x[(size_t)r * ld + c] + (float)x[(size_t)(r + RG) * ld + c]) +
+             ((float)x[(size_t)(r + 2 * RG) * ld + c] + (float)x[(size_t)(r + 3 * RG) * ld + c]);
+    for (; r < r1; r += RG) acc += (float)x[(size_t)r * ld + c];
+  }
+  __shared__ float red[256];
+  red[tid] = rg < RG ? acc : 0.f;
+  __syncthreads();
+  if (tid < C) {
+    float t = 0.f;
+    for (int g = 0; g < RG; ++g) t += red[g * C + tid];       // (row groups in order)
+    ws[(size_t)blockIdx.y * C + tid] = t;
+  }
+}
+// any C (> 256 without the vector layout): 64 channels per block column, four row partitions
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_wide_kernel(const T* __restrict__ x, int ld, long M, int C, long rows_per_block, float* __restrict__ ws) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int part = threadIdx.x >> 6;
   const long r0 = (long)blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
@@ -715,8 +740,10 @@ int css_launch_colsum(const void* x, int ld, long M, int C, float* out, float* w
     const int CV = C / VEC;
     if (C % VEC == 0 && ld % VEC == 0 && CV <= 256 && 256 % CV == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0)
       hipLaunchKernelGGL(colsum_vec_kernel<T>, dim3(1, nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
+    else if (C <= 256)
+      hipLaunchKernelGGL(colsum_kernel<T>, dim3(1, nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
     else
-      hipLaunchKernelGGL(colsum_kernel<T>, dim3(cdiv(C, 64), nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
+      hipLaunchKernelGGL(colsum_wide_kernel<T>, dim3(cdiv(C, 64), nrows), dim3(256), 0, st, (const T*)x, ld, M, C, COLSUM_RPB, ws);
   });
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(cdiv(C, 64)), dim3(1024), 0, st, ws, nrows, C, out);
   CSS_CHECK_LAUNCH();

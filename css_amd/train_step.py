@@ -73,6 +73,7 @@ class MixTrainer:
         self._flag_pending = None              # (pinned host copy of the agreed flag, event recorded behind the copy)
         self._skip_flag = None                 # device flag of THIS step for css_sgd_ema (non-zero: leave weights / momentum / teacher alone)
         self._peer_pending = None              # (pinned copy of the SyncBN peer-exchange status word, event) of the previous step
+        self._peer_host = None                 # two pinned words, alternating (allocated on first use)
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -239,7 +240,7 @@ class MixTrainer:
     def _check_peer_status(self):
         """CSS_SYNCBN=peer: an exchange of the previous step that gave up waiting for a peer (css_amd/peer.py) - read one step late from a
         pinned copy, like the bucket flag."""
-        pending, self._peer_pending = self._peer_pending, None
+        pending, self._peer_pending = getattr(self, "_peer_pending", None), None
         if pending is None:
             return
         host, ev = pending
@@ -252,7 +253,9 @@ class MixTrainer:
         if not (peer.enabled() and ops.collectives_on()):
             return
         ex = peer.exchange(self.flat_p.device)
-        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+        if self._peer_host is None:
+            self._peer_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
+        host = self._peer_host[self.it & 1]
         host.copy_(ex.status, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()

@@ -111,3 +111,15 @@ def test_loss_kernels_are_reproducible_at_bench_scale():
     ref = torch.zeros(K, C, dtype=torch.float64, device=dev()).index_add_(0, cls[cls >= 0].long(), rep[cls >= 0].double())
     assert torch.allclose(res[0][0][:K * C].view(K, C), ref, rtol=1e-6, atol=1e-3)
     assert torch.allclose(res[0][1].double(), rep.double().sum(0), rtol=1e-4, atol=5e-2)
+    # the other two column-sum kernels: C = 21 (class logits: dense lanes, 12 rows per pass) and a width above 256 without the vector layout,
+    # both accumulating INTO out, fp32 and bf16, ragged row counts
+    for C2, M2, dt in ((21, 32 * 129 * 129, torch.bfloat16), (19, 100003, torch.float32), (300, 70001, torch.bfloat16), (257, 513, torch.float32)):
+        x = torch.randn(M2, C2, device=dev()).to(dt)
+        outs = []
+        for _ in range(2):
+            o = torch.full((C2,), 0.5, dtype=torch.float32, device=dev())
+            w = torch.empty(query("css_colsum_ws_bytes", M2, C2) // 4, dtype=torch.float32, device=dev())
+            call("css_colsum", x, C2, M2, C2, o, w, dtype_code(dt), d, st)
+            outs.append(o.clone())
+        assert _same_bits(outs[0], outs[1]), (C2, M2)
+        assert torch.allclose(outs[0].double(), x.double().sum(0) + 0.5, rtol=1e-4, atol=5e-2), (C2, M2, float((outs[0].double() - x.double().sum(0) - 0.5).abs().max()))

@@ -142,7 +142,7 @@ def _bucket_worker(rank, world, port, q, mode="plain"):
     tr._grad_pg = tr._ready_order = tr._buckets = tr._span_reports = tr._span_bucket = tr._flag_pending = None
     tr._flags = [torch.zeros(1), torch.zeros(1)]
     tr._flag_host = [torch.zeros(1), torch.zeros(1)]
-    tr._skip_flag = None
+    tr._skip_flag = tr._peer_pending = tr._peer_host = None
     tr.it = 0
     errs = []
     raised = []

@@ -612,3 +612,25 @@ def test_product_modules_have_no_unbound_names():
         if missing:
             bad[os.path.relpath(f, root)] = missing
     assert not bad, bad
+
+
+def test_round4_host_logic():
+    """Host-side pieces of round 4 that need no GPU: which up-sampling shapes the fused (reproducible) loss path takes; the packed layout of the
+    mixing-partner broadcast; the weight-gradient slice plan fills whole rounds of the chip with few slabs; the peer exchange is opt-in."""
+    import torch
+    from css_amd import _lib, peer
+    from css_amd.dataset_helpers import gpu_aug
+    from css_amd.loss.loss import fused_upsample_ok
+    assert fused_upsample_ok((129, 129), (513, 513), 21) and fused_upsample_ok((193, 193), (769, 769), 19)
+    assert not fused_upsample_ok((33, 33), (40, 40)) and not fused_upsample_ok((17, 17), (513, 513)) and not fused_upsample_ok((129, 129), (513, 513), 30)
+    # packed broadcast: int64 class-id maps travel as bytes, every part starts on a 16-byte boundary
+    ts = [torch.zeros(3, 3, 5, 7), torch.zeros(3, 5, 7, dtype=torch.int64), torch.zeros(3, 5, 7), torch.zeros(3, 5, 7)]
+    lay, total = gpu_aug._pack_layout(ts)
+    assert [l[2] for l in lay] == [False, True, False, False] and all(l[0] % 16 == 0 for l in lay)
+    assert lay[1][1] == 3 * 5 * 7 and lay[0][1] == 3 * 3 * 5 * 7 * 4 and total % 16 == 0 and total >= sum(l[1] for l in lay)
+    # slice plan (css_wgrad_splits is a host-side query): one or two whole rounds of 256 CUs, slabs bounded
+    for ktot, cd, want_wgs in ((2304, 256, 252), (4608, 512, 252), (18432, 256, 504), (1024, 256, 256)):
+        s_ = _lib.query("css_wgrad_splits", 32 * 65 * 65, ktot, cd, 1, 256)
+        assert -(-ktot // 256) * -(-cd // 256) * s_ == want_wgs, (ktot, cd, s_)
+    assert peer.enabled() is (os.environ.get("CSS_SYNCBN", "rccl") == "peer")
+    assert _lib.query("css_peer_buffer_bytes", 100) == (4 * 100 + 4) * 8
