@@ -448,6 +448,11 @@ int css_aug_color(uint8_t* img_q, uint8_t* tmp, const int* jp, int64_t* sums, in
   set_dev(device);
   return css_launch_aug_color(img_q, tmp, jp, reinterpret_cast<unsigned long long*>(sums), B, H, W, any_jitter, any_blur, S(stream));
 }
+int css_mix_boxes(const void* self, const void* partner, void* out, const int* boxes, const int* pj, int B, int P, int H, int W, int elem_bytes, int mode,
+                  long fill_bits, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_mix_boxes(self, partner, out, boxes, pj, B, P, H, W, elem_bytes, mode, (long long)fill_bits, S(stream));
+}
 int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc, int Wc,
                    float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream) {
   set_dev(device);

@@ -369,3 +369,42 @@ int css_launch_aug_finish(const unsigned char* img_q, const unsigned char* lab_q
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }
+
+// ---- cutmix / cutout boxes of a whole batch in ONE launch per tensor (generate_cut_gather*, dataset_helpers/VOC.py:354-477) -----------------
+// out[b][p][y][x] = inside box b ? (mode 0: partner[pj[b]][p][y][x], mode 1: fill) : self[b][p][y][x]; boxes int32 [B][4] = {y0, y1, x0, x1}
+// (half-open), tensors contiguous [B][P][H][W] of 4- or 8-byte elements.  Replaces a clone + one strided copy per image and tensor (64 copy
+// launches of ~5 us per c2 step); a pure copy, bit-exact.
+template <typename E>
+__global__ __launch_bounds__(256) void mix_boxes_kernel(const E* __restrict__ self, const E* __restrict__ partner, E* __restrict__ out,
+                                                        const int* __restrict__ boxes, const int* __restrict__ pj, int B, int P, int H, int W,
+                                                        int mode, E fill) {
+  const size_t plane = (size_t)H * W, per_img = plane * P, total = per_img * B;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int b = (int)(idx / per_img);
+    const size_t r = idx - (size_t)b * per_img;
+    const int yx = (int)(r % plane), y = yx / W, x = yx - y * W;
+    const int* bx = boxes + 4 * b;
+    const bool in = y >= bx[0] && y < bx[1] && x >= bx[2] && x < bx[3];
+    out[idx] = in ? (mode == 0 ? partner[(size_t)pj[b] * per_img + r] : fill) : self[idx];
+  }
+}
+int css_launch_mix_boxes(const void* self, const void* partner, void* out, const int* boxes, const int* pj, int B, int P, int H, int W, int elem_bytes,
+                         int mode, long long fill_bits, hipStream_t st) {
+  if (B <= 0 || P <= 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1) || (mode == 0 && (!partner || !pj))) return CSS_ERR_ARG;
+  const size_t total = (size_t)B * P * H * W;
+  int grid = (int)((total + 255) / 256);
+  if (grid > 16384) grid = 16384;
+  if (elem_bytes == 4) {
+    const unsigned f = (unsigned)fill_bits;
+    hipLaunchKernelGGL(mix_boxes_kernel<unsigned>, dim3(grid), dim3(256), 0, st, (const unsigned*)self, (const unsigned*)partner, (unsigned*)out, boxes, pj, B,
+                       P, H, W, mode, f);
+  } else if (elem_bytes == 8) {
+    hipLaunchKernelGGL(mix_boxes_kernel<unsigned long long>, dim3(grid), dim3(256), 0, st, (const unsigned long long*)self,
+                       (const unsigned long long*)partner, (unsigned long long*)out, boxes, pj, B, P, H, W, mode, (unsigned long long)fill_bits);
+  } else {
+    return CSS_ERR_DTYPE;
+  }
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+

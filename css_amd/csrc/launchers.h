@@ -173,3 +173,5 @@ int css_launch_bn_peer_finalize(const unsigned long long* bases, int world, int 
                                 int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
                                 float* mean, float* invstd, float* scale, float* shift, double* count_out, int* status, long long timeout, int phase,
                                 hipStream_t st);
+int css_launch_mix_boxes(const void* self, const void* partner, void* out, const int* boxes, const int* pj, int B, int P, int H, int W, int elem_bytes,
+                         int mode, long long fill_bits, hipStream_t st);

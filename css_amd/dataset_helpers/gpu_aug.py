@@ -202,6 +202,26 @@ def _mix(tensors, mode, rng, prefetched=None):
         if mode == "classmix":               # one mask per gathered image, drawn from that image's label map (VOC.py:412,424)
             labels_all = [torch.empty_like(tensors[1]) for _ in range(world)]
             dist.all_gather(labels_all, tensors[1].contiguous())
+    if mode != "classmix" and all(t.is_cuda and t.is_contiguous() and t.element_size() in (4, 8) for t in list(tensors) + list(partners)):
+        # device tensors: the boxes of the whole batch in ONE launch per tensor (css_mix_boxes) instead of a clone + one strided copy per
+        # image and tensor; every rank still draws for ALL gathered images in order and keeps the block of its own rank (VOC.py:411-437)
+        from .._lib import call, dev_stream
+        boxes = torch.zeros((b, 4), dtype=torch.int32)
+        for gi in range(world * b):
+            y0, y1, x0, x1 = cutout_box(h, w, 2, rng)
+            if rank * b <= gi < (rank + 1) * b:
+                boxes[gi - rank * b] = torch.tensor([y0, y1, x0, x1], dtype=torch.int32)
+        boxes = boxes.to(image.device)
+        pj = ((torch.arange(b, dtype=torch.int32) + rank * b + 1) % b).to(image.device)      # partner of gathered image gi: (gi + 1) % B
+        dev_i, st = dev_stream(image)
+        outs = []
+        for t, pt in zip(tensors, partners):
+            o = torch.empty_like(t)
+            planes = t.shape[1] if t.dim() == 4 else 1
+            fill = -1 if t.dtype == torch.int64 else 0
+            call("css_mix_boxes", t, pt, o, boxes, pj, b, planes, h, w, t.element_size(), 0 if mode == "cutmix" else 1, fill, dev_i, st)
+            outs.append(o)
+        return outs
     outs = [t.clone() for t in tensors]
     # every rank draws for ALL gathered images in order and keeps the block of its own rank (VOC.py:411-437)
     for gi in range(world * b):

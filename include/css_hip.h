@@ -229,6 +229,11 @@ CSS_API int css_aug_geom(const float* img, const float* label, const float* logi
  * (float bits), 8 hue shift (uint8), 9 blur on, 10 / 11 box-blur centre / neighbour weight (24-bit fixed point). */
 CSS_API int css_aug_color(uint8_t* img_q, uint8_t* tmp, const int* jp, int64_t* sums, int B, int H, int W, int any_jitter, int any_blur,
                           int device, css_stream_t stream);
+/* cutmix / cutout boxes of a whole batch in one launch per tensor (generate_cut_gather*, VOC.py:354-477): out[b][p][y][x] = inside box b ?
+ * (mode 0: partner[pj[b]][p][y][x] | mode 1: fill_bits) : self[b][p][y][x]; boxes int32 [B][4] = {y0, y1, x0, x1} half-open; contiguous
+ * [B][P][H][W] tensors of elem_bytes = 4 or 8 (fp32 images / confidence maps, int64 label maps).  A pure copy: bit-exact. */
+CSS_API int css_mix_boxes(const void* self, const void* partner, void* out, const int* boxes, const int* pj, int B, int P, int H, int W, int elem_bytes,
+                          int mode, long fill_bits, int device, css_stream_t stream);
 CSS_API int css_aug_finish(const uint8_t* img_q, const uint8_t* lab_q, const uint8_t* l1_q, const uint8_t* l2_q, const int* flags, int B, int Hc,
                            int Wc, float* img, int64_t* label, float* logits1, float* logits2, int device, css_stream_t stream);
 

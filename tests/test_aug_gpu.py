@@ -191,3 +191,23 @@ def test_mixing_modes_on_device():
         assert len(kept) == len(torch.unique(lab[i])) // 2            # half of the image's classes survive
         other = ~((o1[i] == l1[i]) & (o1[i] != l1[j]))
         assert torch.equal(o2[i][other], l2[j][other]) and torch.equal(oi[i][:, other], img[j][:, other])
+
+
+def test_mix_boxes_kernel_equals_the_indexing_path():
+    """css_mix_boxes (one launch per tensor for the boxes of the whole batch) against the per-image indexing path the CPU tensors take
+    (generate_cut_gather*, VOC.py:354-477): the same draws, the same bits - cutmix and cutout, the 2-, 3- and 1-label forms, a batch whose
+    size does not divide anything, int64 labels with -1."""
+    import numpy as np
+    from css_amd.dataset_helpers import gpu_aug
+    g = torch.Generator().manual_seed(4)
+    b, h, w = 5, 37, 45
+    img = torch.randn(b, 3, h, w, generator=g)
+    lab = torch.randint(-1, 21, (b, h, w), generator=g)
+    l1, l2 = torch.rand(b, h, w, generator=g), torch.rand(b, h, w, generator=g)
+    for mode in ("cutmix", "cutout"):
+        for fn, args in ((gpu_aug.generate_cut_gather_2, (img, lab, l1, l2)), (gpu_aug.generate_cut_gather_3, (img, lab, lab.flip(0), l1, l2)),
+                         (gpu_aug.generate_cut_gather, (img, lab, l1))):
+            want = fn(*[t.clone() for t in args], mode=mode, rng=np.random.RandomState(11))
+            got = fn(*[t.to(dev()) for t in args], mode=mode, rng=np.random.RandomState(11))
+            for a, c in zip(want, got):
+                assert a.dtype == c.dtype and torch.equal(a, c.cpu()), (mode, fn.__name__)
