@@ -795,9 +795,16 @@ static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b, int n_cu
     hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 64, 64, 2, 2>), g, dim3(256), 0, st, b);
   }
 }
-static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b) {
+static void launch_small_n128(dim3 g, hipStream_t st, const ConvArgs& b, int n_cu = 0) {
   static const bool dma = !(getenv("CSS_SMALL_DMA") && atoi(getenv("CSS_SMALL_DMA")) == 0) && !getenv("CSS_NO_DMA_CONV");
-  if (dma && b.Cs % 64 == 0) {
+  // more workgroups than CUs: TWO LDS stages (72 KiB) instead of three (104 KiB) let two workgroups share a CU - two waves per SIMD at
+  // different points of the wait -> barrier -> issue -> read -> multiply chain instead of one (CSS_SMALL_NST2=0/1 overrides)
+  // (measured, alternating processes: c4 136.0 -> 133.3 ms per step - its leftover launches are 306 workgroups, two rounds of one per CU
+  // before - and c2 113.3 -> 113.1)
+  static const int nst2 = getenv("CSS_SMALL_NST2") ? atoi(getenv("CSS_SMALL_NST2")) : 1;
+  if (dma && b.Cs % 64 == 0 && nst2 && n_cu > 0 && (int)g.x > n_cu) {
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2, 2>), g, dim3(256), 0, st, b);
+  } else if (dma && b.Cs % 64 == 0) {
     hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 128, 2, 2>), g, dim3(256), 0, st, b);
   } else {
     hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, 128, 64, 2, 2>), g, dim3(256), 0, st, b);
@@ -873,7 +880,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
           if ((rem_mode == 1 && wgs128 * 2 <= n_cu) || (rem_mode == 2 && wgs128 <= n_cu))
             launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b, n_cu);
           else
-            launch_small_n128(dim3(wgs128), st, b);
+            launch_small_n128(dim3(wgs128), st, b, n_cu);
         }
         P1();
       }
@@ -898,13 +905,13 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
         ConvArgs b = a;
         b.m_begin = full_mt * 256;
         P0(false, (double)(b.M - b.m_begin) / a.M);
-        launch_small_n128(dim3(cdiv(a.M - b.m_begin, 128) * nt_n), st, b);
+        launch_small_n128(dim3(cdiv(a.M - b.m_begin, 128) * nt_n), st, b, n_cu);
         P1();
       }
     } else if (a.Cd > 64) {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 128));
       P0(false, (double)(a.M - a.m_begin) / a.M);
-      launch_small_n128(g, st, a);
+      launch_small_n128(g, st, a, n_cu);
       P1();
     } else {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 64));

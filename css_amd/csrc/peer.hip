@@ -72,7 +72,9 @@ __global__ __launch_bounds__(1024) void bn_peer_exchange_kernel(const unsigned l
   __syncthreads();
   for (int i = tid; i < n; i += 1024) {
     double s = 0.0;
-    for (int r = 0; r < world; ++r) s += sys_load(reinterpret_cast<const double*>(bases[r]) + (size_t)slot * slot_doubles + i);     // rank order
+    // rank order; this rank's own term comes from `local` (the very numbers it published: no round trip through its slot)
+    for (int r = 0; r < world; ++r)
+      s += (r == rank && phase != 2) ? local[i] : sys_load(reinterpret_cast<const double*>(bases[r]) + (size_t)slot * slot_doubles + i);
     if (FINALIZE) tot[i] = s;
     else out[i] = s;
   }
