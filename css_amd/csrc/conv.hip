@@ -783,12 +783,20 @@ __global__ __launch_bounds__(64 * NWM * NWN * NWK) void conv_igemm_dma_kernel(co
 // --------------------------------------------------------------------------
 // 128-row tiles (leftover rows of the big-tile kernels, layers with Cout <= 64): LDS-DMA instances; CSS_SMALL_DMA=0 selects the
 // register-staged kernels instead (kept for the fp32 path and as the A/B reference)
-static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b, int n_cu = 0) {
+static inline bool small64_nst2() {
+  // (measured, alternating processes on one box: c2 116.0 -> 115.3 ms per step, c4 137.4 -> 135.9: profiles/r04_small64_nst2_ab.txt)
+  static const int v = getenv("CSS_SMALL64_NST2") ? atoi(getenv("CSS_SMALL64_NST2")) : 1;
+  return v != 0;
+}
+static void launch_small_n64(dim3 g, hipStream_t st, const ConvArgs& b, int n_cu = 0, bool leftover = false) {
   static const bool dma = !(getenv("CSS_SMALL_DMA") && atoi(getenv("CSS_SMALL_DMA")) == 0) && !getenv("CSS_NO_DMA_CONV");
   static const bool no_split = getenv("CSS_NO_SMALL_SPLITK") != nullptr;
-  if (dma && b.Cs % 64 == 0 && !no_split && n_cu > 0 && (int)g.x <= n_cu && b.Ktot >= 8 * 64 && !b.bias) {
+  if (dma && b.Cs % 64 == 0 && !no_split && leftover && n_cu > 0 && (int)g.x <= n_cu && b.Ktot >= 8 * 64 && !b.bias) {
     // at most one workgroup per CU (the leftover rows of the persistent kernels): two K groups per workgroup
     hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2, 3, 2>), g, dim3(512), 0, st, b);
+  } else if (dma && b.Cs % 64 == 0 && small64_nst2() && n_cu > 0 && (int)g.x > 2 * n_cu) {
+    // more than two workgroups per CU: two LDS stages (51 KiB) let THREE share a CU instead of two (the Cout <= 64 layers; CSS_SMALL64_NST2=0: off)
+    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2, 2>), g, dim3(256), 0, st, b);
   } else if (dma && b.Cs % 64 == 0) {      // (channel counts that are not whole K tiles - the 7x7 stem - change tap inside a tile: register-staged)
     hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 64, 2, 2>), g, dim3(256), 0, st, b);
   } else {
@@ -878,7 +886,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
           static const int rem_mode = getenv("CSS_REM_N64") ? atoi(getenv("CSS_REM_N64")) : 1;
           const int wgs128 = cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 128);
           if ((rem_mode == 1 && wgs128 * 2 <= n_cu) || (rem_mode == 2 && wgs128 <= n_cu))
-            launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b, n_cu);
+            launch_small_n64(dim3(cdiv(a.M - b.m_begin, 128) * cdiv(a.Cd, 64)), st, b, n_cu, true);
           else
             launch_small_n128(dim3(wgs128), st, b, n_cu);
         }
@@ -916,7 +924,7 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
     } else {
       dim3 g(cdiv(a.M, 128) * cdiv(a.Cd, 64));
       P0(false, (double)(a.M - a.m_begin) / a.M);
-      launch_small_n64(g, st, a);
+      launch_small_n64(g, st, a, n_cu);
       P1();
     }
   } else if (dtype == CSS_F32) {

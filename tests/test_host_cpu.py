@@ -208,6 +208,11 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     assert sum("v_mfma_f32_32x32x16_bf16" in l for l in lines[start:end]) == 16
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 2 * (128 + 128) * 128 + 2 * 12 * 64 * 4
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
+    sym = "_Z21conv_igemm_dma_kernelILi128ELi64ELi2ELi2ELi2ELi1EE"          # and of the 128x64 kernel: 51 KiB, three workgroups per CU
+    start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 2 * (128 + 64) * 128 + 2 * 12 * 32 * 4
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
     # weight-gradient kernels live in conv_wgrad.hip (the 256x256 forward kernel of rounds 1-2 and the one-barrier weight-gradient kernels were
     # archived under scripts/proto in round 4)
     src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv_wgrad.hip")
