@@ -897,9 +897,13 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
       // kernel (4x as many, smaller tiles, two per CU) instead of paying a full extra round for a fraction of one.
       const int nt_n = cdiv(a.Cd, 128), mt = cdiv(a.M, 256);
       const int slots = n_cu;
-      int full_mt = mt;
+      // Round 4: with two workgroups of the two-stage 128x128 kernel per CU the Cout = 65..255 layers run all their rows there - no
+      // 256x128 launch + leftover launch pair (conv forward + dgrad kernels of the step: c4 69.7 -> 68.9 ms, c2 59.2 -> 58.7;
+      // profiles/r04_n128_small_only_ab.txt).  CSS_N128_SMALL_ONLY=0: the 256x128 kernel for the whole rounds again.
+      static const bool small_only = !(getenv("CSS_N128_SMALL_ONLY") && atoi(getenv("CSS_N128_SMALL_ONLY")) == 0);
+      int full_mt = small_only ? 0 : mt;
       const double rounds = (double)mt * nt_n / slots;
-      if (rounds > 1.0 && rounds - (long)rounds < 0.6 && (rounds - (long)rounds) > 1e-9) {
+      if (!small_only && rounds > 1.0 && rounds - (long)rounds < 0.6 && (rounds - (long)rounds) > 1e-9) {
         full_mt = (int)((long)rounds * slots / nt_n);      // m-tiles covered by whole rounds
       }
       if (full_mt > 0) {

@@ -55,7 +55,7 @@ assert max(e) < 2e-2 and es < 2e-3, (e, es)
 
 SWITCHES = [{}, {"CSS_NO_P8_CONV": "1"}, {"CSS_NO_SMALL_SPLITK": "1"}, {"CSS_NO_P8_CONV": "1", "CSS_NO_PP_CONV": "1"},
             {"CSS_PP_KORDER": "0"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"}, {"CSS_WGRAD_ATOMICS": "1"},
-            {"CSS_NO_DMA256_WGRAD": "1"}, {"CSS_REM_N64": "1"}, {"CSS_BN_RED_BLOCKS": "256"}, {"CSS_SMALL_NST2": "0", "CSS_SMALL64_NST2": "0"}]
+            {"CSS_NO_DMA256_WGRAD": "1"}, {"CSS_REM_N64": "1"}, {"CSS_BN_RED_BLOCKS": "256"}, {"CSS_SMALL_NST2": "0", "CSS_SMALL64_NST2": "0"}, {"CSS_N128_SMALL_ONLY": "0"}]
 
 
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()) or "default")
