@@ -5,6 +5,7 @@
 #include "launchers.h"
 
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -301,6 +302,55 @@ int css_bn_finalize(const double* sums, int G, double count, const double* count
                     css_stream_t stream) {
   set_dev(device);
   return css_launch_bn_finalize(sums, G, count, count_dev, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, C, S(stream));
+}
+int css_peer_alloc(size_t bytes, int device, void** out, int* mem_kind_out) {
+  if (!out || bytes == 0) return CSS_ERR_ARG;
+  set_dev(device);
+  void* p = nullptr;
+  int kind = 1;
+  if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained) != hipSuccess || !p) {
+    (void)hipGetLastError();
+    kind = 2;
+    p = nullptr;
+    if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) != hipSuccess || !p) {
+      (void)hipGetLastError();
+      return CSS_ERR_WORKSPACE;
+    }
+  }
+  if (hipMemset(p, 0, bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(p);
+    return CSS_ERR_LAUNCH;
+  }
+  *out = p;
+  if (mem_kind_out) *mem_kind_out = kind;
+  return CSS_OK;
+}
+int css_peer_free(void* p, int device) {
+  set_dev(device);
+  return (!p || hipFree(p) == hipSuccess) ? CSS_OK : CSS_ERR_ARG;
+}
+int css_peer_ipc_export(void* p, int device, unsigned char* handle64) {
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  if (!p || !handle64) return CSS_ERR_ARG;
+  set_dev(device);
+  hipIpcMemHandle_t h;
+  if (hipIpcGetMemHandle(&h, p) != hipSuccess) { (void)hipGetLastError(); return CSS_ERR_ARG; }
+  memcpy(handle64, &h, 64);
+  return CSS_OK;
+}
+int css_peer_ipc_open(const unsigned char* handle64, int device, void** out) {
+  if (!handle64 || !out) return CSS_ERR_ARG;
+  set_dev(device);
+  hipIpcMemHandle_t h;
+  memcpy(&h, handle64, 64);
+  void* p = nullptr;
+  if (hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !p) { (void)hipGetLastError(); return CSS_ERR_ARG; }
+  *out = p;
+  return CSS_OK;
+}
+int css_peer_ipc_close(void* p, int device) {
+  set_dev(device);
+  return (!p || hipIpcCloseMemHandle(p) == hipSuccess) ? CSS_OK : CSS_ERR_ARG;
 }
 size_t css_peer_buffer_bytes(int slot_doubles) { return css_peer_buffer_bytes_(slot_doubles); }
 int css_bn_peer_finalize(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local, int G, int C,

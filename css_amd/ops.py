@@ -386,9 +386,10 @@ def _row_stride(t):
 def _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, dev, st):
     """SyncBN forward: (sum, sum of squares, row count) of every rank -> global statistics, finalised.  Counts may differ per rank: they ride
     behind the sums.  -> the [G] global counts on the device (the backward divides by them)."""
-    if peer.enabled():           # peer-mapped exchange buffers: one launch, no RCCL call (css_amd/peer.py)
+    ex = peer.exchange(stats.device) if peer.enabled() else None      # (None: not asked for, or refused for this group -> RCCL)
+    if ex is not None:           # peer-mapped exchange buffers: one launch, no RCCL call (css_amd/peer.py)
         count_t = torch.empty(g, dtype=torch.float64, device=stats.device)
-        peer.exchange(stats.device).finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, count_t)
+        ex.finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum, eps, mean, invstd, scale, shift, count_t)
         return count_t
     dist.all_reduce(stats)
     count_t = stats[g * 2 * c:]
@@ -502,8 +503,9 @@ class _BNAct(torch.autograd.Function):
             call("css_bn_reduce", partial, nrb, c, g, sums, dgamma, dbeta, 0, 0.0, dev, st)
         if sync and collectives_on():
             # SyncBN backward: global sum(dz), sum(dz*xhat) per group
-            if peer.enabled():
-                peer.exchange(y.device).gather(sums)
+            ex = peer.exchange(y.device) if peer.enabled() else None
+            if ex is not None:
+                ex.gather(sums)
             else:
                 dist.all_reduce(sums)
         dy = torch.empty_like(y)

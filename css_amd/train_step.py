@@ -68,12 +68,14 @@ class MixTrainer:
         self._buckets = None                   # [(runs = [(start, end), ...], frozenset of the bucket's spans)]
         self._span_reports = None              # span -> number of gradient reports per step (recorded on the first step)
         self._span_bucket = None               # span -> index of its bucket
-        self._flags = [torch.zeros(1, device=self.flat_g.device) for _ in range(2)]   # violation flag agreed across ranks (MAX all-reduce)
-        self._flag_host = [torch.zeros(1).pin_memory() if torch.cuda.is_available() else torch.zeros(1) for _ in range(2)]
-        self._flag_pending = None              # (pinned host copy of the agreed flag, event recorded behind the copy)
+        # The verdict of a step, agreed across ranks with one MAX all-reduce: non-zero when some rank's gradient reports did not fit the bucket
+        # plan OR (CSS_SYNCBN=peer) an exchange of some rank gave up waiting for a peer.  It (a) stops the step's optimizer on the device
+        # (css_sgd_ema's skip_flag: weights, momentum and teacher stay those of the last valid step - on EVERY rank, so replicas stay
+        # equal) and (b) travels to a pinned host word behind an event that later steps POLL (never wait for) - see _check_verdicts.
+        self._flags = [torch.zeros(2, device=self.flat_g.device) for _ in range(2)]   # [agreed verdict, this rank's own reason code]
+        self._verdicts = []                    # pending (pinned [verdict, local reason], event, iteration) in step order
+        self._pinned_pool = []
         self._skip_flag = None                 # device flag of THIS step for css_sgd_ema (non-zero: leave weights / momentum / teacher alone)
-        self._peer_pending = None              # (pinned copy of the SyncBN peer-exchange status word, event) of the previous step
-        self._peer_host = None                 # two pinned words, alternating (allocated on first use)
 
     # ---- what differs between the three entry scripts (overridden by CrossTrainer / OriTrainer below) -------------------------
     def _student_outputs(self, l_img, u_img):
@@ -135,6 +137,8 @@ class MixTrainer:
             ops.assert_no_lazy_res_grads()
             if sync:
                 dist.all_reduce(self.flat_g)     # one bucket, after backward
+                if peer.enabled():               # (no bucket plan here; the peer exchange still needs an agreed verdict)
+                    self._agree_on_verdict(0, None, None)
             return
         if self._grad_pg is None:
             self._grad_pg = dist.new_group()     # same ranks, own communicator / stream
@@ -189,6 +193,8 @@ class MixTrainer:
             self._buckets = self._plan_buckets(order)
             self._span_bucket = {sp: b for b, (_, spans) in enumerate(self._buckets) for sp in spans}
             dist.all_reduce(self.flat_g, group=self._grad_pg)
+            if peer.enabled():
+                self._agree_on_verdict(0, self._grad_pg, None)
             return
         if state["b"] < len(self._buckets):      # incomplete spans: the graph changed; keep the collective sequence identical on every rank
             state["bad"] = 1
@@ -204,67 +210,72 @@ class MixTrainer:
         if pos < self.flat_g.numel():
             rest.append((pos, self.flat_g.numel()))
         launch(rest)
-        flag = self._flags[self.it & 1]
-        flag.fill_(float(state["bad"]))
-        works.append(dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._grad_pg, async_op=True))
+        self._agree_on_verdict(state["bad"], self._grad_pg, works)
         for w in works:
             w.wait()                             # the compute stream waits for the buckets (host does not block on RCCL)
-        # the agreed flag (a) stops this step's optimizer on the device (css_sgd_ema skips: no invalid gradient ever reaches the weights, the
-        # momentum or the teacher) and (b) travels to a pinned host buffer behind an event, read at the start of the next step - by then the
-        # copy has long landed, so the host never blocks on the device inside a step (float(flag[0]) here drained the forward)
+
+    def _agree_on_verdict(self, bad, group, works):
+        """One small MAX all-reduce behind the gradient buckets: [bucket-plan violation | peer-exchange timeout] of ANY rank -> every rank.
+        ``works``: a list to append the asynchronous collective to (overlap path), or None for a blocking call on ``group``."""
+        flag = self._flags[self.it & 1]
+        code = 1.0 if bad else 0.0
+        flag.fill_(code)
+        ex = peer.exchange(self.flat_p.device) if (peer.enabled() and ops.collectives_on()) else None
+        if ex is not None:                       # this step's exchanges (forward and backward) are all queued ahead of this point
+            timed_out = ex.status.ne(0).to(flag.dtype)
+            flag[0:1].copy_(torch.maximum(flag[0:1], timed_out))
+            flag[1:2].add_(2.0 * timed_out)
+            ex.status.zero_()                    # (stream-ordered behind the read: the next step starts from a clean word)
+        if works is not None:
+            works.append(dist.all_reduce(flag[0:1], op=dist.ReduceOp.MAX, group=group, async_op=True))
+            works[-1].wait()                     # (stream-level wait: the host copy below is ordered behind the collective)
+        else:
+            dist.all_reduce(flag[0:1], op=dist.ReduceOp.MAX, group=group)
         self._skip_flag = flag
-        host = self._flag_host[self.it & 1]
+        host = self._pinned_pool.pop() if self._pinned_pool else (torch.zeros(2).pin_memory() if flag.is_cuda else torch.zeros(2))
         host.copy_(flag, non_blocking=True)
         ev = None
         if flag.is_cuda:
             ev = torch.cuda.Event()
             ev.record()
-        self._flag_pending = (host, ev)
+        self._verdicts.append((host, ev, self.it))
+
+    def _check_verdicts(self, block=False):
+        """Raise - on every rank - when the agreed verdict of an earlier step was non-zero.  Inside a run the pinned copies are POLLED
+        (``event.query()``: ADVICE r04 - a wait here blocked the host until the previous backward had drained, so it could never queue the
+        next forward ahead of the GPU); a verdict that has not landed yet is looked at by a later step, `finish()` or `state_dict()`
+        (``block=True``).  Late is safe: the step was already skipped on the device.  On a violation the iteration counter, the EMA step
+        counter and the bucket plan go back to the state of the last APPLIED step before the exception leaves."""
+        while self._verdicts:
+            host, ev, it = self._verdicts[0]
+            if ev is not None and not ev.query():
+                if not block:
+                    return
+                ev.synchronize()
+            self._verdicts.pop(0)
+            verdict, mine = float(host[0]), int(host[1])
+            self._pinned_pool.append(host)
+            if verdict != 0.0:
+                self._verdicts.clear()
+                self._buckets = None
+                self.it -= 1                     # that step changed nothing: lr schedule and EMA decay continue from the last valid step
+                self.model.step -= 1
+                why = {0: "another rank reported it", 1: "this rank's gradient reports did not fit the recorded bucket plan",
+                       2: "a SyncBN peer exchange of this rank timed out waiting for a peer (CSS_PEER_TIMEOUT_S)",
+                       3: "bucket-plan violation and peer-exchange timeout on this rank"}.get(mine, str(mine))
+                raise RuntimeError(f"training step {it} was invalid and has been skipped on every rank ({why}): gradient readiness changed "
+                                   "between steps on some rank (a span reported more or less often than on the first step) or SyncBN "
+                                   "statistics were incomplete; buckets were reset on every rank, weights / momentum / teacher are those of "
+                                   "the last valid step (batch-norm running statistics of the skipped step are not rolled back) - rebuild the "
+                                   "trainer or resume from the last checkpoint")
 
     def _check_bucket_flag(self):
-        """Raise - on every rank - when some rank's gradient reports did not fit the recorded plan.  The agreed flag is read ONE STEP
-        LATE (start of the next step, `finish()`, or before a checkpoint is written) from its pinned host copy; the step it belongs to was
-        already skipped on the device (css_sgd_ema's skip_flag), so weights, momentum and teacher are those of the last valid step."""
-        pending, self._flag_pending = self._flag_pending, None
-        if pending is None:
-            return
-        host, ev = pending
-        if ev is not None:
-            ev.synchronize()
-        if float(host[0]) != 0.0:
-            self._buckets = None
-            raise RuntimeError("gradient readiness changed between steps on some rank (a span reported more or less often than on the "
-                               "first step); buckets were reset on every rank - the gradients of that step are invalid, rebuild the "
-                               "trainer for a new graph")
-
-    def _check_peer_status(self):
-        """CSS_SYNCBN=peer: an exchange of the previous step that gave up waiting for a peer (css_amd/peer.py) - read one step late from a
-        pinned copy, like the bucket flag."""
-        pending, self._peer_pending = getattr(self, "_peer_pending", None), None
-        if pending is None:
-            return
-        host, ev = pending
-        ev.synchronize()
-        if int(host[0]) != 0:
-            raise RuntimeError(f"SyncBN peer exchange {int(host[0])} of the previous step timed out waiting for a peer: its statistics were "
-                               "incomplete, the step is invalid")
-
-    def _queue_peer_status(self):
-        if not (peer.enabled() and ops.collectives_on()):
-            return
-        ex = peer.exchange(self.flat_p.device)
-        if self._peer_host is None:
-            self._peer_host = [torch.zeros(1, dtype=torch.int32).pin_memory() for _ in range(2)]
-        host = self._peer_host[self.it & 1]
-        host.copy_(ex.status, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-        self._peer_pending = (host, ev)
+        """(kept for direct callers of _backward_and_reduce: the non-blocking poll)"""
+        self._check_verdicts(False)
 
     def finish(self):
-        """Call after the last step of a run and before saving a checkpoint: surfaces a pending bucket-plan violation of the final step."""
-        self._check_bucket_flag()
-        self._check_peer_status()
+        """Call after the last step of a run and before saving a checkpoint: surfaces a pending invalid-step verdict (waits for it)."""
+        self._check_verdicts(True)
 
     def state_dict(self):
         """Trainer state for a checkpoint (checked first: a step whose gradients were invalid raises here instead of being saved)."""
@@ -277,8 +288,7 @@ class MixTrainer:
 
     def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
         m = self.model
-        self._check_bucket_flag()                                            # (before anything of this step is queued: the read cannot stall it)
-        self._check_peer_status()
+        self._check_verdicts(False)                                          # (a poll: the host never waits for the device here)
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
         # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
         # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144
@@ -304,7 +314,6 @@ class MixTrainer:
         call("css_sgd_ema", self.flat_p, self.flat_g, self.flat_m, self.flat_ema, self.flat_p.numel(), float(self.lr), float(self.momentum),
              float(self.wd), int(self.it == 0), float(decay), 1.0 / world, self._skip_flag, dev, st)
         m.refresh_weights()
-        self._queue_peer_status()
         m.step += 1
         self.it += 1
         return dict(sup=sup.detach(), unsup=unsup.detach(), contrast=con.detach(), total=total.detach(), pseudo=u_lab)

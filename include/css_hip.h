@@ -144,6 +144,17 @@ CSS_API int css_bn_finalize(const double* sums, int G, double count, const doubl
  * counts as css_bn_reduce / css_bn_reduce_finalize_slabs emit them; does css_bn_finalize's work in the same launch and writes the global
  * counts to count_out[G].  css_bn_peer_gather (backward): out[n] = the summed doubles (out may alias local).  phase 0 = whole exchange;
  * 1 = publish only, 2 = wait + sum only (tests that play several ranks in one process). */
+/* Exchange-buffer memory (peers poll flags and read payloads INSIDE a running kernel; HIP promises cross-device visibility of
+ * ordinary coarse-grained hipMalloc memory at kernel boundaries only).  css_peer_alloc: bytes of FINE-GRAINED device memory
+ * (hipExtMallocWithFlags(hipDeviceMallocFinegrained), hipDeviceMallocUncached if that is refused), zero-filled, the device synchronised - the
+ * one documented allocation of the library (a caching allocator cannot hand out this memory type).  css_peer_ipc_export: the 64-byte
+ * hipIpcMemHandle_t of such a buffer; css_peer_ipc_open: a peer's buffer mapped into this process (node-local: hipIpc does not cross hosts);
+ * css_peer_ipc_close / css_peer_free undo them.  *mem_kind_out: 1 = fine-grained, 2 = uncached. */
+CSS_API int css_peer_alloc(size_t bytes, int device, void** out, int* mem_kind_out);
+CSS_API int css_peer_free(void* p, int device);
+CSS_API int css_peer_ipc_export(void* p, int device, unsigned char* handle64);
+CSS_API int css_peer_ipc_open(const unsigned char* handle64, int device, void** out);
+CSS_API int css_peer_ipc_close(void* p, int device);
 CSS_API size_t css_peer_buffer_bytes(int slot_doubles);
 CSS_API int css_bn_peer_finalize(const unsigned long long* bases, int world, int rank, unsigned long long seq, int slot_doubles, const double* local,
                                  int G, int C, const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,

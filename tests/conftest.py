@@ -29,7 +29,10 @@ def pytest_configure(config):
 _RANK = {"test_oracle_golden": 0, "test_host_cpu": 0, "test_dataset_cpu": 0, "test_dist_cpu": 0,
          "test_full_size_gpu": 2, "test_dist_gpu": 2, "test_kernel_switches_gpu": 2, "test_determinism_gpu": 2,
          "test_bf16_trajectory_gpu": 3}
-_RANK_BY_NAME = {"test_three_steps_fp32_and_bf16_vs_oracle": 1}      # (an oracle parity test that lives in the trajectory file)
+_RANK_BY_NAME = {"test_three_steps_fp32_and_bf16_vs_oracle": 1,      # (an oracle parity test that lives in the trajectory file)
+                 # the oracle parity tests of the full-size file (configs[0] as a step, bf16 at 129^2)
+                 "test_c1_config_logits_vs_oracle_fp32": 1, "test_c1_full_step_vs_oracle_fp32": 1,
+                 "test_bf16_step_vs_oracle_with_injected_draws": 1, "test_bf16_step_vs_oracle_129_b4": 1}
 
 
 def pytest_collection_modifyitems(session, config, items):

@@ -139,10 +139,10 @@ def _bucket_worker(rank, world, port, q, mode="plain"):
     tr.flat_g = flat_g
     tr._span = {id(p): (o, e) for p, o, e in zip(params, offs, offs[1:] + [tot])}
     tr.bucket_mb = 4096 / 2 ** 20                                   # 1024 floats per bucket
-    tr._grad_pg = tr._ready_order = tr._buckets = tr._span_reports = tr._span_bucket = tr._flag_pending = None
-    tr._flags = [torch.zeros(1), torch.zeros(1)]
-    tr._flag_host = [torch.zeros(1), torch.zeros(1)]
-    tr._skip_flag = tr._peer_pending = tr._peer_host = None
+    tr._grad_pg = tr._ready_order = tr._buckets = tr._span_reports = tr._span_bucket = tr._skip_flag = None
+    tr._flags = [torch.zeros(2), torch.zeros(2)]
+    tr._verdicts, tr._pinned_pool = [], []
+    tr.model = type("M", (), dict(step=0))()                    # (the EMA step counter a skipped step rolls back)
     tr.it = 0
     errs = []
     raised = []

@@ -333,6 +333,70 @@ def test_rccl_collectives_on_one_rank_change_nothing(tmp_path):
         assert ((qa - qb).norm() / qa.norm().clamp_min(1e-12)).item() < 1e-4
 
 
+SKIP_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from css_amd import peer
+from css_amd.networks import resnet
+from css_amd.networks.ddp_model import Model_mix
+from css_amd.train_step import MixTrainer
+dev = torch.device("cuda:0")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+K, S = 21, 65
+torch.manual_seed(11)
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix", "device_aug": "identity"}}
+m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
+m.model.train(); m.ema_model.train()
+m.set_compute_dtype(torch.bfloat16)
+tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
+g = torch.Generator().manual_seed(100)
+import numpy as np
+np.random.seed(3)
+def batch():
+    return (torch.randn(2, 3, S, S, generator=g).to(dev), torch.randint(-1, K, (2, S, S), generator=g).to(dev), torch.randn(2, 3, S, S, generator=g).to(dev))
+tr.step(*batch()); tr.step(*batch())
+tr.finish()
+ex = peer.exchange(dev)
+assert ex is not None and ex.mem_kind in ("fine-grained", "uncached")
+p0, m0, e0 = tr.flat_p.clone(), tr.flat_m.clone(), tr.flat_ema.clone()
+it0, step0 = tr.it, m.step
+ex.status.fill_(77)                     # what the exchange kernel leaves behind when it gave up waiting for a peer
+tr.step(*batch())                       # this step must not reach weights, momentum or teacher
+torch.cuda.synchronize()
+same = bool(torch.equal(tr.flat_p, p0) and torch.equal(tr.flat_m, m0) and torch.equal(tr.flat_ema, e0))
+raised = ""
+try:
+    tr.finish()
+except RuntimeError as e:
+    raised = str(e)
+res = dict(same=same, raised=raised, it_back=(tr.it == it0), step_back=(m.step == step0), status=int(ex.status.item()), kind=ex.mem_kind)
+tr.step(*batch())                       # the trainer goes on (the caller decided to): a valid step moves the weights again
+tr.finish()
+res["moved"] = not bool(torch.equal(tr.flat_p, p0))
+json.dump(res, open(sys.argv[1], "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_peer_timeout_verdict_skips_the_step_on_the_device(tmp_path):
+    """ADVICE r04 (medium): a SyncBN peer exchange that gave up waiting leaves its number in the status word; the trainer ORs it into the
+    verdict every rank agrees on (one MAX all-reduce with the bucket flag), css_sgd_ema skips that step on the device - weights, momentum and
+    the EMA teacher bit-identical to before - and the host learns about it late (finish(): blocking; step(): a poll) with the iteration and
+    EMA-step counters rolled back.  Also: the exchange buffer is fine-grained memory of the library's own (css_peer_alloc)."""
+    import json
+    out = str(tmp_path / "skip.json")
+    env = dict(os.environ, CSS_FORCE_COLLECTIVES="1", CSS_SYNCBN="peer", MASTER_ADDR="127.0.0.1", MASTER_PORT="29581", RANK="0", WORLD_SIZE="1",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    p = subprocess.Popen([sys.executable, "-c", SKIP_WORKER % ROOT, out], env=env)
+    assert p.wait(timeout=900) == 0
+    r = json.load(open(out))
+    print(r)
+    assert r["same"] and r["it_back"] and r["step_back"] and r["moved"] and r["status"] == 0
+    assert "peer exchange" in r["raised"] and "skipped on every rank" in r["raised"]
+
+
 def test_peer_exchange_kernel_plays_three_ranks_in_one_process():
     """css_amd/csrc/peer.hip with W = 3 exchange buffers in ONE process: every exchange is played as publish (phase 1) for each rank, then
     wait + sum (phase 2) for each rank - the slot ring, the flags, the rank-ordered sum and the fused train-mode finalize are the multi-GPU

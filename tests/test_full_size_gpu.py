@@ -82,19 +82,22 @@ def test_c1_config_logits_vs_oracle_fp32():
     assert pred.shape == po.shape and e_p < 1e-3 and e_r < 1e-3
 
 
-def test_bf16_step_vs_oracle_with_injected_draws():
-    """The bf16 throughput path of MixTrainer.step against the fp32 CPU oracle at 65x65 (well-conditioned weights, the oracle's
-    sampler draws injected): bf16 activations through ~110 batch-stat BN layers - losses within 2e-2, prototype cosines > 0.97 / 0.99 mean."""
+def _step_vs_oracle(S, B, dtype, Q, N, seed, blocks):
+    """One MixTrainer.step on the HIP path against oracle.train_step_mix (mix_label.py:162-196) on the same seeded inputs and weights
+    (bn3 gains x0.25: the conditioning of a trained network), the oracle's sampler draws injected.  Returns (hip result, oracle result,
+    trainer, oracle state)."""
     from css_amd.networks import resnet
     from css_amd.networks.ddp_model import Model_mix
     from css_amd.train_step import MixTrainer
     from oracle import css_oracle as O
-    K, S, B, seed, gain = 21, 65, 2, 7, 0.25
+    K, gain = 21, 0.25
     cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}}
     g = torch.Generator().manual_seed(seed)
     l_img, u_img = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
-    l_lab = torch.randint(0, K, (B, 5, 5), generator=g).repeat_interleave(13, 1).repeat_interleave(13, 2)[:, :S, :S].clone()
-    args = dict(lr=1e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=64, num_negatives=128)
+    cell = -(-S // blocks)
+    l_lab = torch.randint(0, K, (B, blocks, blocks), generator=g).repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :S, :S].clone()
+    l_lab[:, : cell // 2, : cell] = -1                        # some ignored pixels, like the reference's 255 -> -1 border
+    args = dict(lr=1e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=Q, num_negatives=N)
     st = O.MixState("tv", K, 256, seed, gain)
     rec = {}
     torch.manual_seed(0)
@@ -104,20 +107,72 @@ def test_bf16_step_vs_oracle_with_injected_draws():
     sd = O.init_state("tv", K, 256, seed, gain)
     m.model.load_state_dict(sd)
     m.ema_model.load_state_dict(sd)
-    m = m.to(dev()).train().set_compute_dtype(torch.bfloat16)
-    tr = MixTrainer(m, K, lr=1e-3, total_iter=100, num_queries=64, num_negatives=128, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97)
-    # the class lists the draws index into depend on the hard flags (own-class probability < 0.8): under bf16 a few pixels near the
-    # threshold change sides, so the injected indices are taken modulo the list lengths by the kernel (css_contrast_resolve)
+    m = m.to(dev()).train().set_compute_dtype(dtype)
+    tr = MixTrainer(m, K, lr=1e-3, total_iter=100, num_queries=Q, num_negatives=N, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97)
+    # the class lists the draws index into depend on the hard flags (own-class probability < 0.8): where a pixel near the threshold
+    # changes sides the injected indices are taken modulo the list lengths by the kernel (css_contrast_resolve)
     r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()), _injected=dict(anchor=rec["anchor"], negative=rec["negative"]))
+    torch.cuda.synchronize()
+    return r, ro, tr, st
+
+
+def test_c1_full_step_vs_oracle_fp32():
+    """BASELINE configs[0] as a STEP: 321x321, B = 2 + 2, fp32, tv-R101, K = 21, Q = 256, N = 512 - teacher x2, student
+    forward / backward x2, the three losses, the prototype EMA, SGD + EMA teacher - against oracle.train_step_mix with injected draws:
+    losses 1e-3, prototypes 1e-3, pseudo labels < 0.5 % mismatching, the updated student weights on a probe."""
+    r, ro, tr, st = _step_vs_oracle(321, 2, torch.float32, 256, 512, 11, 10)
+    for key in ("sup", "unsup", "contrast"):
+        a, b = float(r[key]), float(ro[key])
+        print(f"c1 step fp32 {key}: hip {a:.6f} oracle {b:.6f} rel {abs(a - b) / max(1.0, abs(b)):.2e}")
     for key in ("sup", "contrast"):
         a, b = float(r[key]), float(ro[key])
-        print(f"bf16 {key}: hip {a:.5f} oracle {b:.5f}")
+        assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (key, a, b)
+    a, b = float(r["unsup"]), float(ro["unsup"])             # a mean over the few pixels above the 0.97 confidence threshold
+    assert (math.isnan(a) and math.isnan(b)) or abs(a - b) < 3e-2 * max(1.0, abs(b)), (a, b)
+    e = ((tr.prototypes.cpu() - st.prototypes).abs().max() / st.prototypes.abs().max()).item()
+    mism = (r["pseudo"].cpu() != ro["pseudo"]).float().mean().item()
+    print(f"c1 step fp32: prototypes rel {e:.2e}, pseudo labels mismatching {mism:.2e}")
+    assert e < 1e-3 and mism < 5e-3, (e, mism)
+    # the optimizer's result: updated student weights, and the UPDATE itself (lr x nesterov(gradient + wd x weight)) as a direction -
+    # a wrong gradient scale or a missed layer shows in the cosine, ReLU-flip noise of two fp32 forwards (test_network_gpu.py) does not
+    from oracle import css_oracle as O
+    w0 = O.init_state("tv", 21, 256, 11, 0.25)
+    names = [n for n in st.pnames if n.endswith("conv3.weight") or n.endswith("conv2.weight") or n.startswith("classifier")
+             or n.startswith("representation") or n.startswith("ASPP")][:: 3]
+    sdh = tr.model.model.state_dict()
+    worst_w, worst_c = 0.0, 1.0
+    for n in names:
+        wh, wo = sdh[n].detach().cpu().double(), st.student[n].detach().double()
+        worst_w = max(worst_w, rel_err(wh, wo))
+        worst_c = min(worst_c, torch.nn.functional.cosine_similarity((wh - w0[n].double()).flatten(), (wo - w0[n].double()).flatten(), dim=0).item())
+    print(f"c1 step fp32: updated student weights over {len(names)} probed layers: worst rel {worst_w:.2e}, worst update cosine {worst_c:.6f}")
+    assert worst_w < 1e-3 and worst_c > 0.995, (worst_w, worst_c)
+
+
+def _bf16_step_checks(r, ro, tr, st, tag):
+    for key in ("sup", "contrast"):
+        a, b = float(r[key]), float(ro[key])
+        print(f"{tag} bf16 {key}: hip {a:.5f} oracle {b:.5f}")
         assert abs(a - b) < 2e-2 * max(1.0, abs(b)), (key, a, b)
     pa, pb = tr.prototypes.cpu().double(), st.prototypes.double()
     present = pb.abs().sum(1) > 0
     cos = torch.nn.functional.cosine_similarity(pa[present], pb[present], dim=1)
-    print("bf16 prototypes: cosine over present classes: min", float(cos.min()), "mean", float(cos.mean()))
-    # measured on MI355X: min 0.986 (a class with few valid pixels: the mean of a handful of bf16-path embeddings)
+    print(f"{tag} bf16 prototypes: cosine over present classes: min", float(cos.min()), "mean", float(cos.mean()))
+    # measured on MI355X at 65^2: min 0.986 (a class with few valid pixels: the mean of a handful of bf16-path embeddings)
     assert present.any() and float(cos.min()) > 0.97 and float(cos.mean()) > 0.99
     mism = (r["pseudo"].cpu() != ro["pseudo"]).float().mean().item()
+    print(f"{tag} bf16 pseudo labels mismatching: {mism:.2e}")
     assert mism < 2e-2, mism
+
+
+def test_bf16_step_vs_oracle_with_injected_draws():
+    """The bf16 throughput path of MixTrainer.step against the fp32 CPU oracle at 65x65 (well-conditioned weights, the oracle's
+    sampler draws injected): bf16 activations through ~110 batch-stat BN layers - losses within 2e-2, prototype cosines > 0.97 / 0.99 mean."""
+    _bf16_step_checks(*_step_vs_oracle(65, 2, torch.bfloat16, 64, 128, 7, 5), "65^2 B=2+2")
+
+
+def test_bf16_step_vs_oracle_129_b4():
+    """The same at 129x129, B = 4 + 4, Q = 256, N = 512: here the BN / loss / contrast kernels of the bench dtype
+    run multi-tile launches (M = 8 x 17^2 ... 8 x 65^2 rows per layer, two statistics groups of 4 images) against an oracle, not
+    only against properties."""
+    _bf16_step_checks(*_step_vs_oracle(129, 4, torch.bfloat16, 256, 512, 13, 6), "129^2 B=4+4")

@@ -4,9 +4,11 @@ reference (tests/golden/net_*.npz).
 Two regimes (measured, see DESIGN.md "Parity"):
 * ``*_damped`` fixtures (bn3 gains x0.25, i.e. the well-conditioned regime of a trained network): the 1e-3 relative
   bar on logits that BASELINE.json's north_star states, asserted strictly.
-* undamped random-init fixtures with batch 2: the network itself amplifies a 1-ulp input perturbation to ~5e-4 and
-  the reference's own fp32 CPU output is only within ~1.4e-3 of an fp64 evaluation, so the HIP path is required to
-  be as close to the fp64 truth as the reference's fp32 path is (factor 2), plus a per-stage error-growth guard.
+* undamped random-init fixtures with batch 2: the network itself amplifies a 1-ulp perturbation (input, weights, or
+  the summation order of the oracle's own GEMMs) to 0.5 ... 1.8e-3 and the reference's own fp32 CPU output is only
+  within 0.5 ... 3.8e-3 of an fp64 evaluation.  The HIP-vs-reference error is printed and asserted against
+  max(1e-3, 2 x that measured floor) - the gap to north_star's 1e-3 is explicit in the log, not hidden in a flat
+  5e-3 - plus: as close to the fp64 truth as the reference's fp32 path, and a per-stage guard.
 """
 import pytest
 import torch
@@ -62,17 +64,39 @@ def test_network_fp32_vs_reference_golden(golden, tag, backbone):
         ref_p, ref_r = rel_err(gp, tp), rel_err(gr, tr)
         hip_p, hip_r = rel_err(pred.detach().cpu(), tp), rel_err(rep.detach().cpu(), tr)
         print(f"{tag}: vs fp64 truth: reference fp32 {ref_p:.2e}/{ref_r:.2e}, HIP fp32 {hip_p:.2e}/{hip_r:.2e}")
-        # noise floor of the problem itself: what a 1-ulp (1e-7 relative) input perturbation does to the fp32 oracle
+        # noise floor of the problem itself (round 5: the bound is DERIVED from it, no flat 5e-3 any more): what legitimate fp32
+        # evaluations of this very network differ by - a 1-ulp relative perturbation of the input (3 draws), of every weight (3 draws),
+        # and the same oracle on one thread (another summation order inside its GEMMs).  Each of these stands for "another correct
+        # fp32 implementation"; the HIP path is one more.  Measured in the build container (max norm): 0.4 ... 0.9e-3 (tv 65), 0.5 ... 1.7e-3
+        # (stem 65), 0.7 ... 1.9e-3 (tv 97) - the reference's fp32 output itself sits 1.4e-3 / 0.5e-3 / 3.9e-3 from its fp64 evaluation.
         from oracle import css_oracle as O
-        gen = torch.Generator().manual_seed(0)
-        xn = torch.from_numpy(g["x"])
-        xn = xn * (1 + 1e-7 * torch.randn(xn.shape, generator=gen))
+        xn0 = torch.from_numpy(g["x"])
+        sd0 = O.init_state(backbone, K, 256, seed, gain)
+        floors = []
         with torch.no_grad():
-            pn, rn = O.deeplab_forward(O.init_state(backbone, K, 256, seed, gain), xn, backbone, True, K, 256)
-        ulp_p, ulp_r = rel_err(pn, gp), rel_err(rn, gr)
-        print(f"{tag}: 1-ulp input perturbation moves the fp32 oracle by {ulp_p:.2e}/{ulp_r:.2e}")
+            for s_ in range(3):
+                gen = torch.Generator().manual_seed(s_)
+                pn, rn = O.deeplab_forward(sd0, xn0 * (1 + 1e-7 * torch.randn(xn0.shape, generator=gen)), backbone, True, K, 256)
+                floors.append((rel_err(pn, gp), rel_err(rn, gr)))
+            for s_ in range(3):
+                gen = torch.Generator().manual_seed(100 + s_)
+                sdn = {k: (v * (1 + 6e-8 * torch.randn(v.shape, generator=gen)) if v.is_floating_point() else v) for k, v in sd0.items()}
+                pn, rn = O.deeplab_forward(sdn, xn0, backbone, True, K, 256)
+                floors.append((rel_err(pn, gp), rel_err(rn, gr)))
+            nt = torch.get_num_threads()
+            torch.set_num_threads(1)
+            try:
+                pn, rn = O.deeplab_forward(sd0, xn0, backbone, True, K, 256)
+            finally:
+                torch.set_num_threads(nt)
+            floors.append((rel_err(pn, gp), rel_err(rn, gr)))
+        ulp_p, ulp_r = max(f[0] for f in floors), max(f[1] for f in floors)
+        bound_p, bound_r = max(1e-3, 2 * ulp_p), max(1e-3, 2 * ulp_r)
+        print(f"{tag}: 1-ulp floor of the fp32 oracle (7 legitimate re-evaluations, max): {ulp_p:.2e}/{ulp_r:.2e}; "
+              f"HIP vs reference {e_pred:.2e}/{e_rep:.2e} = {e_pred / 1e-3:.2f}x/{e_rep / 1e-3:.2f}x north_star's 1e-3, "
+              f"{e_pred / ulp_p:.2f}x/{e_rep / ulp_r:.2f}x the floor; asserted against max(1e-3, 2 x floor) = {bound_p:.2e}/{bound_r:.2e}")
         assert hip_p < 4 * max(ref_p, ulp_p) and hip_r < 4 * max(ref_r, ulp_r)
-        assert e_pred < 5e-3 and e_rep < 5e-3
+        assert e_pred < bound_p and e_rep < bound_r, (e_pred, bound_p, e_rep, bound_r)
     loss = (pred * torch.from_numpy(g["wp"]).to(dev())).sum() + (rep * torch.from_numpy(g["wr"]).to(dev())).sum()
     loss.backward()
     # Gradients: the two fp32 forwards differ by ~1e-5..1e-3, so a few dozen of ~1e5 pre-activations per layer sit on
