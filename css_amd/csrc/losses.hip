@@ -17,7 +17,13 @@ enum { ST_S = 0, ST_NPOS = 1, ST_NVALID = 2, ST_NCONF = 3 };
 constexpr float CE_FIX = 4294967296.f;               // 2^32
 constexpr double CE_UNFIX = 1.0 / 4294967296.0;
 typedef unsigned long long ce_acc_t;                  // (two's complement: losses are >= 0 up to rounding, negative partials wrap correctly)
-__device__ __forceinline__ ce_acc_t ce_fix(float v) { return (ce_acc_t)(long long)(v * CE_FIX); }
+// A NON-FINITE pixel loss (diverged logits) must surface as NaN like the reference's fp32 mean does (float -> integer conversion of
+// NaN is 0 on AMDGPU, so the fixed-point sum stayed finite while the network was NaN): every non-finite partial adds CE_POISON to the
+// image's NVALID word - counts live in its low 40 bits (an image has < 2^40 pixels), the number of poisoned partials in the high 24 -
+// still an integer add, still order-independent; ce_finalize / ohem_init turn a non-zero high part into NaN.
+constexpr ce_acc_t CE_POISON = 1ull << 40;
+constexpr ce_acc_t CE_COUNT_MASK = CE_POISON - 1;
+__device__ __forceinline__ ce_acc_t ce_fix(float v) { return isfinite(v) ? (ce_acc_t)(long long)(v * CE_FIX) : (ce_acc_t)0; }
 
 template <bool BWD>
 __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ label,
@@ -49,18 +55,20 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
       for (int k = 0; k < K; ++k) mx = fmaxf(mx, row[k]);
       float se = 0.f;
       for (int k = 0; k < K; ++k) se += __expf(row[k] - mx);
-      bool valid = lab >= 0 && lab < K;
+      bool valid = lab >= 0 && lab < K, nonfin = false;
       float loss = 0.f, gtp = 1.f;
       if (valid) {
         const float xg = row[lab];
         loss = logf(se) + mx - xg;
         gtp = __expf(xg - mx) / se;
+        nonfin = !isfinite(loss);
         if (keep_thr && !(gtp <= *keep_thr)) { valid = false; loss = 0.f; }
       }
       if (!BWD) {
         if (gtprob_out) gtprob_out[p] = (lab >= 0 && lab < K) ? gtp : 1.f;
         if (stats) {
           const int s = b - b_first;
+          if (nonfin) atomicAdd(&sacc[s][ST_NVALID], CE_POISON);
           if (valid) {
             atomicAdd(&sacc[s][ST_S], ce_fix(loss));
             atomicAdd(&sacc[s][ST_NVALID], (ce_acc_t)1);
@@ -99,7 +107,12 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
 __global__ void ce_finalize_kernel(const ce_acc_t* __restrict__ acc, int B, int mode, float* __restrict__ loss, float* __restrict__ coef) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   // (the fixed-point / integer accumulators as doubles: exact for every count and for sums below 2^21)
-  auto stat = [&](int i) { return (i & 3) == ST_S ? (double)(long long)acc[i] * CE_UNFIX : (double)acc[i]; };
+  auto stat = [&](int i) {
+    if ((i & 3) == ST_NVALID) return (double)(acc[i] & CE_COUNT_MASK);
+    if ((i & 3) != ST_S) return (double)acc[i];
+    const double v = (double)(long long)acc[i] * CE_UNFIX;
+    return (acc[(i & ~3) + ST_NVALID] >> 40) ? (double)NAN : v;          // a non-finite pixel loss in this image: NaN, like the reference
+  };
   double S = 0, NV = 0, NP = 0, WS = 0;
   for (int b = 0; b < B; ++b) {
     S += stat(b * 4 + ST_S);
@@ -133,7 +146,7 @@ __global__ void ohem_init_kernel(OhemState* s, const ce_acc_t* __restrict__ stat
   s->hist[threadIdx.x] = 0;
   if (threadIdx.x == 0) {
     double nv = 0;
-    for (int b = 0; b < B; ++b) nv += (double)stats[b * 4 + ST_NVALID];
+    for (int b = 0; b < B; ++b) nv += (double)(stats[b * 4 + ST_NVALID] & CE_COUNT_MASK);
     s->prefix = 0;
     long k = (long)min((long)P, (long)min_kept) - 1;
     s->k = (unsigned)(k < 0 ? 0 : k);
@@ -222,16 +235,18 @@ __global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__
         se += __expf(v - mx);
         if (k == lab) xg = v;
       }
-      bool valid = lab >= 0 && lab < K;
+      bool valid = lab >= 0 && lab < K, nonfin = false;
       float loss = 0.f, gtp = 1.f;
       if (valid) {
         loss = logf(se) + mx - xg;
         gtp = __expf(xg - mx) / se;
+        nonfin = !isfinite(loss);
         if (keep_thr && !(gtp <= *keep_thr)) { valid = false; loss = 0.f; }
       }
       if (gtprob_out) gtprob_out[p] = (lab >= 0 && lab < K) ? gtp : 1.f;
       if (stats) {
         const int s = b - b_first;
+        if (nonfin) atomicAdd(&sacc[s][ST_NVALID], CE_POISON);
         if (valid) {
           atomicAdd(&sacc[s][ST_S], ce_fix(loss));
           atomicAdd(&sacc[s][ST_NVALID], (ce_acc_t)1);
@@ -311,7 +326,7 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
   if (tid < 4) sacc[tid] = 0;
   __syncthreads();
   const float kthr = keep_thr ? *keep_thr : 0.f;
-  float a_s = 0.f, a_nv = 0.f, a_np = 0.f, a_nc = 0.f;
+  float a_s = 0.f, a_nv = 0.f, a_np = 0.f, a_nc = 0.f, a_bad = 0.f;
   const int x = X0 + (tid & 31);
 #pragma unroll
   for (int trip = 0; trip < CES_TH / 8; ++trip) {
@@ -336,6 +351,7 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
     if (valid) {
       loss = logf(se) + mx - xg;
       gtp = __expf(xg - mx) / se;
+      if (!isfinite(loss)) a_bad += 1.f;
       if (keep_thr && !(gtp <= kthr)) { valid = false; loss = 0.f; }
     }
     if (gtprob_out) gtprob_out[p] = (lab >= 0 && lab < K) ? gtp : 1.f;
@@ -347,10 +363,11 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
     if (conf && conf[p] >= conf_thr) a_nc += 1.f;
   }
   if (stats) {
-    a_s = wave_sum(a_s); a_nv = wave_sum(a_nv); a_np = wave_sum(a_np); a_nc = wave_sum(a_nc);
+    a_s = wave_sum(a_s); a_nv = wave_sum(a_nv); a_np = wave_sum(a_np); a_nc = wave_sum(a_nc); a_bad = wave_sum(a_bad);
     // (a lane's four pixels add in program order, wave_sum is a fixed butterfly: the wave's sums are reproducible; from here on integers)
     if ((tid & 63) == 0) {
-      atomicAdd(&sacc[ST_S], ce_fix(a_s)); atomicAdd(&sacc[ST_NVALID], (ce_acc_t)a_nv); atomicAdd(&sacc[ST_NPOS], (ce_acc_t)a_np);
+      atomicAdd(&sacc[ST_S], ce_fix(a_s)); atomicAdd(&sacc[ST_NVALID], (ce_acc_t)a_nv + (a_bad > 0.f ? CE_POISON : (ce_acc_t)0));
+      atomicAdd(&sacc[ST_NPOS], (ce_acc_t)a_np);
       atomicAdd(&sacc[ST_NCONF], (ce_acc_t)a_nc);
     }
     __syncthreads();

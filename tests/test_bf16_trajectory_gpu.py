@@ -10,7 +10,10 @@ reference", which needs VOC and ImageNet weights that are not here (VERDICT r02,
   differ" can be put properly: an ENSEMBLE of fp32 runs whose input images are perturbed by one unit in the last place (x (1 +- 2^-23),
   the smallest perturbation there is) measures how far apart two legitimate fp32 trajectories of this problem end up; the bf16 run must
   lie inside a fixed multiple (ENV_C = 2) of that envelope - in TIME lag between the supervised-loss curves, in the mean of the last
-  five steps, in the cosines of prototypes and weights.  No margin is a number read off runs: every bound is `ENV_C x ensemble value`.
+  five steps, in the cosines of prototypes and weights.  Round 5: the envelope is the SECOND-LARGEST member value (robust
+  against one member's excursion) and every bound is capped by an absolute figure (lag 8 steps, tail 50 %) - see the end of the test.
+* 20 steps of the same problem at 1/32 of the training lr, where two fp32 runs one ulp apart stay together: bf16 against fp32 under
+  ABSOLUTE per-step bounds (test_bf16_tracks_fp32_in_a_calm_regime).
   Asserted absolutely: every run is finite, and the MEDIAN run of the ten (fp32, eight perturbed fp32, bf16) takes the supervised loss below a
   tenth of its start - a single run may not: in the second deterministic "universe" of round 4 (same test, weight gradients summed in
   another fixed order) the member fp32+ulp3 bounced back to 7.3 at step 9 and ended at 1.8, 21 steps behind the base run, which is exactly what
@@ -178,11 +181,61 @@ def test_thirty_steps_bf16_inside_fp32_ensemble():
     assert ends[len(ends) // 2] < 0.1, ends
     # everything else relative to the envelope of the fp32 ensemble (floors: half a step of lag, the resolution of the lag measure;
     # 1e-3 on the cosines' distance from 1; 0.5 % on the contrastive loss, whose sampler is seeded and whose logits are normalised)
-    env = dict(lag=max(max(m["lag"] for m in mm), 0.5), tail=max(m["tail"] for m in mm), contrast=max(max(m["contrast"] for m in mm), 5e-3),
-               proto=max(max(1.0 - m["proto_cos"] for m in mm), 1e-3), w=max(max(1.0 - m["w_cos"] for m in mm), 1e-3))
-    print(f"fp32 ensemble envelope: lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, contrast {env['contrast']:.4f}, 1 - prototype cosine "
-          f"{env['proto']:.4f}, 1 - weights cosine {env['w']:.5f};  bf16 must stay inside {ENV_C} x these")
-    assert mb["lag"] <= ENV_C * env["lag"], (mb["lag"], env["lag"])
-    assert mb["tail"] <= ENV_C * env["tail"], (mb["tail"], env["tail"])
-    assert mb["contrast"] <= ENV_C * env["contrast"], (mb["contrast"], env["contrast"])
-    assert 1.0 - mb["proto_cos"] <= ENV_C * env["proto"] and 1.0 - mb["w_cos"] <= ENV_C * env["w"], (mb, env)
+    # ROBUST envelope (the MAX over eight chaotic members gave bounds - 32 to 42 steps of lag, 8x to 44x on the tail - that could not
+    # fail): the SECOND-LARGEST member value, so one member's excursion does not widen it, and every bound is CAPPED by the absolute figures
+    # of round 3 (lag <= 8 steps, tail gap <= 50 %, cosines >= 0.97 / 0.98, contrastive gap <= 2 %) that a broken bf16 path would violate.
+    # (A run is a pure function of its inputs since round 4, so this is not a coin flip per run: it is decided once per source tree.)
+    def second(vals):
+        v = sorted(vals)
+        return v[-2] if len(v) > 1 else v[-1]
+    env = dict(lag=max(second(m["lag"] for m in mm), 0.5), tail=second(m["tail"] for m in mm), contrast=max(second(m["contrast"] for m in mm), 5e-3),
+               proto=max(second(1.0 - m["proto_cos"] for m in mm), 1e-3), w=max(second(1.0 - m["w_cos"] for m in mm), 1e-3))
+    cap = dict(lag=8.0, tail=0.5, contrast=2e-2, proto=0.03, w=0.02)
+    bound = {k: min(ENV_C * env[k], cap[k]) for k in env}
+    print(f"fp32 ensemble envelope (second-largest of {N_MEMBERS}): lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, contrast {env['contrast']:.4f}, "
+          f"1 - prototype cosine {env['proto']:.4f}, 1 - weights cosine {env['w']:.5f};  bf16 must stay inside min({ENV_C} x these, {cap}) = {bound}")
+    assert mb["lag"] <= bound["lag"], (mb["lag"], bound)
+    assert mb["tail"] <= bound["tail"], (mb["tail"], bound)
+    assert mb["contrast"] <= bound["contrast"], (mb["contrast"], bound)
+    assert 1.0 - mb["proto_cos"] <= bound["proto"] and 1.0 - mb["w_cos"] <= bound["w"], (mb, bound)
+
+
+def test_bf16_tracks_fp32_in_a_calm_regime():
+    """The same question where the problem is NOT chaotic ("compare bf16 against the ensemble in a calmer regime, keep at least one
+    absolute bound that a broken bf16 path would violate"): the same 129^2, B = 4 + 4 problem at lr = CSS_TRAJ_LR_CALM (default 2e-4, 1/32 of the
+    training rate) for 20 steps.  There two fp32 runs that differ by 1 ulp of input stay together, so bf16 can be held to ABSOLUTE bounds
+    step by step: supervised loss within 5 % of fp32 at every step, contrastive loss within 2 %, prototype cosine >= 0.98, centred weight
+    cosine >= 0.99 - and the perturbed fp32 run, printed beside it, shows how much of that is the problem's own spread."""
+    S, B, seed, gain, steps = 129, 4, 11, 0.25, 20
+    lr = os.environ.get("CSS_TRAJ_LR_CALM", "2e-4")
+    l_img, l_lab, u_img = _batch(S, B, 5, 16)
+    prev = os.environ.get("CSS_TRAJ_LR")
+    os.environ["CSS_TRAJ_LR"] = lr
+    try:
+        base = _thirty(torch.float32, l_img, l_lab, u_img, steps, S, seed, gain)
+        pert = _thirty(torch.float32, _perturb_ulp(l_img, 0), l_lab, _perturb_ulp(u_img, 100), steps, S, seed, gain)
+        bf = _thirty(torch.bfloat16, l_img, l_lab, u_img, steps, S, seed, gain)
+    finally:
+        if prev is None:
+            os.environ.pop("CSS_TRAJ_LR", None)
+        else:
+            os.environ["CSS_TRAJ_LR"] = prev
+    for i in range(steps):
+        print(f"step {i:2d} sup fp32 {base[0][i]['sup']:.4f} fp32+ulp {pert[0][i]['sup']:.4f} bf16 {bf[0][i]['sup']:.4f} | contrast "
+              f"{base[0][i]['contrast']:.4f} {pert[0][i]['contrast']:.4f} {bf[0][i]['contrast']:.4f}")
+    def gaps(run):
+        g_sup = max(abs(a["sup"] - b["sup"]) / abs(a["sup"]) for a, b in zip(base[0], run[0]))
+        g_con = max(abs(a["contrast"] - b["contrast"]) / max(abs(a["contrast"]), 1.0) for a, b in zip(base[0], run[0]))
+        present = base[1].abs().sum(1) > 0
+        pc = float(torch.nn.functional.cosine_similarity(base[1][present], run[1][present], dim=1).min())
+        wc = float(torch.nn.functional.cosine_similarity(base[2] - base[2].mean(), run[2] - run[2].mean(), dim=0))
+        dw = float(torch.nn.functional.cosine_similarity(run[2] - w0, base[2] - w0, dim=0))
+        return g_sup, g_con, pc, wc, dw
+    w0 = _thirty(torch.float32, l_img, l_lab, u_img, 0, S, seed, gain)[2]               # the initial flat weights (no step)
+    gp, gb = gaps(pert), gaps(bf)
+    print(f"calm regime (lr {lr}): fp32+ulp vs fp32: sup {gp[0]:.4f} contrast {gp[1]:.4f} proto cos {gp[2]:.5f} w cos {gp[3]:.6f} update cos {gp[4]:.5f}")
+    print(f"calm regime (lr {lr}):     bf16 vs fp32: sup {gb[0]:.4f} contrast {gb[1]:.4f} proto cos {gb[2]:.5f} w cos {gb[3]:.6f} update cos {gb[4]:.5f}")
+    assert all(math.isfinite(d["sup"]) and math.isfinite(d["contrast"]) for d in bf[0])
+    assert base[0][-1]["sup"] < base[0][0]["sup"] and bf[0][-1]["sup"] < bf[0][0]["sup"]             # both learn
+    assert gb[0] <= 0.05 and gb[1] <= 0.02 and gb[2] >= 0.98 and gb[3] >= 0.99, gb
+    assert gb[4] >= 0.9, gb           # the accumulated 20-step UPDATE of bf16 points where fp32's does (weights cosine alone is dominated by w0)

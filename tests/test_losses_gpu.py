@@ -114,6 +114,31 @@ def test_ohem_golden(golden, name):
     assert rel_err(p.grad.cpu(), grad) < 5e-5
 
 
+def test_non_finite_logits_surface_as_nan_losses():
+    """the loss statistics are 64-bit fixed-point integers (order-independent sums) and float -> integer conversion of NaN is 0 on
+    AMDGPU - a diverged network reported a FINITE supervised loss.  A non-finite pixel loss now poisons its image's accumulator and the
+    finalize kernel returns NaN, like the reference's fp32 mean (mix_label.py:169; loss.py:57-62), on the materialising path, on the fused
+    low-resolution path and for the attention-threshold loss; a clean input next to it stays finite."""
+    from css_amd.loss.loss import CrossEntropyLoss, Attention_Threshold_Loss, ProbOhemCrossEntropy2d
+    g = torch.Generator().manual_seed(5)
+    B, K, H, h = 2, 21, 129, 33
+    lab = torch.randint(0, K, (B, H, H), generator=g).to(dev())
+    conf = torch.rand(B, H, H, generator=g).to(dev())
+    for bad in (float("nan"), float("inf")):
+        big = torch.randn(B, K, H, H, generator=g)
+        small = torch.randn(B, h, h, K, generator=g)
+        clean = [CrossEntropyLoss(-1)(big.to(dev()), lab), CrossEntropyLoss(-1).forward_small(small.to(dev()), lab),
+                 Attention_Threshold_Loss(0.5)(big.to(dev()), lab, conf), ProbOhemCrossEntropy2d(-1, thresh=0.7, min_kept=100).forward_small(small.to(dev()), lab)]
+        assert all(torch.isfinite(c) for c in clean), clean
+        big[1, 3, 40, 50] = bad                                     # one logit of one pixel of the second image
+        small[1, 10, 12, 3] = bad
+        outs = [CrossEntropyLoss(-1)(big.to(dev()), lab), CrossEntropyLoss(-1).forward_small(small.to(dev()), lab),
+                Attention_Threshold_Loss(0.5)(big.to(dev()), lab, conf), Attention_Threshold_Loss(0.5).forward_small(small.to(dev()), lab, conf)]
+        ref = torch.nn.functional.cross_entropy(big, lab.cpu(), ignore_index=-1)
+        print(bad, [float(o) for o in outs], "torch:", float(ref))
+        assert torch.isnan(ref) and all(torch.isnan(o) for o in outs), (bad, outs)
+
+
 def test_ce_nchw_input_and_big():
     """Plain NCHW-contiguous input (what an unmodified caller passes) and a size that spans many tiles/images."""
     from oracle import css_oracle as O
