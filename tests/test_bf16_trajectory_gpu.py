@@ -11,7 +11,7 @@ reference", which needs VOC and ImageNet weights that are not here (VERDICT r02,
   the smallest perturbation there is) measures how far apart two legitimate fp32 trajectories of this problem end up; the bf16 run must
   lie inside a fixed multiple (ENV_C = 2) of that envelope - in TIME lag between the supervised-loss curves, in the mean of the last
   five steps, in the cosines of prototypes and weights.  Round 5: the envelope is the SECOND-LARGEST member value (robust
-  against one member's excursion) and every bound is capped by an absolute figure (lag 8 steps, tail 50 %) - see the end of the test.
+  against one member's excursion) and every bound is capped by an absolute figure (lag 15 steps, tail 3x, cosines) - see the end of the test.
 * 20 steps of the same problem at 1/32 of the training lr, where two fp32 runs one ulp apart stay together: bf16 against fp32 under
   ABSOLUTE per-step bounds (test_bf16_tracks_fp32_in_a_calm_regime).
   Asserted absolutely: every run is finite, and the MEDIAN run of the ten (fp32, eight perturbed fp32, bf16) takes the supervised loss below a
@@ -182,15 +182,18 @@ def test_thirty_steps_bf16_inside_fp32_ensemble():
     # everything else relative to the envelope of the fp32 ensemble (floors: half a step of lag, the resolution of the lag measure;
     # 1e-3 on the cosines' distance from 1; 0.5 % on the contrastive loss, whose sampler is seeded and whose logits are normalised)
     # ROBUST envelope (the MAX over eight chaotic members gave bounds - 32 to 42 steps of lag, 8x to 44x on the tail - that could not
-    # fail): the SECOND-LARGEST member value, so one member's excursion does not widen it, and every bound is CAPPED by the absolute figures
-    # of round 3 (lag <= 8 steps, tail gap <= 50 %, cosines >= 0.97 / 0.98, contrastive gap <= 2 %) that a broken bf16 path would violate.
+    # fail): the SECOND-LARGEST member value, so one member's excursion does not widen it, and every bound is CAPPED by an absolute figure that a
+    # broken bf16 path would violate (a path that does not learn sits ~30 steps behind with a tail gap of ~60; cosines >= 0.97 / 0.98,
+    # contrastive gap <= 2 %).  Round 3's fixed caps (lag <= 8 steps, tail <= 50 %) do NOT hold for fp32 itself here: in the first universe of
+    # round 5 two of eight 1-ulp fp32 members sit 8.8 and 12.6 steps from the base run (tail gaps 0.80 / 1.53) and bf16 sits at 8.6 / 0.77 -
+    # inside the fp32 spread, outside those caps (gpurun_out/r05_run1.txt).  The ABSOLUTE per-step bounds live in the calm-regime test below.
     # (A run is a pure function of its inputs since round 4, so this is not a coin flip per run: it is decided once per source tree.)
     def second(vals):
         v = sorted(vals)
         return v[-2] if len(v) > 1 else v[-1]
     env = dict(lag=max(second(m["lag"] for m in mm), 0.5), tail=second(m["tail"] for m in mm), contrast=max(second(m["contrast"] for m in mm), 5e-3),
                proto=max(second(1.0 - m["proto_cos"] for m in mm), 1e-3), w=max(second(1.0 - m["w_cos"] for m in mm), 1e-3))
-    cap = dict(lag=8.0, tail=0.5, contrast=2e-2, proto=0.03, w=0.02)
+    cap = dict(lag=15.0, tail=3.0, contrast=2e-2, proto=0.03, w=0.02)
     bound = {k: min(ENV_C * env[k], cap[k]) for k in env}
     print(f"fp32 ensemble envelope (second-largest of {N_MEMBERS}): lag {env['lag']:.2f} steps, tail {env['tail']:.3f}, contrast {env['contrast']:.4f}, "
           f"1 - prototype cosine {env['proto']:.4f}, 1 - weights cosine {env['w']:.5f};  bf16 must stay inside min({ENV_C} x these, {cap}) = {bound}")
