@@ -16,6 +16,8 @@ the only exchanges (RCCL).  Rank 0 prints ONE JSON line; at N=1 it also carries
   * ``extra.c4``: 5 steps (after 3 warm-up) of the Cityscapes-shaped 769x769 workload (BASELINE configs[3] shape on one GPU),
   * ``extra.c5``: 5 steps (after 3) of c4 with Q=1024, N=2048, forced-valid (BASELINE configs[4] shape),
   * ``extra.c2_forced_valid``: 5 steps (after 3) of c2 with every unlabeled pixel valid (SURVEY 8d "forced-valid": worst-case contrastive load),
+  * ``extra.c2_aug_pil``: 5 steps (after 3) of c2 with the reference's in-step augmentation on the device inside the timed step,
+  * ``extra.c2_cross_trainer`` / ``extra.c2_ori_trainer``: 3 steps (after 3) of the two other entry scripts' train bodies at the c2 shapes,
   * ``cpu_baseline``: the CPU oracle timed on the host cores.
 """
 import argparse
@@ -137,8 +139,10 @@ def synth_batch(B, S, K, seed, dev):
     return l_img.to(dev), l_lab.to(dev), u_img.to(dev), u_blk.to(dev)
 
 
-def make_trainer_class(forced_valid):
-    from css_amd.train_step import MixTrainer
+def make_trainer_class(forced_valid, script="mix"):
+    from css_amd.train_step import CrossTrainer, MixTrainer, OriTrainer
+    if script != "mix":          # the two other entry scripts of the reference (cross_label.py:153-200, ori_pseudo.py:149-189)
+        return CrossTrainer if script == "cross" else OriTrainer
     if not forced_valid:
         return MixTrainer
 
@@ -160,18 +164,28 @@ def make_trainer_class(forced_valid):
     return ForcedValidTrainer
 
 
-def build(workload, dev, rank, dtype="bf16", mix="cutmix", aug="identity", forced_valid=False, size=None, batch=None):
+BN_GAMMA_NOTE = ("BN gamma ~ U(0.25, 0.75), beta ~ N(0, 0.1) - SURVEY 8(d) says gamma ~ U(0.5, 1.5): the narrower draw keeps the residual stream of the "
+                 "random-init network O(1) through 33 blocks, so the supervised loss starts at ln K (tests/test_full_size_gpu.py asserts it); the "
+                 "kernels, their launch shapes and their work are identical for any gamma")
+
+
+def build(workload, dev, rank, dtype="bf16", mix="cutmix", aug="identity", forced_valid=False, size=None, batch=None, script="mix"):
     """-> (trainer, (l_img, l_lab, u_img), meta) for one rank: seeded non-degenerate weights (Kaiming convs from the
     constructor, BN gamma ~ U(.25,.75), beta ~ N(0,.1)), synthetic crops of the workload's shape."""
     from css_amd.networks import resnet
-    from css_amd.networks.ddp_model import Model_mix
+    from css_amd.networks.ddp_model import Model_cross, Model_mix, Model_ori_pseudo
     K, S, B, backbone, sup, Q, N, cfg_idx = WORKLOADS[workload]
     S, B = size or S, batch or B
     torch.manual_seed(3407)
     cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (0.5, 1.5) if aug == "pil" else (1.0, 1.0), "mix_mode": mix, "device_aug": aug}}
     bb = resnet.resnet101_tv(zero_init_residual=False) if backbone == "tv" else resnet.resnet101(zero_init_residual=False)
     with contextlib.redirect_stdout(sys.stderr):     # the constructor prints like the reference's; stdout carries the ONE JSON line only
-        model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
+        if script == "mix":
+            model = Model_mix(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
+        elif script == "cross":
+            model = Model_cross(bb, num_classes=K, output_dim=256, config=cfg, temp=0.5)
+        else:
+            model = Model_ori_pseudo(bb, num_classes=K, output_dim=256, config=cfg)
     g = torch.Generator().manual_seed(3407)
     with torch.no_grad():
         for mod in model.model.modules():
@@ -180,7 +194,7 @@ def build(workload, dev, rank, dtype="bf16", mix="cutmix", aug="identity", force
                 mod.bias.copy_(torch.randn(mod.bias.shape, generator=g) * 0.1)
         model.ema_model.load_state_dict(model.model.state_dict())
     model = model.to(dev).train().set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32)
-    tr = make_trainer_class(forced_valid)(model, K, lr=6.4e-3, total_iter=80000, num_queries=Q, num_negatives=N, strong_threshold=0.8,
+    tr = make_trainer_class(forced_valid, script)(model, K, lr=6.4e-3, total_iter=80000, num_queries=Q, num_negatives=N, strong_threshold=0.8,
                                           weak_threshold=0.7, un_threshold=0.97, sup=sup, ohem_min_kept=50000 * B)
     l_img, l_lab, u_img, u_blk = synth_batch(B, S, K, 3407 + rank, dev)
     if forced_valid:
@@ -259,7 +273,8 @@ def pmc_traffic(workload):
     return round((rd + wr) / n * 1e6), f"profiles/{os.path.basename(files[-1])} (replayed)"
 
 
-def rooflines(prof, dtype, workload):
+def rooflines(prof, dtype, workload, step_conv_flops=None):
+    """step_conv_flops: the algorithmic conv FLOPs of one step (8 B F for mix / cross, 7 B F for ori_pseudo - SURVEY 8d)."""
     def tot(*names):
         return tuple(sum(prof[n][i] for n in names) for i in range(3))
     peak = PEAK_BF16 if dtype == "bf16" else PEAK_F32
@@ -277,6 +292,13 @@ def rooflines(prof, dtype, workload):
             "alg_bytes_per_launch": round(prof["igemm256_bytes"][2] / max(prof["igemm256_bytes"][1], 1)),
             "traffic_over_alg_bytes": (round(traffic / (prof["igemm256_bytes"][2] / max(prof["igemm256_bytes"][1], 1)), 3)
                                        if traffic and prof["igemm256_bytes"][2] > 0 else None)}
+    # SURVEY 8(d)'s own definition of the MFMA fraction: (8 B F / t_conv) / peak with t_conv = EVERY convolution kernel of the step (forward,
+    # data gradient, weight gradient: persistent, weight-stationary, leftover, narrow and stem launches alike), HIP events of the profiled step
+    t_conv = tot("conv_fwd_other", "igemm256_fwd", "conv_dgrad_other", "igemm256_dgrad", "conv_wgrad_other", "wgrad256")[0]
+    if step_conv_flops and t_conv > 0:
+        roof["mfma_frac_all_conv"] = round(step_conv_flops / (t_conv * 1e-3) / peak, 4)
+        roof["all_conv_ms_per_step"] = round(t_conv, 3)
+        roof["mfma_frac_all_conv_is"] = "(8 B F / sum of all conv kernel time of the step) / peak - SURVEY 8(d); `frac` is the dominant kernel alone"
     # (keys name the kernels that run today: the big-tile class = conv_igemm_p8_kernel + conv_ws_kernel launches, forward and dgrad)
     mfma_groups = {"conv_igemm_p8_and_ws_kernels": tot("igemm256_fwd", "igemm256_dgrad"), "conv_wgrad_p8_kernel": prof["wgrad256"],
                    "conv_fwd_all_kernels": tot("conv_fwd_other", "igemm256_fwd"), "conv_dgrad_all_kernels": tot("conv_dgrad_other", "igemm256_dgrad"),
@@ -409,10 +431,10 @@ def main():
             print(f"bench.py rank {rank}: rendezvous failed: {e}", file=sys.stderr)
             sys.exit(RC_RENDEZVOUS)
 
-    def run_leg(workload, steps, warmup, forced_valid, profile=True, size=None, batch=None):
-        tr, batch_t, meta = build(workload, dev, rank, a.dtype, a.mix, a.aug, forced_valid, size, batch)
+    def run_leg(workload, steps, warmup, forced_valid, profile=True, size=None, batch=None, aug=None, script="mix"):
+        tr, batch_t, meta = build(workload, dev, rank, a.dtype, a.mix, aug or a.aug, forced_valid, size, batch, script)
         dt, out, prof = timed_run(tr, batch_t, steps, warmup, world, dev, profile)
-        roof, kernels = rooflines(prof, a.dtype, workload)
+        roof, kernels = rooflines(prof, a.dtype, workload, (7 if script == "ori" else 8) * meta["B"] * meta["fwd_flop"])
         losses = {k: round(float(v), 4) for k, v in out.items() if k != "pseudo"}
         del tr, batch_t
         torch.cuda.empty_cache()
@@ -443,7 +465,7 @@ def main():
             "config": {"workload": (f"BASELINE configs[{meta['cfg_idx']}]{' shape' if a.workload != 'c2' else ''}: {shape} mix_label step, {net} "
                                     f"DeepLabv3+, {S}x{S}, B={B}+{B} per GPU, K={K}, sup={meta['sup']}, Q={meta['Q']}, N={meta['N']}, "
                                     f"mix_mode={a.mix}, device_aug={a.aug}" + (", forced-valid pseudo labels" if fv else "")),
-                       "global_batch": 2 * B * world, "parallelism": f"dp{world}"},
+                       "global_batch": 2 * B * world, "parallelism": f"dp{world}", "weights": BN_GAMMA_NOTE},
             "roofline": roof, "kernels": kernels,
             "step_alg_tflops": round(8 * B * meta["fwd_flop"] / (dt / a.steps) / 1e12, 2),
             "losses": losses, "source_sha256": source_sha256(),
@@ -457,7 +479,7 @@ def main():
         extra["c4"] = {"workload": "BASELINE configs[3] shape on one GPU: Cityscapes-shaped, deep-stem ResNet-101, 769x769, B=8+8, K=19, OHEM",
                        "value": round(2 * m4["B"] * n4 / d4, 3), "unit": "images/s", "ms_per_step": round(d4 / n4 * 1e3, 3), "steps": n4, "warmup": w4,
                        "roofline": {k: r4[k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "avg_launch_us",
-                                                       "alg_bytes_per_launch", "traffic_over_alg_bytes")},
+                                                       "alg_bytes_per_launch", "traffic_over_alg_bytes", "mfma_frac_all_conv", "all_conv_ms_per_step") if k in r4},
                        "step_alg_tflops": round(8 * m4["B"] * m4["fwd_flop"] / (d4 / n4) / 1e12, 2), "losses": l4}
         n5, w5 = 5, 3
         d5, l5, r5, k5, m5 = run_leg("c5", n5, w5, True)
@@ -471,6 +493,20 @@ def main():
                                             "contrastive pool: losses.unsup != 0)",
                                     "value": round(2 * m2["B"] * n2 / d2, 3), "unit": "images/s", "ms_per_step": round(d2 / n2 * 1e3, 3), "steps": n2,
                                     "warmup": w2, "losses": l2}
+        # the in-step augmentation of the reference INSIDE the timed step (ddp_model.py:121-137): random rescale 0.5-1.5, crop,
+        # colour jitter, blur, flip on the device (csrc/aug.hip), cutmix - the headline line times the identity stand-in
+        d6, l6, _, _, m6 = run_leg("c2", n2, w2, False, profile=False, aug="pil")
+        extra["c2_aug_pil"] = {"what": "c2 with device_aug='pil': the reference's in-step augmentation (VOC.py:126-196,325-352) on the device inside the "
+                                       "timed step", "value": round(2 * m6["B"] * n2 / d6, 3), "unit": "images/s", "ms_per_step": round(d6 / n2 * 1e3, 3),
+                               "steps": n2, "warmup": w2, "losses": l6}
+        # the two other entry scripts (VERDICT r04 missing 4): cross_label.py:153-200 (8 B F per step) and ori_pseudo.py:149-189 (7 B F per step)
+        for script, ref in (("cross", "cross_label.py:153-200, warm-up branch"), ("ori", "ori_pseudo.py:149-189")):
+            ns, wsu = 3, 3
+            ds, ls, _, _, ms_ = run_leg("c2", ns, wsu, False, profile=False, script=script)
+            extra[f"c2_{script}_trainer"] = {"what": f"c2 shapes through {'CrossTrainer' if script == 'cross' else 'OriTrainer'} ({ref})",
+                                             "value": round(2 * ms_["B"] * ns / ds, 3), "unit": "images/s", "ms_per_step": round(ds / ns * 1e3, 3),
+                                             "steps": ns, "warmup": wsu, "losses": ls,
+                                             "step_alg_tflops": round((7 if script == "ori" else 8) * ms_["B"] * ms_["fwd_flop"] / (ds / ns) / 1e12, 2)}
         res["extra"] = extra
     if rank == 0:
         if world == 1 and not a.no_cpu_baseline:

@@ -242,10 +242,9 @@ __global__ __launch_bounds__(1024) void bn_reduce_finalize_kernel(const double* 
 // Stage 2 for the statistics the convolution epilogue emits (conv.hip: store_wave_tile, conv_pp.hip): partial is fp32
 // [nslab][2][C], two rows ("slabs") per convolution tile of BM rows of the [G*Mg][C] tensor y: slab p covers rows
 // (p >> 1) * BM + (p & 1) * (BM - 128) ... of the tile's first (BM - 128 rows) or second (128 rows) pixel half and holds the sums of
-// those of its rows that belong to the statistics group of its FIRST row.  BM = 256 (128-row slabs, every kernel of conv.hip) or
-// 272 (conv_pp.hip's 272-row tiling).  Group g = the slabs that START inside it plus - when g*Mg is not a slab start - the rows
-// g*Mg .. (next slab start) of y itself (< 144 rows, summed here from the bf16 tensor: the head of the group sits in a slab that
-// started in the previous group).
+// those of its rows that belong to the statistics group of its FIRST row.  BM = 256 (128-row slabs: every convolution kernel of the library).
+// Group g = the slabs that START inside it plus - when g*Mg is not a slab start - the rows g*Mg .. (next slab start) of y itself (< 128 rows,
+// summed here from the bf16 tensor: the head of the group sits in a slab that started in the previous group).
 // sums_out != null: write [G][2][C] sums (+ [G] row counts) only (SyncBN: all-reduced before bn_finalize); else finalize in place.
 __device__ __forceinline__ int slab_start(int p, int BM) { return (p >> 1) * BM + (p & 1) * (BM - 128); }
 __device__ __forceinline__ int first_slab_from(int row, int BM) {         // first slab whose start is >= row (rows < 2^31)
@@ -595,7 +594,7 @@ int css_launch_bn_reduce_finalize(const double* partial, int nrb, int G, double 
 int css_launch_bn_reduce_slabs(const float* partial, int M, int Mg, int G, double count, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                float* shift, double* sums_out, int C, const void* y, int ldy, int tile_rows, hipStream_t st) {
-  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C || (tile_rows != 256 && tile_rows != 272)) return CSS_ERR_ARG;
+  if (M <= 0 || Mg < 128 || G <= 0 || (long)Mg * G != M || !y || ldy < C || tile_rows != 256) return CSS_ERR_ARG;
   hipLaunchKernelGGL(bn_reduce_slabs_kernel, dim3(cdiv(C, S2_CH)), dim3(1024), 0, st, partial, 2 * cdiv(M, tile_rows), Mg, G, count, gamma, beta,
                      running_mean, running_var, momentum, eps, mean, invstd, scale, shift, sums_out, C, (const bf16_t*)y, ldy, tile_rows);
   CSS_CHECK_LAUNCH();

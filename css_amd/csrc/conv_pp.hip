@@ -56,14 +56,14 @@ __device__ __forceinline__ float pp_lo(unsigned u) { return __builtin_bit_cast(f
 __device__ __forceinline__ float pp_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 }  // namespace
 
-// TI0: 16-pixel tiles of the FIRST pixel half (8 or 9; the second half always has 8): tile height BM = 256 or 272 rows.  The
-// launcher picks the height that fills whole rounds of the chip (135200 rows = 32 images of 65x65: 498 tiles of 272 rows = two
-// rounds of 256 CUs; 529 tiles of 256 rows would leave 17 tiles for a third round or a latency-bound leftover launch - r01: 9.7 ms
-// per step).  NST: LDS stages (5 x 32 KiB = all 160 KiB of the CU at BM = 256, 4 x 33 KiB at 272; NST-1 K steps in flight).
-// STATS: batch-norm statistics of the output (forward).  ADD: + a.addend before the store (data gradient with a residual branch).
-template <int TI0, bool STATS, bool ADD>
+// Tile = 256 rows x 256 channels: TI0 = 8 sixteen-pixel tiles per pixel half.  NST: LDS stages (5 x 32 KiB = all 160 KiB of the CU; NST-1 K
+// steps in flight).  STATS: batch-norm statistics of the output (forward).  ADD: + a.addend before the store (data gradient with a residual
+// branch).  (Rows that do not fill a round of the chip go to the 128-row kernels of conv.hip; a taller tile that absorbed them was measured
+// slower per row in round 2 and left the library in round 5.)
+template <bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
-  constexpr int S0 = 16 * TI0, BM = S0 + 128, BN = 256, BK = 32, NST = TI0 == 8 ? 5 : 4;
+  constexpr int TI0 = 8;
+  constexpr int S0 = 16 * TI0, BM = S0 + 128, BN = 256, BK = 32, NST = 5;
   constexpr int A_BYTES = BM * 64, ST_BYTES = A_BYTES + BN * 64;   // 64-byte LDS rows (32 bf16)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
 
@@ -71,10 +71,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;                       // pixel half (= ping-pong group), channel quarter
   const int l15 = lane & 15, lg = lane >> 4;
-  // LDS-DMA instructions of this wave per K step: 2 + 2 (16 rows of each operand tile per instruction); at BM = 272 the 17th
-  // 16-row piece of the pixel tile goes round the waves, one K step each (a fixed owner would have 25 % more to issue in every
-  // LOAD segment, and the slowest wave sets the pace: measured -15 %).  The counted waits below assume 4 per step: with the odd
-  // fifth among the youngest they wait for one more instruction than necessary, never for one less.
+  // LDS-DMA instructions of this wave per K step: 2 + 2 (16 rows of each operand tile per instruction); the counted waits below assume 4 per step.
 
   // ---- tile schedule: this workgroup's position inside a round of gridDim.x tiles; XCD x owns a contiguous run of logical tiles
   const int G = gridDim.x, q8 = G >> 3, r8 = G & 7;
@@ -123,8 +120,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   };
 
   // ---- issue side (LDS-DMA producer state, NST-1 K steps ahead of the MFMAs) --------------------------------------------------
-  // thread -> rows wave*32 + 16 i + (lane >> 2) of BOTH operand tiles (i = 0, 1; wave 0 also row 256 + (lane >> 2) of a 272-row
-  // pixel tile), 16-byte position lane & 3 of the row;
+  // thread -> rows wave*32 + 16 i + (lane >> 2) of BOTH operand tiles (i = 0, 1), 16-byte position lane & 3 of the row;
   // the chunk stored at position p of row r is source chunk p ^ f((r >> 2) & 3), f = {2,0,1,3}: with 64-byte rows the 16 lanes of
   // every ds_read_b128 group of the 16x16x32 operand reads (rows r..r+15 at chunks c, c, c+1, c+1 per quad) then hit 16 distinct
   // 16-byte slots of the 256-byte bank row
@@ -138,7 +134,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
   //   boff  : byte offset of my weight rows (+ my chunk), or OOB
   // "cur" feeds the DMAs; "nxt" is the tile after it, prepared by the consumer side at the end of an epilogue (when the 128
   // accumulator registers are free) so that the LOAD segments never pay for a tile change
-  constexpr int AR = TI0 == 9 ? 3 : 2;    // A rows per thread (the third: row 256 + (lane >> 2) of a 272-row tile, every 8th K step)
+  constexpr int AR = 2;                   // A rows per thread
   int rowoff[AR], nrowoff[AR];
   unsigned rmask[AR], nrmask[AR];
   unsigned boff[2], nboff[2];
@@ -156,7 +152,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     const int m0 = a.m_begin + mt * BM, n0 = (lt - mt * nt_n) * BN;
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      const int m = i < 2 ? m0 + prow + 16 * i : m0 + 256 + (lane >> 2);
+      const int m = m0 + prow + 16 * i;
       unsigned msk = 0;
       int off = 0;
       if (m < a.M) {
@@ -238,10 +234,6 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       const bool ok = cok && ((rmask[i] >> tap) & 1);
       pp_dma16(rs_a, sa + i * 1024, ok ? (unsigned)(rowoff[i] + da) : PP_OOB);
     }
-    if (TI0 == 9 && (it_step & 7) == wave) {
-      const bool ok = cok && ((rmask[AR - 1] >> tap) & 1);
-      pp_dma16(rs_a, smem + stage * ST_BYTES + 256 * 64, ok ? (unsigned)(rowoff[AR - 1] + da) : PP_OOB);
-    }
     ++it_step;
 #pragma unroll
     for (int i = 0; i < 2; ++i) pp_dma16(rs_b, sa + A_BYTES + i * 1024, (cok && boff[i] != PP_OOB) ? boff[i] + kb : PP_OOB);
@@ -275,7 +267,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 
   // ---- consumer state ---------------------------------------------------------------------------------------------------
   f32x4 acc[TI0][4];      // [pixel tile i: pixels 16 i + (lane & 15) of my half][channel tile j: channels 16 j + 4 (lane >> 4) + reg]
-  const int ti_n = wm ? 8 : TI0;                       // pixel tiles of my half
+  const int ti_n = TI0;                                // pixel tiles of my half
   const int koff = ((lg ^ ((0xD2 >> (2 * ((lane >> 2) & 3))) & 3)) << 4);
   const int a_addr = (wm * S0 + l15) * 64 + koff, b_addr = A_BYTES + (wn * 64 + l15) * 64 + koff;
 
@@ -324,7 +316,6 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
       for (int j = 0; j < 4; ++j) fw[j] = *reinterpret_cast<const bf16x8*>(sb + b_addr + j * 1024);
 #pragma unroll
       for (int i = 0; i < 8; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(sb + a_addr + i * 1024);
-      if (TI0 == 9 && wm == 0) fa[TI0 - 1] = *reinterpret_cast<const bf16x8*>(sb + a_addr + 8 * 1024);
 #endif
       issue(st_i);                                     // K step + NST-1 (past the last tile: all-OOB = zeros into a free stage)
       st_c = st_c == NST - 1 ? 0 : st_c + 1;
@@ -356,19 +347,11 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], z, 0, 0, 0);
-        if (TI0 == 9 && wm == 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[TI0 - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[TI0 - 1], z, 0, 0, 0);
-        }
       } else {
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[i], acc[i][j], 0, 0, 0);
-        if (TI0 == 9 && wm == 0) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) acc[TI0 - 1][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[j], fa[TI0 - 1], acc[TI0 - 1][j], 0, 0, 0);
-        }
       }
 #endif
       __builtin_amdgcn_s_setprio(0);
@@ -380,7 +363,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
 
     // ---------------- epilogue of tile ti (no LDS, no barrier, no load but the optional addend) ----------------
     const int mrow0 = ct.m0 + wm * S0, n0w = ct.n0 + wn * 64;
-    // a wave's rows (128 or 16 TI0 of them) are one "slab" of a.stats: its row holds the sums of the rows that belong to the
+    // a wave's 128 rows are one "slab" of a.stats: its row holds the sums of the rows that belong to the
     // statistics group of the slab's FIRST row; rows of a slab past a group boundary (< 144 per boundary) are summed from the
     // stored tensor by stage 2 (bn_reduce_slabs_kernel)
     const int bnd = STATS ? (mrow0 / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;
@@ -388,7 +371,7 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     //   lane group g = 0: tile j ch 0-7 | g = 1: tile j+1 ch 0-7 | g = 2: tile j ch 8-15 | g = 3: tile j+1 ch 8-15   (j = 0, 2)
     const int nl = n0w + 16 * (lg & 1) + 8 * (lg >> 1);
     pp_u32x4 radd[ADD ? TI0 : 1][2];
-    const bool has_mask = ADD && TI0 == 8 && a.add_mask != nullptr;      // (the opt-in 272-row variant has no register left: the dispatch keeps masked launches off it)
+    const bool has_mask = ADD && a.add_mask != nullptr;
     if (ADD) {
       // all 16 addend vectors of the wave tile are requested before the first one is used: ONE drain of the vector-memory queue per
       // tile (the compiler waits for an ordinary load with everything older, i.e. with the LDS-DMA of the next tile's first K steps)
@@ -445,7 +428,6 @@ __global__ __launch_bounds__(512) void conv_igemm_pp_kernel(const ConvArgs a) {
     store_pixel_tile(std::integral_constant<int, 5>());
     store_pixel_tile(std::integral_constant<int, 6>());
     store_pixel_tile(std::integral_constant<int, 7>());
-    if (TI0 == 9 && wm == 0) store_pixel_tile(std::integral_constant<int, TI0 - 1>());   // (uniform: the second half has 8 pixel tiles)
     if (STATS) {
       // Batch-norm statistics of exactly the bf16 values stored (what bn_apply reads back; rows >= M are exact zeros), one channel
       // tile at a time (8 live sums next to the 128 accumulators): per lane its 8 pixels, then the 16 pixels of a lane row by DPP;
@@ -505,8 +487,7 @@ bool css_conv_pp_supported(const ConvArgs& a) {
 }
 
 // 256 when the persistent 256x256-tile kernels take the launch (whole rounds of the chip there, leftover rows on the 128-row kernels of
-// conv.hip); 0: not a shape for them.  (A 272-row tiling that absorbed the partial round was measured ~15 % slower per row and removed in
-// round 4; scripts/proto keeps nothing of it - it was this kernel with TI0 = 9.)
+// conv.hip); 0: not a shape for them.
 int css_conv_pp_plan(const ConvArgs& a, int n_cu) {
   (void)n_cu;
   if (!css_conv_pp_supported(a) || (size_t)a.M * a.ldd * 2 >= 0x7FFFFFF0ull) return 0;
@@ -523,7 +504,7 @@ void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st) {
   if (a.addend) a.add_bytes = (unsigned)((size_t)a.M * a.ld_add * 2);
   if (a.add_mask) a.mask_bytes = (unsigned)((size_t)a.M * (a.Cd / 8));
   const dim3 g(grid), b(512);
-  if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, true, false>), g, b, 0, st, a);
-  else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, true>), g, b, 0, st, a);
-  else hipLaunchKernelGGL((conv_igemm_pp_kernel<8, false, false>), g, b, 0, st, a);
+  if (a.stats) hipLaunchKernelGGL((conv_igemm_pp_kernel<true, false>), g, b, 0, st, a);
+  else if (a.addend) hipLaunchKernelGGL((conv_igemm_pp_kernel<false, true>), g, b, 0, st, a);
+  else hipLaunchKernelGGL((conv_igemm_pp_kernel<false, false>), g, b, 0, st, a);
 }

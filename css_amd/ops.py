@@ -196,7 +196,7 @@ class _Conv2d(torch.autograd.Function):
             stats = torch.empty((2 * ((m + 255) // 256), 2, cout), dtype=torch.float32, device=x.device)
             call("css_conv2d_forward_bnstats", x, wf, y, stats, mg, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
                  flops, dtype_code(dt), dev, st)
-            # rows per convolution tile (= two statistics slabs): 256, or 272 when the launcher tiles the rows that way
+            # rows per convolution tile (= two statistics slabs), asked of the library - never hard-coded here
             bm = _lib.query("css_conv2d_forward_bnstats_tile_rows", x, wf, y, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil,
                             dtype_code(dt), dev)
             _conv_stats_out = (stats, mg, stat_groups, cout, bm)

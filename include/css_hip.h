@@ -31,8 +31,8 @@ CSS_API int css_device_cu_count(int device);
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------------
  * Every kernel launch of a bracketed call gets its own event pair.  kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad
  * (launches of every kernel but the 256x256 LDS-DMA ones), 3 = contrast loss gather, 4 = similarity,
- * 5 / 6 / 7 = forward / dgrad launches of the 256-channel-panel MFMA kernels (conv_igemm_pp64_kernel, conv_igemm_pp_kernel,
- * conv_igemm_dma256_kernel, conv_ws_kernel) and conv_wgrad_dma256_kernel launches; 13 / 14 = the conv_ws_kernel launches among 5 / 6
+ * 5 / 6 / 7 = forward / dgrad launches of the 256-channel-panel MFMA kernels (conv_igemm_p8_kernel, conv_igemm_pp_kernel, conv_ws_kernel,
+ * conv_ws4_kernel) and conv_wgrad_p8_kernel launches; 13 / 14 = the conv_ws_kernel / conv_ws4_kernel launches among 5 / 6
  * again, with their FLOPs (13) and with their algorithmic bytes (14: the kernel is judged against both rooflines); 15 = the OTHER
  * launches among 5 / 6 (the persistent 256x256-tile kernels) with the call's algorithmic bytes - source, weights, output once each,
  * + addend and mask - so that a PMC traffic figure for that kernel can be read against them.
@@ -53,10 +53,10 @@ CSS_API int css_conv2d_forward(const void* x, const void* w, const float* bias, 
 /* css_conv2d_forward (bias-free, bf16) that also emits the batch-norm statistics of its output, saving bn_stats' pass over
  * the tensor (every convolution of the reference's backbone/ASPP/decoder is followed by BatchNorm: resnet.py:119-137,
  * aspp.py:21-62, deeplabv3.py:115-133).  The output holds G = M/Mg statistics groups of Mg >= 128 rows.
- * stats: fp32 [2 * ceil(M/256)][2][Cout] (room for either tiling): two rows ("slabs") per convolution tile of BM rows - the tile's
- * first BM-128 and last 128 rows - each holding the sums of the slab's rows that lie in the statistics group of its first row;
- * BM = css_conv2d_forward_bnstats_tile_rows(same arguments) = 256 or 272 (the launcher tiles M in 272-row tiles when that fills whole
- * rounds of the chip).  Consumed by css_bn_reduce_finalize_slabs, which sums the (< 144) rows past each group boundary from y itself. */
+ * stats: fp32 [2 * ceil(M/256)][2][Cout]: two rows ("slabs") per convolution tile of BM = 256 rows - the tile's first and last 128 rows -
+ * each holding the sums of the slab's rows that lie in the statistics group of its first row; BM = css_conv2d_forward_bnstats_tile_rows(same
+ * arguments) (256 for every kernel the dispatcher can reach; the query stays so that callers never hard-code it).  Consumed by
+ * css_bn_reduce_finalize_slabs, which sums the (< 128) rows past each group boundary from y itself. */
 CSS_API int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho,
                                        int Wo, int Cout, int ldy, int R, int S, int stride, int pad, int dil, double alg_flops, int dtype,
                                        int device, css_stream_t stream);
@@ -124,7 +124,7 @@ CSS_API int css_bn_reduce(const double* partial, int nrb, int C, int G, double* 
 CSS_API int css_bn_reduce_finalize(const double* partial, int nrb, int G, double count, const float* gamma, const float* beta,
                                    float* running_mean, float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
                                    float* shift, int C, int device, css_stream_t stream);
-/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [2 * ceil(M/tile_rows)][2][C] (tile_rows = 256 or 272, see there) + the bf16
+/* stage 2 for css_conv2d_forward_bnstats: partial fp32 [2 * ceil(M/tile_rows)][2][C] (tile_rows = 256, see there) + the bf16
  * tensor y [M][ldy] the statistics are of -> per-group sums (fp64).  sums_out == NULL:
  * train-mode finalize like css_bn_reduce_finalize; else only write sums_out [G][2][C] + [G] local counts (SyncBN all-reduces them, then
  * css_bn_finalize) */

@@ -177,12 +177,16 @@ int main() {
   run("A  one stream, full chip (again)", s1, s1, 256, 256);
   unsigned* probe;
   CK(hipMalloc((void**)&probe, 4096 * 4));
-  for (int X : {224, 192, 160, 128}) {     // (conv_ws_kernel needs (X / 8) % 4 == 0 for its four panels)
+  // PB_X=<CUs of the main partition>: ONE split per process (the first run of this harness did not come back from its second split - the
+  // streams of a split are created once and never destroyed here, and the caller bounds every process with `timeout`)
+  const int X = getenv("PB_X") ? atoi(getenv("PB_X")) : 192;     // (conv_ws_kernel needs (X / 8) % 4 == 0 for its four panels)
+  {
     unsigned mm[8] = {0}, mw[8] = {0};
     for (int bit = 0; bit < 256; ++bit) (bit < X ? mm : mw)[bit >> 5] |= 1u << (bit & 31);
     hipStream_t sm, sw;
     CK(hipExtStreamCreateWithCUMask(&sm, 8, mm));
     CK(hipExtStreamCreateWithCUMask(&sw, 8, mw));
+    printf("   masked streams created (X = %d)\n", X); fflush(stdout);
     // which XCDs does each partition reach?
     for (int w = 0; w < 2; ++w) {
       CK(hipMemset(probe, 0xFF, 4096 * 4));
@@ -194,13 +198,15 @@ int main() {
       printf("   X = %d, %s partition: workgroups per XCC", X, w ? "side" : "main");
       for (int i = 0; i < 8; ++i) printf(" %u", cnt[i]);
       printf("; blockIdx & 7 == XCC for %u of the first 64\n", rr);
+      fflush(stdout);
     }
     char name[128];
     snprintf(name, sizeof name, "C  masked streams: BN + dgrad on %d CUs, wgrad on %d CUs", X, 256 - X);
     run(name, sm, sw, X, 256 - X);
     snprintf(name, sizeof name, "C' masked, but everything on the %d-CU stream", X);
     run(name, sm, sm, X, X);
-    CK(hipStreamDestroy(sm)); CK(hipStreamDestroy(sw));
+    snprintf(name, sizeof name, "C\" masked, but everything on the %d-CU stream", 256 - X);
+    run(name, sw, sw, 256 - X, 256 - X);
   }
   run("A  one stream, full chip (last)", s1, s1, 256, 256);
   return 0;

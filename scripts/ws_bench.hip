@@ -64,7 +64,10 @@ int main() {
       float us[2] = {0, 0};
       bool skip = false;
       for (int v = 0; v < 2; ++v) {      // 0: reference path, 1: conv_ws
-        css_conv_ws_set_enabled(v);
+        // WB_REF_WS=1: the reference (v = 0) is round 4's conv_ws_kernel instead of the 256x256 persistent kernels (A/B of conv_ws4_kernel against it);
+        // WB_NO_WS4=1: v = 1 runs conv_ws_kernel too; WB_STAGGER=<cycles>: start delay of a CU's second workgroup in conv_ws4_kernel
+        css_conv_ws_set_enabled(v || getenv("WB_REF_WS") ? 1 : 0);
+        css_conv_ws4_set((v == 1 && !getenv("WB_NO_WS4")) ? 1 : 0, getenv("WB_STAGGER") ? atoi(getenv("WB_STAGGER")) : 1536);
         ConvArgs a{};
         a.src = dx; a.wt = dw; a.dst = dy[v]; a.bias = nullptr;
         a.N = s.N; a.Hs = s.H; a.Ws = s.W; a.Cs = s.Cin; a.lds = s.Cin;
@@ -98,6 +101,22 @@ int main() {
         float ms;
         hipEventElapsedTime(&ms, e0, e1);
         us[v] = ms / reps * 1e3f;
+        if (v == 1 && getenv("WB_RACE")) {          // race screen: WB_RACE launches, every output compared with the first one's
+          const int nr = atoi(getenv("WB_RACE"));
+          std::vector<unsigned short> first(ny), cur(ny);
+          std::vector<float> sfirst(nstat), scur(nstat);
+          int nbad = 0;
+          for (int r = 0; r < nr; ++r) {
+            hipMemset(dy[v], 0xFF, ny * 2);
+            css_launch_conv(a, CSS_BF16, 256, 0);
+            hipDeviceSynchronize();
+            hipMemcpy((r ? cur : first).data(), dy[v], ny * 2, hipMemcpyDeviceToHost);
+            if (ep == 1) hipMemcpy((r ? scur : sfirst).data(), dstat[v], nstat * 4, hipMemcpyDeviceToHost);
+            if (r && (memcmp(first.data(), cur.data(), ny * 2) || (ep == 1 && memcmp(sfirst.data(), scur.data(), (size_t)((M + 127) / 128) * 2 * s.Cout * 4)))) ++nbad;
+          }
+          printf("    race screen %s %s: %d of %d launches differ from the first\n", s.name, ep_name[ep], nbad, nr - 1);
+          if (nbad) ++bad;
+        }
 #ifdef WS_STAMP
         if (v == 1) {
           hipMemset(dbg, 0, 256 * 8 * 8 * 8);

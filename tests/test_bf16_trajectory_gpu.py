@@ -207,8 +207,9 @@ def test_bf16_tracks_fp32_in_a_calm_regime():
     """The same question where the problem is NOT chaotic ("compare bf16 against the ensemble in a calmer regime, keep at least one
     absolute bound that a broken bf16 path would violate"): the same 129^2, B = 4 + 4 problem at lr = CSS_TRAJ_LR_CALM (default 2e-4, 1/32 of the
     training rate) for 20 steps.  There two fp32 runs that differ by 1 ulp of input stay together, so bf16 can be held to ABSOLUTE bounds
-    step by step: supervised loss within 5 % of fp32 at every step, contrastive loss within 2 %, prototype cosine >= 0.98, centred weight
-    cosine >= 0.99 - and the perturbed fp32 run, printed beside it, shows how much of that is the problem's own spread."""
+    step by step: supervised loss within 25 % of fp32 at every step (a path that does not learn is 49 % off at the end), contrastive loss within
+    2 %, prototype cosine >= 0.98, centred weight cosine >= 0.99 - and the perturbed fp32 run, printed beside it, shows how much of that is the
+    problem's own spread (12 % on the supervised loss: the problem is chaotic at ANY useful rate)."""
     S, B, seed, gain, steps = 129, 4, 11, 0.25, 20
     lr = os.environ.get("CSS_TRAJ_LR_CALM", "2e-4")
     l_img, l_lab, u_img = _batch(S, B, 5, 16)
@@ -239,6 +240,12 @@ def test_bf16_tracks_fp32_in_a_calm_regime():
     print(f"calm regime (lr {lr}): fp32+ulp vs fp32: sup {gp[0]:.4f} contrast {gp[1]:.4f} proto cos {gp[2]:.5f} w cos {gp[3]:.6f} update cos {gp[4]:.5f}")
     print(f"calm regime (lr {lr}):     bf16 vs fp32: sup {gb[0]:.4f} contrast {gb[1]:.4f} proto cos {gb[2]:.5f} w cos {gb[3]:.6f} update cos {gb[4]:.5f}")
     assert all(math.isfinite(d["sup"]) and math.isfinite(d["contrast"]) for d in bf[0])
-    assert base[0][-1]["sup"] < base[0][0]["sup"] and bf[0][-1]["sup"] < bf[0][0]["sup"]             # both learn
-    assert gb[0] <= 0.05 and gb[1] <= 0.02 and gb[2] >= 0.98 and gb[3] >= 0.99, gb
-    assert gb[4] >= 0.9, gb           # the accumulated 20-step UPDATE of bf16 points where fp32's does (weights cosine alone is dominated by w0)
+    # ABSOLUTE bounds (measured on MI355X, round 5: bf16 0.106 / 0.0018 / 0.9981 / 0.99974, the fp32 pair 0.121 / 0.0015 / 0.9982 / 0.99988).  Even
+    # at 1/32 of the training rate two fp32 runs ONE ULP apart differ by 12 % in the supervised loss of some step, and their accumulated
+    # 20-step updates are nearly orthogonal (cosine 0.03: the gradient of this random-init network is dominated by components that flip sign
+    # with the ReLU masks) - the 5 % per-step bound first written here does not hold for fp32 itself, and the update cosine is printed, not
+    # asserted.  What a BROKEN bf16 path would violate: a path that does not learn stays at 7.0 while fp32 reaches 4.7 (gap 0.49 > 0.25);
+    # wrong statistics / wrong prototypes show in the contrastive loss (2 %) and the prototype cosine (0.98).
+    assert base[0][-1]["sup"] < 0.85 * base[0][0]["sup"] and bf[0][-1]["sup"] < 0.85 * bf[0][0]["sup"], (base[0][-1], bf[0][-1])      # both learn
+    assert gb[0] <= 0.25 and gb[1] <= 0.02 and gb[2] >= 0.98 and gb[3] >= 0.99, gb
+    assert gb[0] <= 2.5 * max(gp[0], 0.04), (gb[0], gp[0])          # ... and relative to the fp32 pair of the same run
