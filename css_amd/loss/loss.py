@@ -17,6 +17,7 @@ import torch.nn as nn
 
 from .. import _lib, ops
 from .._lib import call, dev_stream, dtype_code, query
+from ..ops import on_backward_stream
 from ..functional import nhwc
 
 
@@ -53,6 +54,7 @@ class _PixelCE(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, g):
         x, label, coef, keep = ctx.saved_tensors
         mode, in_dtype = ctx.cfg
@@ -103,6 +105,7 @@ class _PixelCESmall(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, g):
         x, label, coef, keep = ctx.saved_tensors
         mode, in_dtype = ctx.cfg
@@ -210,6 +213,7 @@ class _ContrastCore(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, g):
         gradbuf, anchor_pix, meta = ctx.saved_tensors
         P, C, K, Q, dt = ctx.cfg

@@ -11,7 +11,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import _lib, peer
+from . import _lib, partition, peer
 from ._lib import call, dev_stream, dtype_code
 
 BN_EPS = 1e-5
@@ -137,6 +137,25 @@ class direct_param_grads:
         _direct_grads = self.prev
 
 
+def on_backward_stream(fn):
+    """Decorator of every custom ``backward``: inside a partition window (css_amd/partition.py) the body runs with the partition's MAIN stream
+    current, ordered against the stream the autograd engine chose for the node in both directions; outside a window it is the function itself."""
+    def wrapper(ctx, *grads):
+        part = partition.active()
+        if part is None:
+            return fn(ctx, *grads)
+        cur = torch.cuda.current_stream(part.device)
+        if cur == part.main:
+            return fn(ctx, *grads)
+        part.main.wait_stream(cur)
+        with torch.cuda.stream(part.main):
+            out = fn(ctx, *grads)
+        cur.wait_stream(part.main)
+        return out
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
 # Called with a parameter right after the kernels that ADD its gradient into the flat buffer were enqueued (direct mode only):
 # lets the trainer start the all-reduce of a gradient bucket while the rest of backward is still running (train_step.py)
 _grad_ready_cb = None
@@ -211,6 +230,7 @@ class _Conv2d(torch.autograd.Function):
         return y
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dy, dtap=None):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias, flops = ctx.cfg
@@ -228,6 +248,11 @@ class _Conv2d(torch.autograd.Function):
             dyp = torch.zeros((n, ho, wo, cout_pad), dtype=dt, device=dy.device)
             call("css_copy_channels", dy, cout, dyp, cout_pad, n * ho * wo, cout, dc, dc, dev, st)
         dx = dw = db = None
+        part = partition.active()
+        ev_dy = None
+        if part is not None and ctx.needs_input_grad[1]:
+            ev_dy = torch.cuda.Event()       # the incoming gradient is complete HERE on the main stream: the side stream's weight gradient
+            ev_dy.record(part.main)          # waits for this, not for the data gradient queued below
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
@@ -252,8 +277,21 @@ class _Conv2d(torch.autograd.Function):
             # workspace for the per-slice partial tiles (plain stores + ordered reduction instead of fp32 atomics); 0 bytes: the
             # shape takes a kernel without that path
             wsb = _lib.query("css_conv2d_wgrad_ws_bytes", n * ho * wo, r * s * cp, cout_pad, dc, dev)
-            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
-            if sink is not None:      # the wgrad kernels ADD into dw: straight into param.grad
+            part = part if sink is not None else None
+            if part is not None:
+                # partitioned backward: the weight gradient goes to the SIDE stream (its own CUs) behind the data gradient's operands; nothing
+                # of backward reads it, the window's end joins it before the optimizer.  x / dyp stay referenced until the side stream is past them.
+                part.side.wait_event(ev_dy)
+                with torch.cuda.stream(part.side):
+                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
+                    call("css_conv2d_wgrad", x, dyp, sink, ws, wsb, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
+                         dc, dev, part.side.cuda_stream)
+                part.hold(x, dyp)
+                _grad_ready(weight)
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if (wsb and part is None) else None
+            if part is not None:
+                pass
+            elif sink is not None:      # the wgrad kernels ADD into dw: straight into param.grad
                 call("css_conv2d_wgrad", x, dyp, sink, ws, wsb, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
                      dc, dev, st)
                 _grad_ready(weight)
@@ -470,6 +508,7 @@ class _BNAct(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, da):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
@@ -588,6 +627,7 @@ class _MaxPool(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         (arg,) = ctx.saved_tensors
         (n, h, w, c), ks, stride, pad = ctx.cfg
@@ -622,6 +662,7 @@ class _Bilinear(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         (n, hs, ws, c), in_dtype = ctx.cfg
         ldo = _row_stride(dout)       # a channel slice of a concat gradient is read in place
@@ -649,6 +690,7 @@ class _GlobalAvgPool(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         n, h, w, c = ctx.cfg
         dout = dout.contiguous()
@@ -678,6 +720,7 @@ class _Broadcast(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         n, h, w, c = dout.shape
@@ -706,6 +749,7 @@ class _CatFromViews(torch.autograd.Function):
         return buf.view(buf.shape)
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         outs, off = [None], 0
@@ -737,6 +781,7 @@ class _CatChannels(torch.autograd.Function):
         return out
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         n, h, w, ct = dout.shape
@@ -768,6 +813,7 @@ class _Split2(torch.autograd.Function):
         return x.narrow(0, 0, b), x.narrow(0, b, x.shape[0] - b)
 
     @staticmethod
+    @on_backward_stream
     def backward(ctx, g0, g1):
         out = torch.empty(ctx.shape, dtype=ctx.dt, device=(g0 if g0 is not None else g1).device)
         for g, sl in ((g0, out.narrow(0, 0, ctx.b)), (g1, out.narrow(0, ctx.b, ctx.shape[0] - ctx.b))):
