@@ -30,7 +30,6 @@ struct ConvArgs {
   unsigned stat_bytes, add_bytes; // sizes of the stats / addend buffers (buffer descriptors)
   unsigned mask_bytes;            // size of add_mask
   int korder;                     // order of the K steps (conv_pp.hip: issue())
-  int ws_stagger;                 // conv_ws4_kernel: cycles the second workgroup of a CU starts late (filled by the launcher)
   int tab_da[63], tab_kb[63], tab_tap[63];   // conv_p8.hip: tap lists per set of valid kernel rows (7 x 9)
 };
 
@@ -67,7 +66,6 @@ void css_launch_conv_p8(ConvArgs a, int grid, hipStream_t st);
 bool css_conv_ws_supported(const ConvArgs& a, int n_cu);
 void css_launch_conv_ws(ConvArgs a, int n_cu, hipStream_t st);
 void css_conv_ws_set_enabled(int on);
-void css_conv_ws4_set(int on, int stagger);
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
 size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu);
 

@@ -137,23 +137,76 @@ class direct_param_grads:
         _direct_grads = self.prev
 
 
-def on_backward_stream(fn):
+_VIEW_NODES = ("PermuteBackward", "ViewBackward", "ReshapeAliasBackward", "UnsafeViewBackward", "AsStridedBackward", "SliceBackward", "SelectBackward",
+               "TBackward", "TransposeBackward", "AliasBackward", "ExpandBackward", "SqueezeBackward", "UnsqueezeBackward", "DetachBackward")
+_OWN_NODES = set()           # names of the autograd nodes of this package's Functions ("<Function>Backward"): filled by the decorator
+
+
+def _node_kind(node):
+    """'own' (a Function of this package: runs on the partition's main stream), 'view' (no kernel), 'native' (a torch kernel on the engine's stream)."""
+    name = type(node).__name__
+    if name in _OWN_NODES:
+        return "own"
+    return "view" if name.startswith(_VIEW_NODES) else "native"
+
+
+def on_backward_stream(fn=None, *, entry=False):
     """Decorator of every custom ``backward``: inside a partition window (css_amd/partition.py) the body runs with the partition's MAIN stream
-    current, ordered against the stream the autograd engine chose for the node in both directions; outside a window it is the function itself."""
-    def wrapper(ctx, *grads):
-        part = partition.active()
-        if part is None:
-            return fn(ctx, *grads)
-        cur = torch.cuda.current_stream(part.device)
-        if cur == part.main:
-            return fn(ctx, *grads)
-        part.main.wait_stream(cur)
-        with torch.cuda.stream(part.main):
-            out = fn(ctx, *grads)
-        cur.wait_stream(part.main)
-        return out
-    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
-    return wrapper
+    current (torch's own allocations / fills / casts inside it follow).  Ordering against the stream the autograd engine chose for the node:
+    ``entry`` nodes (the losses: their incoming gradient comes from torch's scalar arithmetic) wait for it first; a node that hands a gradient to
+    a torch-native consumer (AccumulateGrad, a view in front of one) makes it wait for the main stream afterwards; between two nodes of this
+    package nothing is needed - both are on the main stream.  ``part.strict`` (the first backward found a torch-native kernel node between two
+    of ours, or CSS_BWD_PARTITION_STRICT=1) synchronises both ways around EVERY node instead.  Outside a window: the function itself."""
+    def deco(f):
+        def wrapper(ctx, *grads):
+            part = partition.active()
+            if part is None:
+                return f(ctx, *grads)
+            cur = torch.cuda.current_stream(part.device)
+            if cur == part.main:
+                return f(ctx, *grads)
+            if entry or part.strict:
+                part.main.wait_stream(cur)
+            with torch.cuda.stream(part.main):
+                out = f(ctx, *grads)
+            sync = part.strict
+            if not sync:
+                outs = out if isinstance(out, tuple) else (out,)
+                nf = ctx.next_functions
+                for i, g in enumerate(outs):
+                    if g is not None and i < len(nf) and nf[i][0] is not None and _node_kind(nf[i][0]) != "own":
+                        sync = True
+                        break
+            if sync:
+                cur.wait_stream(part.main)
+            return out
+        wrapper.__name__, wrapper.__doc__ = f.__name__, f.__doc__
+        wrapper._css_on_backward_stream = True
+        return wrapper
+    return deco(fn) if fn is not None else deco
+
+
+def register_own_node(cls):
+    """Class decorator of the package's autograd Functions: their backward nodes count as 'own' in a partitioned backward."""
+    _OWN_NODES.add(cls.__name__ + "Backward")
+    return cls
+
+
+def graph_allows_light_partition(root) -> bool:
+    """Walk the autograd graph of ``root`` once: a torch-native kernel node DOWNSTREAM of one of this package's nodes (its gradient input produced on
+    the main stream, its kernel on the engine's) other than AccumulateGrad would be unordered in the light mode -> False (strict mode)."""
+    seen, stack = set(), [(root.grad_fn, False)]
+    while stack:
+        node, below_own = stack.pop()
+        if node is None or (id(node), below_own) in seen:
+            continue
+        seen.add((id(node), below_own))
+        kind = _node_kind(node)
+        if kind == "native" and below_own and type(node).__name__ != "AccumulateGrad":
+            return False
+        for child, _ in node.next_functions:
+            stack.append((child, below_own or kind == "own"))
+    return True
 
 
 # Called with a parameter right after the kernels that ADD its gradient into the flat buffer were enqueued (direct mode only):
@@ -193,6 +246,7 @@ def conv_out_size(h, k, stride, pad, dil):
 # --------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------
+@register_own_node
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, stat_groups, tap):
@@ -251,7 +305,7 @@ class _Conv2d(torch.autograd.Function):
         part = partition.active()
         ev_dy = None
         if part is not None and ctx.needs_input_grad[1]:
-            ev_dy = torch.cuda.Event()       # the incoming gradient is complete HERE on the main stream: the side stream's weight gradient
+            ev_dy = part.event()             # the incoming gradient is complete HERE on the main stream: the side stream's weight gradient
             ev_dy.record(part.main)          # waits for this, not for the data gradient queued below
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
@@ -436,6 +490,7 @@ def _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum
     return count_t
 
 
+@register_own_node
 class _BNAct(torch.autograd.Function):
     """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
@@ -605,6 +660,7 @@ def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, train
 # --------------------------------------------------------------------------
 # pooling / resize / concat
 # --------------------------------------------------------------------------
+@register_own_node
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ks, stride, pad, ceil_mode):
@@ -643,6 +699,7 @@ def maxpool(x, ks=3, stride=2, pad=1, ceil_mode=False):
     return _MaxPool.apply(x, ks, stride, pad, ceil_mode)
 
 
+@register_own_node
 class _Bilinear(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=True) on NHWC tensors; output dtype selectable."""
 
@@ -679,6 +736,7 @@ def bilinear(x, hd, wd, out_dtype=None, out_into=None):
     return _Bilinear.apply(x, hd, wd, out_dtype or x.dtype, out_into)
 
 
+@register_own_node
 class _GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -704,6 +762,7 @@ def global_avg_pool(x):
     return _GlobalAvgPool.apply(x)
 
 
+@register_own_node
 class _Broadcast(torch.autograd.Function):
     """[N,1,1,C] -> [N,H,W,C] (bilinear resize of a 1x1 map, aspp.py:38)."""
 
@@ -734,6 +793,7 @@ def broadcast_hw(x, h, w, out_into=None):
     return _Broadcast.apply(x, h, w, out_into)
 
 
+@register_own_node
 class _CatFromViews(torch.autograd.Function):
     """The concatenation whose pieces were WRITTEN IN PLACE into ``buf`` by their producers (``out_into=(buf, offset)`` of
     bn_act / broadcast_hw): forward is free, backward hands every producer its channel slice of the gradient as a view."""
@@ -763,6 +823,7 @@ def cat_from_views(buf, *views):
     return _CatFromViews.apply(buf, *views)
 
 
+@register_own_node
 class _CatChannels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -804,6 +865,7 @@ def cat_channels(*xs):
     return _CatChannels.apply(*xs)
 
 
+@register_own_node
 class _Split2(torch.autograd.Function):
     """(x[:b], x[b:]) along dim 0 with a single-copy backward (autograd's own slicing would zero-fill two full tensors)."""
 

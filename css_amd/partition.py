@@ -8,10 +8,12 @@ gradients, the rest for the weight gradients - the memory-bound and the matrix-b
 1209 -> 1106 us at 192 + 64 CUs (scripts/partition_bench.hip, profiles/r05_partition_bench.txt).
 
 How it is wired without touching the autograd engine's stream rules (every backward node runs on the stream its forward ran on):
-``ops.on_backward_stream`` wraps every custom ``backward``: inside a partition window it makes the main stream wait for the engine's stream,
-runs the body with the main stream current (torch allocations, fills and the css_* launches all follow ``torch.cuda.current_stream``), and makes
-the engine's stream wait for the main stream again - so the few torch-native nodes between ours (scalar loss arithmetic) stay ordered in both
-directions.  ``_Conv2d.backward`` sends its weight gradient to the side stream behind an event; the operands stay referenced until the side
+``ops.on_backward_stream`` wraps every custom ``backward``: inside a partition window the body runs with the main stream current (torch
+allocations, fills and the css_* launches all follow ``torch.cuda.current_stream``).  The loss nodes first make the main stream wait for the engine's
+stream (their incoming gradient comes from torch's scalar arithmetic); a node that hands a gradient to a torch-native consumer makes the engine's stream
+wait for the main stream; between two nodes of this package nothing is needed.  The first window walks the graph: a torch-native kernel node between
+two of ours switches to the strict mode (both waits around EVERY node: +40 ms of host time per step when it was the only mode - the first A/B of
+profiles/r05_partition_ab.txt).  ``_Conv2d.backward`` sends its weight gradient to the side stream behind an event; the operands stay referenced until the side
 stream has passed them (no ``record_stream``: the allocator never sees a cross-stream free).  The window ends with the engine's stream waiting for both.
 
 Results are independent of the partition: the data-gradient kernels compute the same tiles on a smaller grid, the weight-gradient slice plan is made
@@ -54,16 +56,23 @@ class BwdPartition:
         self.device, self.main_cus, self.side_cus = dev, main_cus, total - main_cus
         self.main = torch.cuda.ExternalStream(ptrs[0], device=dev)
         self.side = torch.cuda.ExternalStream(ptrs[1], device=dev)
-        self._held = collections.deque()              # (event on the side stream, tensors its kernels read)
+        self._held = []                               # tensors the side stream's kernels read: referenced until the window closes
+        self._events, self._ev_next = [], 0           # reusable events (created once: an Event() per convolution showed up in the host's time)
+        # strict: both-way synchronisation around EVERY node.  None = not decided yet: the first window walks the graph (ops.graph_allows_light_partition)
+        self.strict = True if os.environ.get("CSS_BWD_PARTITION_STRICT") == "1" else None
 
     # ---- the window: one backward pass ----
     @contextlib.contextmanager
-    def window(self):
+    def window(self, root=None):
         global _active
         if _active is not None:
             raise RuntimeError("nested backward partition windows")
+        if self.strict is None:
+            from . import ops
+            self.strict = not (root is not None and ops.graph_allows_light_partition(root))
         cur = torch.cuda.current_stream(self.device)
         self.main.wait_stream(cur)
+        self._ev_next = 0
         _active = self
         try:
             yield self
@@ -74,13 +83,19 @@ class BwdPartition:
             cur.wait_stream(self.side)
             self._held.clear()                        # every later use of those blocks is ordered behind the two waits above
 
+    def event(self):
+        """A reusable event of this window (re-recording an event whose earlier waits were already queued is fine: a wait binds to the record
+        that precedes it in host order)."""
+        if self._ev_next == len(self._events):
+            self._events.append(torch.cuda.Event())
+        ev = self._events[self._ev_next]
+        self._ev_next += 1
+        return ev
+
     def hold(self, *tensors):
-        """Keep ``tensors`` alive until the side stream has passed the work queued on it so far."""
-        ev = torch.cuda.Event()
-        ev.record(self.side)
-        self._held.append((ev, tensors))
-        while len(self._held) > 4 and self._held[0][0].query():
-            self._held.popleft()
+        """Keep ``tensors`` alive until the window closes (the side stream reads them at a time of its own; no ``record_stream``, no allocator
+        events: at the bench's sizes this keeps ~17 GB of incoming gradients alive for the length of a backward pass - of 288)."""
+        self._held.append(tensors)
 
 
 def active():

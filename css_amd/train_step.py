@@ -137,7 +137,7 @@ class MixTrainer:
             part = partition.get(self.flat_p.device) if (not sync and self.flat_p.is_cuda) else None
             with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
                 if part is not None:
-                    with part.window():
+                    with part.window(total):
                         total.backward()
                 else:
                     total.backward()

@@ -39,8 +39,8 @@ CSS_API int css_stream_cu_count(int device, css_stream_t stream);
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------------
  * Every kernel launch of a bracketed call gets its own event pair.  kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad
  * (launches of every kernel but the 256x256 LDS-DMA ones), 3 = contrast loss gather, 4 = similarity,
- * 5 / 6 / 7 = forward / dgrad launches of the 256-channel-panel MFMA kernels (conv_igemm_p8_kernel, conv_igemm_pp_kernel, conv_ws_kernel,
- * conv_ws4_kernel) and conv_wgrad_p8_kernel launches; 13 / 14 = the conv_ws_kernel / conv_ws4_kernel launches among 5 / 6
+ * 5 / 6 / 7 = forward / dgrad launches of the 256-channel-panel MFMA kernels (conv_igemm_p8_kernel, conv_igemm_pp_kernel, conv_ws_kernel)
+ * and conv_wgrad_p8_kernel launches; 13 / 14 = the conv_ws_kernel launches among 5 / 6
  * again, with their FLOPs (13) and with their algorithmic bytes (14: the kernel is judged against both rooflines); 15 = the OTHER
  * launches among 5 / 6 (the persistent 256x256-tile kernels) with the call's algorithmic bytes - source, weights, output once each,
  * + addend and mask - so that a PMC traffic figure for that kernel can be read against them.

@@ -14,7 +14,7 @@ PY
 }
 for rep in 1 2; do
   for wl in c2 c4; do
-    for v in 0 192 160 224; do
+    for v in 0 192 160; do
       CSS_BWD_PARTITION=$v timeout 900 python bench.py --workload $wl --no-cpu-baseline --no-extra --steps 10 --warmup 10 > gpurun_out/ab_tmp.json 2>> gpurun_out/ab_tmp.err
       echo -n "PARTITION=$v $wl: " >> $O; line gpurun_out/ab_tmp.json >> $O
     done

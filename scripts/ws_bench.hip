@@ -64,10 +64,9 @@ int main() {
       float us[2] = {0, 0};
       bool skip = false;
       for (int v = 0; v < 2; ++v) {      // 0: reference path, 1: conv_ws
-        // WB_REF_WS=1: the reference (v = 0) is round 4's conv_ws_kernel instead of the 256x256 persistent kernels (A/B of conv_ws4_kernel against it);
-        // WB_NO_WS4=1: v = 1 runs conv_ws_kernel too; WB_STAGGER=<cycles>: start delay of a CU's second workgroup in conv_ws4_kernel
+        // WB_REF_WS=1: the reference (v = 0) is conv_ws_kernel too (measures the harness's own bias between its first and second variant: the second
+        // one read 3-8 % slower on the SAME kernel in round 5 - alternate processes for A/B figures)
         css_conv_ws_set_enabled(v || getenv("WB_REF_WS") ? 1 : 0);
-        css_conv_ws4_set((v == 1 && !getenv("WB_NO_WS4")) ? 1 : 0, getenv("WB_STAGGER") ? atoi(getenv("WB_STAGGER")) : 1536);
         ConvArgs a{};
         a.src = dx; a.wt = dw; a.dst = dy[v]; a.bias = nullptr;
         a.N = s.N; a.Hs = s.H; a.Ws = s.W; a.Cs = s.Cin; a.lds = s.Cin;

@@ -391,65 +391,6 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
 
 
-def test_conv_ws4_kernel_isa(tmp_path):
-    """conv_ws4_kernel (csrc/conv_ws.hip, round 5: two four-wave workgroups per CU): 256 VGPRs at most and NO scratch (a spill reload inside
-    the loop drains the LDS-DMA queue once per half tile - the first build did exactly that), LDS small enough for two workgroups per CU,
-    the counted stage waits of the source and no compiler-inserted vmcnt(0) between the first barrier and the last MFMA."""
-    import shutil
-    import subprocess
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        pytest.skip("hipcc not available")
-    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv_ws.hip")
-    out = str(tmp_path / "conv_ws.s")
-    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
-                   check=True, capture_output=True, timeout=600)
-    lines = open(out).read().split("\n")
-    for ks, st in ((4, 1), (4, 0), (2, 1), (2, 0), (1, 1), (1, 0)):
-        nt = {4: 2, 2: 4, 1: 6}[ks]
-        la = nt * ks
-        sym = f"_Z15conv_ws4_kernelILi{ks}ELb{st}EEv8ConvArgs:"
-        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
-        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
-        body = lines[start:end]
-        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
-        assert mfma and len(mfma) % (2 * 32 * ks) == 0, (sym, len(mfma))               # two halves x KS stages x 32 MFMAs
-        bar = [i for i, l in enumerate(body) if "s_barrier" in l]
-        assert not any("vmcnt(0)" in l for l in body[bar[0]:mfma[-1] + 1]), sym + " compiler drained the LDS-DMA pipeline inside the K loop"
-        for e in range(nt + 1):                                                       # W(e) = 2 (LA - 1) + 8 min(e, NT)
-            wv = 2 * (la - 1) + 8 * e
-            assert any(f"s_waitcnt vmcnt({wv})" in l for l in body), (sym, wv)
-        tail = lines[end:]
-        assert next(int(l.split()[2]) for l in tail if l.startswith("; ScratchSize:")) == 0, sym
-        assert next(int(l.split()[2]) for l in tail if l.startswith("; NumVgprs:")) <= 256, sym
-        lds = next(int(l.split()[2]) for l in tail if l.startswith("; LDSByteSize:"))
-        assert lds == (la + 1) * 8192 + (2048 if st else 0) and 2 * lds <= 160 * 1024, (sym, lds)
-
-
-def test_conv_ws4_vmcnt_accounting_model():
-    """The same replay as test_conv_ws_vmcnt_accounting_model for conv_ws4_kernel: per half tile KS stages (wait -> two pieces of stage + LA ->
-    MFMAs) and eight stores; every second half tile of the statistics form adds eight statistics stores the wait does NOT count (a smaller
-    count only waits for more).  W(e) = 2 (LA - 1) + 8 min(e, NT), e = half tiles finished."""
-    for ks in (1, 2, 4):
-        nt = {4: 2, 2: 4, 1: 6}[ks]
-        la = nt * ks
-        for stats in (0, 1):
-            ops = [("B",)] * (2 * ks * 4)
-            for st in range(la):
-                ops += [("piece", st)] * 2
-            for e in range(16):
-                for k in range(ks):
-                    s_ = e * ks + k
-                    last = max(i for i, o in enumerate(ops) if o == ("piece", s_))
-                    younger = len(ops) - 1 - last
-                    w = 2 * (la - 1) + 8 * min(e, nt)
-                    assert w <= 63 and w <= younger, (ks, stats, e, k, w, younger)
-                    if not stats and e >= nt:
-                        assert w == younger, (ks, e, k, w, younger)
-                    ops += [("piece", s_ + la)] * 2
-                ops += [("store", e)] * (8 + (8 if stats and e % 2 else 0))
-
-
 def test_conv_ws_vmcnt_accounting_model():
     """conv_ws_kernel waits for "my two LDS-DMA pieces of stage s" with s_waitcnt vmcnt(W): vector-memory operations retire in order, so
     the wait is correct iff W <= the number of operations the wave issued AFTER those pieces, and free of unnecessary stalls iff W equals

@@ -31,9 +31,17 @@ def _with_partition(n, fn):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32], ids=["bf16", "fp32"])
 def test_partitioned_backward_is_bit_identical(dtype):
+    from css_amd import partition
     a = _with_partition(0, lambda: _run(dtype, 5))
     b = _with_partition(192, lambda: _run(dtype, 5))
-    c = _with_partition(160, lambda: _run(dtype, 2))
+    # (the first window walked the graph: no torch-native kernel node between two nodes of this package -> the light mode)
+    assert _with_partition(192, lambda: partition.get(dev())).strict is False
+    os.environ["CSS_BWD_PARTITION_STRICT"] = "1"        # another split, every node synchronised both ways
+    try:
+        c = _with_partition(160, lambda: _run(dtype, 2))
+        assert _with_partition(160, lambda: partition.get(dev())).strict is True
+    finally:
+        os.environ.pop("CSS_BWD_PARTITION_STRICT", None)
     for i in range(a["hist"].shape[0]):
         assert _same_bits(a["hist"][i], b["hist"][i]), (i, a["hist"][i].tolist(), b["hist"][i].tolist())
     for key in ("p", "m", "ema", "proto"):
