@@ -28,20 +28,6 @@ int cu_count(int device) {
   return g_cu_count[d];
 }
 
-// ---- CU partitions: streams created with a CU mask (css_stream_create_masked) and the number of CUs they may use.  The persistent kernels size
-// their grids by the CUs of the STREAM they are launched on (one workgroup per CU: a 256-workgroup grid on a 192-CU partition would need two rounds).
-struct StreamCus { hipStream_t s; int n; };
-std::mutex g_part_mu;
-std::vector<StreamCus> g_stream_cus;
-int cus_of(int device, hipStream_t s) {
-  if (!g_stream_cus.empty()) {
-    std::lock_guard<std::mutex> lk(g_part_mu);
-    for (const auto& e : g_stream_cus)
-      if (e.s == s) return e.n;
-  }
-  return cu_count(device);
-}
-
 // ---- profiling ----
 struct ProfRec { hipEvent_t a, b; int kind; double work; bool alias; };   // alias: second record over the same event pair (not pooled)
 constexpr int PROF_KINDS = 16;
@@ -123,22 +109,6 @@ extern "C" {
 
 int css_abi_version(void) { return 1; }
 int css_device_cu_count(int device) { return cu_count(device); }
-int css_stream_create_masked(int device, int first_cu, int n_cus, css_stream_t* out) {
-  const int total = cu_count(device);
-  if (!out || first_cu < 0 || n_cus < 8 || (n_cus & 7) || (first_cu & 7) || first_cu + n_cus > total || total > 1024) return CSS_ERR_ARG;
-  set_dev(device);
-  unsigned mask[32] = {0};
-  for (int b = first_cu; b < first_cu + n_cus; ++b) mask[b >> 5] |= 1u << (b & 31);
-  hipStream_t st = nullptr;
-  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)((total + 31) / 32), mask) != hipSuccess || !st) { (void)hipGetLastError(); return CSS_ERR_LAUNCH; }
-  {
-    std::lock_guard<std::mutex> lk(g_part_mu);
-    g_stream_cus.push_back({st, n_cus});
-  }
-  *out = reinterpret_cast<css_stream_t>(st);
-  return CSS_OK;
-}
-int css_stream_cu_count(int device, css_stream_t stream) { return cus_of(device, S(stream)); }
 
 int css_prof_enable(int on) { g_prof_on = on != 0; return 0; }
 int css_prof_reset(void) {
@@ -177,7 +147,7 @@ int css_conv2d_forward(const void* x, const void* w, const float* bias, void* y,
   cp.hbm_bytes = short_k_bytes(a, dtype);
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   cp.conv_bytes = conv_alg_bytes(a, dtype);
-  return css_launch_conv(a, dtype, cus_of(device, S(stream)), S(stream), g_prof_on ? &cp : nullptr);
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* stats, int Mg, int N, int H, int W, int Cin, int ldx, int Ho, int Wo,
                                int Cout, int ldy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device,
@@ -195,7 +165,7 @@ int css_conv2d_forward_bnstats(const void* x, const void* w, void* y, float* sta
   cp.hbm_bytes = short_k_bytes(a, dtype);
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   cp.conv_bytes = conv_alg_bytes(a, dtype);
-  return css_launch_conv(a, dtype, cus_of(device, S(stream)), S(stream), g_prof_on ? &cp : nullptr);
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, void* y, int N, int H, int W, int Cin, int ldx, int Ho, int Wo, int Cout,
                                          int ldy, int R, int Sk, int stride, int pad, int dil, int dtype, int device) {
@@ -222,7 +192,7 @@ int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, in
   ConvProf cp(1, 6, alg_flops, S(stream));
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   cp.conv_bytes = conv_alg_bytes(a, dtype);
-  return css_launch_conv(a, dtype, cus_of(device, S(stream)), S(stream), g_prof_on ? &cp : nullptr);
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 static int dgrad_add_impl(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, const unsigned char* mask, int N, int H, int W, int Cin,
                           int lddx, int Ho, int Wo, int Cout, int lddy, int R, int Sk, int stride, int pad, int dil, double alg_flops, int dtype,
@@ -243,7 +213,7 @@ static int dgrad_add_impl(const void* dy, const void* w_t, void* dx, const void*
   ConvProf cp(1, 6, alg_flops, S(stream));
   cp.ws_bytes = conv1x1_bytes(a, dtype);
   cp.conv_bytes = conv_alg_bytes(a, dtype);
-  return css_launch_conv(a, dtype, cus_of(device, S(stream)), S(stream), g_prof_on ? &cp : nullptr);
+  return css_launch_conv(a, dtype, cu_count(device), S(stream), g_prof_on ? &cp : nullptr);
 }
 int css_conv2d_dgrad_add(const void* dy, const void* w_t, void* dx, const void* addend, int ld_add, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy, int R,
                      int Sk, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream) {
@@ -506,7 +476,7 @@ int css_similarity(const void* rep, int ld, const void* proto_n, float* sim, flo
                    float temp, float strong_thr, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   ProfScope ps(4, (double)P * C * (dtype == CSS_BF16 ? 2 : 4), S(stream));
-  return css_launch_similarity(rep, ld, proto_n, sim, prob, cls, hard, P, K, C, temp, strong_thr, dtype, cus_of(device, S(stream)), S(stream));
+  return css_launch_similarity(rep, ld, proto_n, sim, prob, cls, hard, P, K, C, temp, strong_thr, dtype, cu_count(device), S(stream));
 }
 int css_softmax_hard_flags(const void* pred, int ld, const int* cls, int P, int K, float strong_thr, uint8_t* hard, int dtype, int device,
                            css_stream_t stream) {

@@ -17,14 +17,12 @@ import torch.nn as nn
 
 from .. import _lib, ops
 from .._lib import call, dev_stream, dtype_code, query
-from ..ops import on_backward_stream, register_own_node
 from ..functional import nhwc
 
 
 # --------------------------------------------------------------------------
 # pixel-wise cross-entropy family
 # --------------------------------------------------------------------------
-@register_own_node
 class _PixelCE(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, label, conf, conf_thr, mode, ohem):
@@ -55,7 +53,6 @@ class _PixelCE(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
-    @on_backward_stream(entry=True)
     def backward(ctx, g):
         x, label, coef, keep = ctx.saved_tensors
         mode, in_dtype = ctx.cfg
@@ -67,7 +64,6 @@ class _PixelCE(torch.autograd.Function):
         return dx.permute(0, 3, 1, 2).to(in_dtype), None, None, None, None, None
 
 
-@register_own_node
 class _PixelCESmall(torch.autograd.Function):
     """The same losses from the LOW-resolution NHWC logits ``small`` [B,h,w,K]: the bilinear(align_corners=True) up-sampling to the
     label size (ddp_model.py:141,144) is applied on the fly in forward and backward (css_ce_small_*), so the [B,K,H,W] fp32
@@ -107,7 +103,6 @@ class _PixelCESmall(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
-    @on_backward_stream(entry=True)
     def backward(ctx, g):
         x, label, coef, keep = ctx.saved_tensors
         mode, in_dtype = ctx.cfg
@@ -172,7 +167,6 @@ class ProbOhemCrossEntropy2d(nn.Module):
 # --------------------------------------------------------------------------
 # contrastive loss
 # --------------------------------------------------------------------------
-@register_own_node
 class _ContrastCore(torch.autograd.Function):
     """rep [P, C] rows (NHWC-flattened), cls int32 [P], hard uint8 [P]; prototypes updated in place."""
 
@@ -216,7 +210,6 @@ class _ContrastCore(torch.autograd.Function):
         return loss[0]
 
     @staticmethod
-    @on_backward_stream(entry=True)
     def backward(ctx, g):
         gradbuf, anchor_pix, meta = ctx.saved_tensors
         P, C, K, Q, dt = ctx.cfg

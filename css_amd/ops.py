@@ -11,7 +11,7 @@ import os
 import torch
 import torch.distributed as dist
 
-from . import _lib, partition, peer
+from . import _lib, peer
 from ._lib import call, dev_stream, dtype_code
 
 BN_EPS = 1e-5
@@ -137,78 +137,6 @@ class direct_param_grads:
         _direct_grads = self.prev
 
 
-_VIEW_NODES = ("PermuteBackward", "ViewBackward", "ReshapeAliasBackward", "UnsafeViewBackward", "AsStridedBackward", "SliceBackward", "SelectBackward",
-               "TBackward", "TransposeBackward", "AliasBackward", "ExpandBackward", "SqueezeBackward", "UnsqueezeBackward", "DetachBackward")
-_OWN_NODES = set()           # names of the autograd nodes of this package's Functions ("<Function>Backward"): filled by the decorator
-
-
-def _node_kind(node):
-    """'own' (a Function of this package: runs on the partition's main stream), 'view' (no kernel), 'native' (a torch kernel on the engine's stream)."""
-    name = type(node).__name__
-    if name in _OWN_NODES:
-        return "own"
-    return "view" if name.startswith(_VIEW_NODES) else "native"
-
-
-def on_backward_stream(fn=None, *, entry=False):
-    """Decorator of every custom ``backward``: inside a partition window (css_amd/partition.py) the body runs with the partition's MAIN stream
-    current (torch's own allocations / fills / casts inside it follow).  Ordering against the stream the autograd engine chose for the node:
-    ``entry`` nodes (the losses: their incoming gradient comes from torch's scalar arithmetic) wait for it first; a node that hands a gradient to
-    a torch-native consumer (AccumulateGrad, a view in front of one) makes it wait for the main stream afterwards; between two nodes of this
-    package nothing is needed - both are on the main stream.  ``part.strict`` (the first backward found a torch-native kernel node between two
-    of ours, or CSS_BWD_PARTITION_STRICT=1) synchronises both ways around EVERY node instead.  Outside a window: the function itself."""
-    def deco(f):
-        def wrapper(ctx, *grads):
-            part = partition.active()
-            if part is None:
-                return f(ctx, *grads)
-            cur = torch.cuda.current_stream(part.device)
-            if cur == part.main:
-                return f(ctx, *grads)
-            if entry or part.strict:
-                part.main.wait_stream(cur)
-            with torch.cuda.stream(part.main):
-                out = f(ctx, *grads)
-            sync = part.strict
-            if not sync:
-                outs = out if isinstance(out, tuple) else (out,)
-                nf = ctx.next_functions
-                for i, g in enumerate(outs):
-                    if g is not None and i < len(nf) and nf[i][0] is not None and _node_kind(nf[i][0]) != "own":
-                        sync = True
-                        break
-            if sync:
-                cur.wait_stream(part.main)
-            return out
-        wrapper.__name__, wrapper.__doc__ = f.__name__, f.__doc__
-        wrapper._css_on_backward_stream = True
-        return wrapper
-    return deco(fn) if fn is not None else deco
-
-
-def register_own_node(cls):
-    """Class decorator of the package's autograd Functions: their backward nodes count as 'own' in a partitioned backward."""
-    _OWN_NODES.add(cls.__name__ + "Backward")
-    return cls
-
-
-def graph_allows_light_partition(root) -> bool:
-    """Walk the autograd graph of ``root`` once: a torch-native kernel node DOWNSTREAM of one of this package's nodes (its gradient input produced on
-    the main stream, its kernel on the engine's) other than AccumulateGrad would be unordered in the light mode -> False (strict mode)."""
-    seen, stack = set(), [(root.grad_fn, False)]
-    while stack:
-        node, below_own = stack.pop()
-        if node is None or (id(node), below_own) in seen:
-            continue
-        seen.add((id(node), below_own))
-        kind = _node_kind(node)
-        if kind == "native" and below_own and type(node).__name__ != "AccumulateGrad":
-            return False
-        for child, _ in node.next_functions:
-            stack.append((child, below_own or kind == "own"))
-    return True
-
-
 # Called with a parameter right after the kernels that ADD its gradient into the flat buffer were enqueued (direct mode only):
 # lets the trainer start the all-reduce of a gradient bucket while the rest of backward is still running (train_step.py)
 _grad_ready_cb = None
@@ -246,7 +174,6 @@ def conv_out_size(h, k, stride, pad, dil):
 # --------------------------------------------------------------------------
 # convolution
 # --------------------------------------------------------------------------
-@register_own_node
 class _Conv2d(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, dil, stat_groups, tap):
@@ -284,7 +211,6 @@ class _Conv2d(torch.autograd.Function):
         return y
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dy, dtap=None):
         x, weight = ctx.saved_tensors
         stride, pad, dil, has_bias, flops = ctx.cfg
@@ -302,11 +228,6 @@ class _Conv2d(torch.autograd.Function):
             dyp = torch.zeros((n, ho, wo, cout_pad), dtype=dt, device=dy.device)
             call("css_copy_channels", dy, cout, dyp, cout_pad, n * ho * wo, cout, dc, dc, dev, st)
         dx = dw = db = None
-        part = partition.active()
-        ev_dy = None
-        if part is not None and ctx.needs_input_grad[1]:
-            ev_dy = part.event()             # the incoming gradient is complete HERE on the main stream: the side stream's weight gradient
-            ev_dy.record(part.main)          # waits for this, not for the data gradient queued below
         if ctx.needs_input_grad[0]:
             wt = prepared_weight(weight, dt, cp, True)
             dx = torch.empty_like(x)
@@ -331,21 +252,8 @@ class _Conv2d(torch.autograd.Function):
             # workspace for the per-slice partial tiles (plain stores + ordered reduction instead of fp32 atomics); 0 bytes: the
             # shape takes a kernel without that path
             wsb = _lib.query("css_conv2d_wgrad_ws_bytes", n * ho * wo, r * s * cp, cout_pad, dc, dev)
-            part = part if sink is not None else None
-            if part is not None:
-                # partitioned backward: the weight gradient goes to the SIDE stream (its own CUs) behind the data gradient's operands; nothing
-                # of backward reads it, the window's end joins it before the optimizer.  x / dyp stay referenced until the side stream is past them.
-                part.side.wait_event(ev_dy)
-                with torch.cuda.stream(part.side):
-                    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
-                    call("css_conv2d_wgrad", x, dyp, sink, ws, wsb, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
-                         dc, dev, part.side.cuda_stream)
-                part.hold(x, dyp)
-                _grad_ready(weight)
-            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if (wsb and part is None) else None
-            if part is not None:
-                pass
-            elif sink is not None:      # the wgrad kernels ADD into dw: straight into param.grad
+            ws = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
+            if sink is not None:      # the wgrad kernels ADD into dw: straight into param.grad
                 call("css_conv2d_wgrad", x, dyp, sink, ws, wsb, n, h, w_, cp, cp, ho, wo, cout, cout, r, s, stride, pad, dil, flops,
                      dc, dev, st)
                 _grad_ready(weight)
@@ -490,7 +398,6 @@ def _sync_finalize(stats, g, c, gamma, beta, running_mean, running_var, momentum
     return count_t
 
 
-@register_own_node
 class _BNAct(torch.autograd.Function):
     """Batch norm (+ residual, + ReLU).  ``groups`` = number of forward passes batched into ``y`` along dim 0: every group
     of rows gets its own batch statistics and one running-statistics update (see include/css_hip.h, batch-norm block)."""
@@ -563,7 +470,6 @@ class _BNAct(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, da):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
@@ -660,7 +566,6 @@ def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, train
 # --------------------------------------------------------------------------
 # pooling / resize / concat
 # --------------------------------------------------------------------------
-@register_own_node
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, ks, stride, pad, ceil_mode):
@@ -683,7 +588,6 @@ class _MaxPool(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         (arg,) = ctx.saved_tensors
         (n, h, w, c), ks, stride, pad = ctx.cfg
@@ -699,7 +603,6 @@ def maxpool(x, ks=3, stride=2, pad=1, ceil_mode=False):
     return _MaxPool.apply(x, ks, stride, pad, ceil_mode)
 
 
-@register_own_node
 class _Bilinear(torch.autograd.Function):
     """F.interpolate(mode='bilinear', align_corners=True) on NHWC tensors; output dtype selectable."""
 
@@ -719,7 +622,6 @@ class _Bilinear(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         (n, hs, ws, c), in_dtype = ctx.cfg
         ldo = _row_stride(dout)       # a channel slice of a concat gradient is read in place
@@ -736,7 +638,6 @@ def bilinear(x, hd, wd, out_dtype=None, out_into=None):
     return _Bilinear.apply(x, hd, wd, out_dtype or x.dtype, out_into)
 
 
-@register_own_node
 class _GlobalAvgPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
@@ -748,7 +649,6 @@ class _GlobalAvgPool(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         n, h, w, c = ctx.cfg
         dout = dout.contiguous()
@@ -762,7 +662,6 @@ def global_avg_pool(x):
     return _GlobalAvgPool.apply(x)
 
 
-@register_own_node
 class _Broadcast(torch.autograd.Function):
     """[N,1,1,C] -> [N,H,W,C] (bilinear resize of a 1x1 map, aspp.py:38)."""
 
@@ -779,7 +678,6 @@ class _Broadcast(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         n, h, w, c = dout.shape
@@ -793,7 +691,6 @@ def broadcast_hw(x, h, w, out_into=None):
     return _Broadcast.apply(x, h, w, out_into)
 
 
-@register_own_node
 class _CatFromViews(torch.autograd.Function):
     """The concatenation whose pieces were WRITTEN IN PLACE into ``buf`` by their producers (``out_into=(buf, offset)`` of
     bn_act / broadcast_hw): forward is free, backward hands every producer its channel slice of the gradient as a view."""
@@ -809,7 +706,6 @@ class _CatFromViews(torch.autograd.Function):
         return buf.view(buf.shape)
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         outs, off = [None], 0
@@ -823,7 +719,6 @@ def cat_from_views(buf, *views):
     return _CatFromViews.apply(buf, *views)
 
 
-@register_own_node
 class _CatChannels(torch.autograd.Function):
     @staticmethod
     def forward(ctx, *xs):
@@ -842,7 +737,6 @@ class _CatChannels(torch.autograd.Function):
         return out
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, dout):
         dout = dout.contiguous()
         n, h, w, ct = dout.shape
@@ -865,7 +759,6 @@ def cat_channels(*xs):
     return _CatChannels.apply(*xs)
 
 
-@register_own_node
 class _Split2(torch.autograd.Function):
     """(x[:b], x[b:]) along dim 0 with a single-copy backward (autograd's own slicing would zero-fill two full tensors)."""
 
@@ -875,7 +768,6 @@ class _Split2(torch.autograd.Function):
         return x.narrow(0, 0, b), x.narrow(0, b, x.shape[0] - b)
 
     @staticmethod
-    @on_backward_stream
     def backward(ctx, g0, g1):
         out = torch.empty(ctx.shape, dtype=ctx.dt, device=(g0 if g0 is not None else g1).device)
         for g, sl in ((g0, out.narrow(0, 0, ctx.b)), (g1, out.narrow(0, ctx.b, ctx.shape[0] - ctx.b))):

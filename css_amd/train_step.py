@@ -27,7 +27,7 @@ import torch
 import torch.distributed as dist
 
 from . import functional as Fn
-from . import ops, partition, peer
+from . import ops, peer
 from ._lib import call, dev_stream, dtype_code
 from .loss.loss import Attention_Threshold_Loss, Contrast_Loss, CrossEntropyLoss, ProbOhemCrossEntropy2d, fused_upsample_ok
 from .scheduler.my_lr_scheduler import poly_lr
@@ -132,15 +132,8 @@ class MixTrainer:
         overlap = sync and self.bucket_mb > 0
         self._skip_flag = None
         if not overlap:
-            # one rank: backward on a partitioned chip when CSS_BWD_PARTITION asks for it (css_amd/partition.py) - batch norm + data gradients
-            # on the main partition's CUs, the weight gradients on the others, joined before the optimizer
-            part = partition.get(self.flat_p.device) if (not sync and self.flat_p.is_cuda) else None
             with ops.direct_param_grads():       # parameter gradients are added in place into the flat buffer by the kernels
-                if part is not None:
-                    with part.window(total):
-                        total.backward()
-                else:
-                    total.backward()
+                total.backward()
             ops.assert_no_lazy_res_grads()
             if sync:
                 dist.all_reduce(self.flat_g)     # one bucket, after backward

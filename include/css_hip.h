@@ -27,14 +27,6 @@ typedef void* css_stream_t; /* hipStream_t */
 
 CSS_API int css_abi_version(void);
 CSS_API int css_device_cu_count(int device);
-/* CU partitions (round 5).  css_stream_create_masked: a HIP stream whose kernels may only run on CUs [first_cu, first_cu + n_cus)
- * of the device's CU-mask bit order (hipExtStreamCreateWithCUMask; bit b belongs to XCD b % 8, so a range that starts and ends on a multiple of 8
- * takes the same number of CUs from every XCD and the kernels' XCD-aware workgroup maps keep working inside it).  The library remembers n_cus for
- * the stream: every persistent kernel launched on it sizes its grid with css_stream_cu_count (one workgroup per CU of the PARTITION).  Results do
- * not depend on the partition (same tiles, same order of every sum; the weight-gradient slice plan is made for the whole device).  The stream
- * lives as long as the process (the one documented resource the library creates besides css_peer_alloc's buffer). */
-CSS_API int css_stream_create_masked(int device, int first_cu, int n_cus, css_stream_t* out);
-CSS_API int css_stream_cu_count(int device, css_stream_t stream);
 
 /* ---- per-kernel timing with HIP events on the launch stream (bench.py roofline leg) ----------------
  * Every kernel launch of a bracketed call gets its own event pair.  kind: 0 = conv forward, 1 = conv dgrad, 2 = conv wgrad
