@@ -448,6 +448,25 @@ int css_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int 
   set_dev(device);
   return css_launch_colsum(x, ld, M, C, out, ws, dtype, S(stream));
 }
+int css_stem_s2d_enabled(void) { return css_stem_s2d_enabled_(); }
+int css_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_nchw_to_s2d(x, out, N, C, H, W, S(stream));
+}
+int css_stem_s2d_weights(const float* w, void* out, int Cout, int R, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_stem_s2d_weights(w, out, Cout, R, S(stream));
+}
+int css_stem_s2d_fold_wgrad(const float* dw2, float* dw, int Cout, int R, int device, css_stream_t stream) {
+  set_dev(device);
+  return css_launch_stem_s2d_fold_wgrad(dw2, dw, Cout, R, S(stream));
+}
+int css_conv2d_stem_s2d_forward(const void* x_s2d, const void* w2, void* y, float* stats, int Mg, int N, int Hs, int Ws, int Cout, int R,
+                                double alg_flops, int device, css_stream_t stream) {
+  set_dev(device);
+  ProfScope ps(0, alg_flops, S(stream));
+  return css_launch_conv_stem_s2d(x_s2d, w2, y, stats, Mg, N, Hs, Ws, Cout, R, cu_count(device), S(stream));
+}
 int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_nchw_to_nhwc(x, out, N, C, HW, Cpad, dtype, S(stream));

@@ -69,6 +69,14 @@ void css_conv_ws_set_enabled(int on);
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out);
 size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu);
 
+// conv_stem.hip: the stride-2 stem convolutions on the space-to-depth image (round 5)
+int css_stem_s2d_enabled_();
+int css_launch_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, hipStream_t st);
+int css_launch_stem_s2d_weights(const float* w, void* out, int Cout, int R, hipStream_t st);
+int css_launch_stem_s2d_fold_wgrad(const float* dw2, float* dw, int Cout, int R, hipStream_t st);
+int css_launch_conv_stem_s2d(const void* x, const void* w2, void* y, float* stats, int Mg, int N, int Hs, int Ws, int Cout, int R, int n_cu,
+                             hipStream_t st);
+
 int css_bn_nrb_(int Mg, int G, int C, int dtype);
 int css_launch_bn_stats(const void* y, int Mg, int G, int C, int ld, double* partial, int dtype, hipStream_t st);
 int css_launch_bn_reduce(const double* partial, int nrb, int C, int G, double* sums, float* g1, float* g0, int accumulate, double count_local,

@@ -124,12 +124,12 @@ class _StudentTeacher(nn.Module):
     def _teacher_pair(self, xl, xu):
         self._check_pair(xl, xu)
         with ops.bn_groups(2):
-            pred, rep = self.ema_model.forward_nhwc(ops.stage_inputs([xl, xu], self.ema_model.compute_dtype))
+            pred, rep = self.ema_model.forward_nhwc(self.ema_model.stage([xl, xu]))
         b = xl.shape[0]
         return pred[b:], rep[b:]            # the labeled half only moves the teacher's BN running statistics (ddp_model.py:102)
 
     def _teacher(self, x):
-        return self.ema_model.forward_nhwc(ops.stage_input(x, self.ema_model.compute_dtype))
+        return self.ema_model.forward_nhwc(self.ema_model.stage([x]))
 
     def _student_pair(self, xl, xu, out_hw, small=False):
         """-> pred [2B,h,w,K], rep_all [2B,h,w,C] (labeled first), pred_l_large, pred_u_large (logical NCHW, fp32).
@@ -137,7 +137,7 @@ class _StudentTeacher(nn.Module):
         up-sample on the fly (loss._PixelCESmall) and the full-resolution logits are never materialised."""
         self._check_pair(xl, xu)
         with ops.bn_groups(2):
-            pred, rep = self.model.forward_nhwc(ops.stage_inputs([xl, xu], self.model.compute_dtype))
+            pred, rep = self.model.forward_nhwc(self.model.stage([xl, xu]))
         if small:
             sl, su = ops.split2(pred, xl.shape[0])
             return pred, rep, sl, su

@@ -104,6 +104,12 @@ class DeepLabv3Plus_with_rep(nn.Module):
             return pred, self.representation(dec)
         return self.classifier(dec), self.representation(dec)
 
+    def stage(self, xs):
+        """[Bi,3,H,W] fp32 images -> the staged network input of ``forward_nhwc``: NHWC in the compute dtype, or - bf16 and a stride-2 stem
+        that conv_stem_s2d_kernel takes - the space-to-depth staging (ops.S2DInput)."""
+        first = self.resnet_conv1 if hasattr(self.resnet_conv1, "kernel_size") else self.resnet_conv1[0]
+        return ops.stage_inputs(list(xs), self.compute_dtype, s2d=ops.stem_s2d_ok(first, self.compute_dtype))
+
     def forward(self, x):
-        pred, rep = self.forward_nhwc(ops.stage_input(x, self.compute_dtype))
+        pred, rep = self.forward_nhwc(self.stage([x]))
         return pred.permute(0, 3, 1, 2), rep.permute(0, 3, 1, 2)

@@ -50,6 +50,9 @@ class HipConv2d(nn.Module):
         return c
 
     def forward(self, x, tap=False):   # x: NHWC internal tensor
+        if isinstance(x, ops.S2DInput):    # the network input staged space-to-depth: the stride-2 stem (csrc/conv_stem.hip)
+            assert not tap
+            return ops.conv2d_stem_s2d(x, self.weight, bn_stats=self.bias is None and self.training and self.fuse_bn_stats)
         # a bias-free convolution of this network always feeds a batch norm: let its epilogue produce the statistics
         return ops.conv2d(x, self.weight, self.bias, self.stride[0], self.padding[0], self.dilation[0],
                           bn_stats=self.bias is None and self.training and self.fuse_bn_stats, tap=tap)

@@ -275,6 +275,105 @@ class _Conv2d(torch.autograd.Function):
         return dx, dw, db, None, None, None, None, None
 
 
+# --------------------------------------------------------------------------
+# the stride-2 stem convolution on the space-to-depth image (csrc/conv_stem.hip)
+# --------------------------------------------------------------------------
+class S2DInput:
+    """The network input staged as [N, ceil(H/2), ceil(W/2), 16] bf16 (ops.stage_inputs(..., s2d=True)): 2 x 2 x 3 image values per pixel."""
+    __slots__ = ("t", "hw")
+
+    def __init__(self, t, hw):
+        self.t, self.hw = t, hw
+
+    @property
+    def shape(self):          # (what the callers of a staged tensor look at: the batch size)
+        return (self.t.shape[0], self.hw[0], self.hw[1], 3)
+
+
+def stem_s2d_ok(conv, dtype) -> bool:
+    """The first convolution of the backbone is one of the two stride-2 stems conv_stem_s2d_kernel takes (7x7 s2 p3 or 3x3 s2 p1, 3 -> 64, no bias),
+    the compute dtype is bf16 and CSS_NO_STEM_S2D is not set."""
+    if dtype != torch.bfloat16 or not _lib.available() or not _lib.query("css_stem_s2d_enabled"):
+        return False
+    k = getattr(conv, "kernel_size", None)
+    return (k in ((7, 7), (3, 3)) and getattr(conv, "stride", None) == (2, 2) and conv.padding == (k[0] // 2, k[0] // 2)
+            and conv.dilation == (1, 1) and conv.in_channels == 3 and conv.out_channels == 64 and conv.bias is None)
+
+
+def _stem_s2d_weight(weight: torch.Tensor) -> torch.Tensor:
+    """bf16 [64][TA][TA][16] copy of the fp32 master [64,3,R,R] (cached on the parameter like prepared_weight's layouts)."""
+    cache = weight.__dict__.setdefault("_css_wcache", {})
+    stamp = (weight.data_ptr(), weight._version, _epoch)
+    hit = cache.get("s2d")
+    if hit is not None and hit[0] == stamp:
+        return hit[1]
+    cout, _, r, _ = weight.shape
+    ta = (r + 1) // 2
+    w = _phys(weight)
+    dev, st = dev_stream(w)
+    out = torch.empty((cout, ta, ta, 16), dtype=torch.bfloat16, device=w.device)
+    call("css_stem_s2d_weights", w, out, cout, r, dev, st)
+    cache["s2d"] = (stamp, out)
+    return out
+
+
+class _StemS2D(torch.autograd.Function):
+    """y [N,Hs,Ws,64] = conv(image, weight [64,3,R,R], stride 2, pad R/2) from the space-to-depth image; the weight gradient is computed in
+    s2d space by the generic weight-gradient kernels (TA x TA taps, stride 1, 16 channels) and folded back.  The image needs no gradient."""
+
+    @staticmethod
+    def forward(ctx, xs, weight, stat_groups):
+        global _conv_stats_out
+        n, hs, ws, c16 = xs.shape
+        cout, cin, r, _ = weight.shape
+        assert c16 == 16 and xs.dtype == torch.bfloat16 and xs.is_contiguous() and cin == 3 and cout == 64
+        w2 = _stem_s2d_weight(weight)
+        y = torch.empty((n, hs, ws, cout), dtype=torch.bfloat16, device=xs.device)
+        dev, st = dev_stream(xs)
+        m = n * hs * ws
+        flops = 2.0 * m * cout * r * r * cin
+        _conv_stats_out = None
+        stats, mg = None, 0
+        if stat_groups and m % stat_groups == 0 and m // stat_groups >= 128:
+            mg = m // stat_groups
+            stats = torch.empty((2 * ((m + 255) // 256), 2, cout), dtype=torch.float32, device=xs.device)
+        call("css_conv2d_stem_s2d_forward", xs, w2, y, stats, mg, n, hs, ws, cout, r, flops, dev, st)
+        if stats is not None:
+            _conv_stats_out = (stats, mg, stat_groups, cout, 256)
+        ctx.save_for_backward(xs, weight)
+        ctx.flops = flops
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xs, weight = ctx.saved_tensors
+        if not ctx.needs_input_grad[1]:
+            return None, None, None
+        n, hs, ws, _ = xs.shape
+        cout, cin, r, _ = weight.shape
+        ta = (r + 1) // 2
+        dy = dy.contiguous()
+        dev, st = dev_stream(dy)
+        dc = dtype_code(torch.bfloat16)
+        dw2 = torch.zeros((cout, ta, ta, 16), dtype=torch.float32, device=dy.device)
+        wsb = _lib.query("css_conv2d_wgrad_ws_bytes", n * hs * ws, ta * ta * 16, cout, dc, dev)
+        wsp = torch.empty(wsb // 4, dtype=torch.float32, device=dy.device) if wsb else None
+        call("css_conv2d_wgrad", xs, dy, dw2, wsp, wsb, n, hs, ws, 16, 16, hs, ws, cout, cout, ta, ta, 1, ta // 2, 1, ctx.flops, dc, dev, st)
+        sink = _grad_sink(weight, (cout, r, r, cin))
+        if sink is not None:
+            call("css_stem_s2d_fold_wgrad", dw2, sink, cout, r, dev, st)
+            _grad_ready(weight)
+            return None, None, None
+        dwp = torch.zeros((cout, r, r, cin), dtype=torch.float32, device=dy.device)
+        call("css_stem_s2d_fold_wgrad", dw2, dwp, cout, r, dev, st)
+        return None, dwp.permute(0, 3, 1, 2), None
+
+
+def conv2d_stem_s2d(x: S2DInput, weight, bn_stats=False):
+    return _StemS2D.apply(x.t, weight, (_bn_groups if bn_stats else 0))
+
+
+
 _conv_stats_out = None
 
 # Residual gradients whose ReLU backward is still to be applied.  A tapped convolution (Bottleneck.conv1) and the batch norm that uses the
@@ -782,10 +881,22 @@ def split2(x, b):
     return _Split2.apply(x, b)
 
 
-def stage_inputs(xs, dtype: torch.dtype) -> torch.Tensor:
-    """Several [Bi,C,H,W] fp32 NCHW images -> ONE [sum Bi,H,W,Cpad] ``dtype`` tensor (each written into its slice)."""
+def stage_inputs(xs, dtype: torch.dtype, s2d: bool = False):
+    """Several [Bi,C,H,W] fp32 NCHW images -> ONE [sum Bi,H,W,Cpad] ``dtype`` tensor (each written into its slice); ``s2d``: the
+    space-to-depth staging of the stride-2 stems instead (S2DInput: [sum Bi, ceil(H/2), ceil(W/2), 16] bf16 - half the bytes)."""
     xs = [x.detach() if (x.dtype == torch.float32 and x.is_contiguous()) else x.detach().float().contiguous() for x in xs]
     _, c, h, w = xs[0].shape
+    if s2d:
+        assert dtype == torch.bfloat16 and c <= 3
+        hs, ws = (h + 1) // 2, (w + 1) // 2
+        bt = sum(x.shape[0] for x in xs)
+        out = torch.empty((bt, hs, ws, 16), dtype=dtype, device=xs[0].device)
+        dev, st = dev_stream(out)
+        off = 0
+        for x in xs:
+            call("css_nchw_to_s2d", x, out.data_ptr() + off * hs * ws * 16 * out.element_size(), x.shape[0], c, h, w, dev, st)
+            off += x.shape[0]
+        return S2DInput(out, (h, w))
     cp = pad_to(c, vec_of(dtype))
     bt = sum(x.shape[0] for x in xs)
     out = torch.empty((bt, h, w, cp), dtype=dtype, device=xs[0].device)

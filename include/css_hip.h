@@ -203,6 +203,22 @@ CSS_API int css_copy_channels(const void* src, int lds, void* dst, int ldd, long
  * ws (fp32, css_colsum_ws_bytes(M, C) bytes, caller-owned): one partial row per row block, then an ordered sum - no float atomics. */
 CSS_API size_t css_colsum_ws_bytes(long M, int C);
 CSS_API int css_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int dtype, int device, css_stream_t stream);
+/* ---- the stride-2 stem convolution on the SPACE-TO-DEPTH image (round 5; css_amd/csrc/conv_stem.hip).  Replaces, for bf16, the first convolution
+ * of the backbone: torchvision's conv1 = Conv2d(3, 64, 7, stride 2, padding 3) behind models.resnet101() (/root/reference/mix_label.py:68) and
+ * ResNet_Stem.conv1[0] = conv3x3(3, 64, stride 2) (/root/reference/generalframeworks/networks/resnet.py:177-190), R = 7 or 3.
+ * css_nchw_to_s2d: fp32 NCHW image [N][C <= 3][H][W] -> bf16 [N][Hs][Ws][16], Hs = ceil(H / 2), Ws = ceil(W / 2); channel (2 py + px) 3 + c of
+ * s2d pixel (ys, xs) = image(c, 2 ys + py, 2 xs + px), zero outside the image and in channels 12..15.
+ * css_stem_s2d_weights: fp32 master [64][R][R][3] -> bf16 [64][TA][TA][16], TA = (R + 1) / 2: w2[a][b][(2 py + px) 3 + c] = w[2 a + py - 1][2 b + px - 1][c].
+ * css_conv2d_stem_s2d_forward: y [N][Hs][Ws][64] bf16 = the R x R stride-2 pad R/2 convolution; stats (optional) = the batch-norm statistics slabs
+ * of css_conv2d_forward_bnstats (fp32 [2 ceil(M / 256)][2][64], tile rows 256), Mg rows per statistics group.
+ * css_stem_s2d_fold_wgrad: the weight gradient computed in s2d space (css_conv2d_wgrad on the s2d image: TA x TA taps, stride 1, pad TA / 2,
+ * 16 channels) dw2 fp32 [64][TA][TA][16] ADDED into dw fp32 [64][R][R][3].  css_stem_s2d_enabled: 0 under CSS_NO_STEM_S2D=1 (the gather kernels). */
+CSS_API int css_stem_s2d_enabled(void);
+CSS_API int css_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, int device, css_stream_t stream);
+CSS_API int css_stem_s2d_weights(const float* w, void* out, int Cout, int R, int device, css_stream_t stream);
+CSS_API int css_stem_s2d_fold_wgrad(const float* dw2, float* dw, int Cout, int R, int device, css_stream_t stream);
+CSS_API int css_conv2d_stem_s2d_forward(const void* x_s2d, const void* w2, void* y, float* stats, int Mg, int N, int Hs, int Ws, int Cout, int R,
+                                        double alg_flops, int device, css_stream_t stream);
 CSS_API int css_nchw_to_nhwc(const float* x, void* out, int N, int C, int HW, int Cpad, int dtype, int device, css_stream_t stream);
 CSS_API int css_cast(const void* x, void* out, long n, int dtype_in, int dtype_out, int device, css_stream_t stream);
 
