@@ -370,7 +370,10 @@ class _StemS2D(torch.autograd.Function):
 
 
 def conv2d_stem_s2d(x: S2DInput, weight, bn_stats=False):
-    return _StemS2D.apply(x.t, weight, (_bn_groups if bn_stats else 0))
+    y = _StemS2D.apply(x.t, weight, (_bn_groups if bn_stats else 0))
+    if _conv_stats_out is not None:
+        y._css_bnstats = _conv_stats_out          # (picked up by bn_act: the statistics came out of the convolution's epilogue)
+    return y
 
 
 

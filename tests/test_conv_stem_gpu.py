@@ -97,29 +97,40 @@ from css_amd.networks.deeplabv3.deeplabv3 import DeepLabv3Plus_with_rep
 torch.manual_seed(3)
 net = DeepLabv3Plus_with_rep(resnet.resnet101_tv() if sys.argv[2] == "tv" else resnet.resnet101(), dilate_scale=8, num_classes=21, output_dim=256)
 net = net.to("cuda:0").train().set_compute_dtype(torch.bfloat16)
-x = torch.randn(2, 3, 65, 65, generator=torch.Generator().manual_seed(5))
-staged = net.stage([x.to("cuda:0")])
+x = torch.randn(4, 3, 129, 129, generator=torch.Generator().manual_seed(5)).to("cuda:0")
+staged = net.stage([x])
 with torch.no_grad():
-    pred, rep = net(x.to("cuda:0"))
-json.dump(dict(kind=type(staged).__name__, pred=pred.float().cpu().flatten()[::7].tolist()), open(sys.argv[1], "w"))
+    with ops.bn_groups(2):
+        feat = net.resnet_maxpool(net.resnet_bn1(net.resnet_conv1(staged), relu=True))      # stem (+ its batch norms) + max pool
+        pred, rep = net.forward_nhwc(net.stage([x]))
+    net.set_compute_dtype(torch.float32)
+    with ops.bn_groups(2):
+        pred32, _ = net.forward_nhwc(net.stage([x]))
+json.dump(dict(kind=type(staged).__name__, feat=feat.float().cpu().flatten()[::11].tolist(), pred=pred.float().cpu().flatten()[::3].tolist(),
+               pred32=pred32.float().cpu().flatten()[::3].tolist()), open(sys.argv[1], "w"))
 '''
 
 
 @pytest.mark.parametrize("backbone", ["tv", "stem"])
 def test_network_takes_the_s2d_stem_and_agrees_with_the_gather_kernels(tmp_path, backbone):
-    """bf16 network forward with the s2d stem (default) and with CSS_NO_STEM_S2D=1 (the gather kernels), same seeds: the staging differs
-    (S2DInput vs NHWC-8 tensor), the logits agree to bf16 noise through ~110 batch-norm layers."""
+    """bf16 network with the s2d stem (default) and with CSS_NO_STEM_S2D=1 (the gather kernels), same seeds, two statistics groups: the staging
+    differs (S2DInput vs NHWC-8 tensor); the stem's output after its batch norm(s) and the max pool agrees to bf16 rounding (the epilogue's
+    statistics slabs feed the batch norm on both paths); the logits of both paths sit equally close to the fp32 network's."""
     import json
     res = {}
     for tag, env in (("s2d", {}), ("gather", {"CSS_NO_STEM_S2D": "1"})):
         out = str(tmp_path / f"{tag}.json")
         e = dict(os.environ, **env)
-        e.pop("CSS_NO_STEM_S2D", None) if tag == "s2d" else None
+        if tag == "s2d":
+            e.pop("CSS_NO_STEM_S2D", None)
         p = subprocess.Popen([sys.executable, "-c", WORKER % ROOT, out, backbone], env=e)
         assert p.wait(timeout=600) == 0
         res[tag] = json.load(open(out))
     assert res["s2d"]["kind"] == "S2DInput" and res["gather"]["kind"] == "Tensor"
-    a, b = torch.tensor(res["s2d"]["pred"]), torch.tensor(res["gather"]["pred"])
-    cos = torch.nn.functional.cosine_similarity(a, b, dim=0).item()
-    print(f"{backbone}: logits cosine s2d stem vs gather stem: {cos:.5f}")
-    assert cos > 0.99
+    cosf = lambda u, v: torch.nn.functional.cosine_similarity(torch.tensor(u), torch.tensor(v), dim=0).item()
+    c_feat = cosf(res["s2d"]["feat"], res["gather"]["feat"])
+    c_pred = cosf(res["s2d"]["pred"], res["gather"]["pred"])
+    c32 = {t: cosf(res[t]["pred"], res[t]["pred32"]) for t in res}
+    print(f"{backbone}: stem features cosine s2d vs gather {c_feat:.6f}; logits cosine s2d vs gather {c_pred:.5f}; vs the fp32 network: {c32}")
+    assert c_feat > 0.9995
+    assert abs(c32["s2d"] - c32["gather"]) < 0.03 and c32["s2d"] > 0.9, c32
