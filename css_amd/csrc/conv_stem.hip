@@ -323,7 +323,10 @@ __global__ __launch_bounds__(256) void stem_s2d_fold_wgrad_kernel(const float* _
 
 static int g_stem_off = -1;      // -1: read CSS_NO_STEM_S2D on first use
 int css_stem_s2d_enabled_() {
-  if (g_stem_off < 0) g_stem_off = getenv("CSS_NO_STEM_S2D") != nullptr;
+  if (g_stem_off < 0) {
+    const char* e = getenv("CSS_NO_STEM_S2D");
+    g_stem_off = (e && e[0] && e[0] != '0') ? 1 : 0;        // (CSS_NO_STEM_S2D=0 means "not switched off": scripts/ab_env.sh passes 0 / 1)
+  }
   return g_stem_off ? 0 : 1;
 }
 int css_launch_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, hipStream_t st) {
