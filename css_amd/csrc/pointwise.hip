@@ -6,6 +6,7 @@
 //   (mix_label.py:96-97,194-195; ddp_model.py:93-97).
 #include "common.h"
 #include <type_traits>
+#include <cstdlib>
 
 static inline int ew_grid(size_t total) {
   size_t b = (total + 255) / 256;
@@ -614,6 +615,62 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ ema, const
     else return CSS_ERR_DTYPE;                   \
   } while (0)
 
+// The network's only pooling (3x3, stride 2, pad 1: resnet.py:190 / torchvision's maxpool) without the generic kernel's data-dependent loop: an input
+// row is in the windows of output row (hi + 1) / 2 (tap 0 if hi is odd, tap 1 if even) and, for odd hi, of (hi - 1) / 2 (tap 2); the same for columns -
+// at most 2 x 2 windows.  All four (gradient vector, arg-max bytes) pairs are requested up front (predicated, clamped addresses), then summed in the
+// generic kernel's order (r ascending, s ascending: bit-identical results).  r05: 250 -> see DESIGN.md 3e (the generic form ran at 1.35 TB/s: a chain of
+// dependent loads behind divergent branches, two integer divisions per tap).
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_k3s2_kernel(const T* __restrict__ dout, const uint8_t* __restrict__ arg, T* __restrict__ dx, int N, int H,
+                                                               int W, int C, int Ho, int Wo) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)N * H * W * CV;
+  GRID_STRIDE(idx, total) {
+    const int cv = (int)(idx % CV);
+    size_t p = idx / CV;
+    const int wi = (int)(p % W);
+    p /= W;
+    const int hi = (int)(p % H), n = (int)(p / H);
+    // candidate (output index, tap) pairs per axis, ascending tap: a = ((x + 1) >> 1, tap (x & 1) ? 0 : 1), b = ((x - 1) >> 1, tap 2) for odd x only
+    const int ho_[2] = {(hi + 1) >> 1, (hi - 1) >> 1}, wo_[2] = {(wi + 1) >> 1, (wi - 1) >> 1};
+    const int tr[2] = {(hi & 1) ? 0 : 1, 2}, ts[2] = {(wi & 1) ? 0 : 1, 2};
+    const bool okh[2] = {ho_[0] < Ho, (hi & 1) && ho_[1] >= 0 && ho_[1] < Ho}, okw[2] = {wo_[0] < Wo, (wi & 1) && wo_[1] >= 0 && wo_[1] < Wo};
+    Vec16<T> g[2][2];
+    typedef typename std::conditional<VEC == 8, uint2, uint32_t>::type argw_t;
+    union AB { uint8_t b[VEC]; argw_t w; } ab[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const bool ok = okh[i] && okw[j];
+        const size_t ob = ok ? ((size_t)(n * Ho + ho_[i]) * Wo + wo_[j]) * C + cv * VEC : (size_t)cv * VEC;      // (clamped: always a valid address)
+        g[i][j].load(dout + ob);
+        ab[i][j].w = *reinterpret_cast<const argw_t*>(arg + ob);
+        if (!ok) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) ab[i][j].b[e] = 0xFF;
+        }
+      }
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const uint8_t want = (uint8_t)(tr[i] * 3 + ts[j]);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (ab[i][j].b[e] == want) acc[e] += g[i][j].f(e);
+      }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, acc[e]);
+    o.store(dx + idx * VEC);
+  }
+}
+
 int css_launch_maxpool_fwd(const void* x, void* out, uint8_t* arg, int N, int H, int W, int C, int Ho, int Wo, int ks, int stride,
                            int pad, int dtype, hipStream_t st) {
   DISPATCH_T(dtype, {
@@ -630,8 +687,13 @@ int css_launch_maxpool_bwd(const void* dout, const uint8_t* arg, void* dx, int N
   DISPATCH_T(dtype, {
     constexpr int VEC = 16 / sizeof(T);
     if (C % VEC) return CSS_ERR_ARG;
-    hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / VEC))), dim3(256), 0, st, (const T*)dout, arg,
-                       (T*)dx, N, H, W, C, Ho, Wo, ks, stride, pad);
+    static const bool generic = getenv("CSS_MAXPOOL_BWD_GENERIC") != nullptr;
+    if (ks == 3 && stride == 2 && pad == 1 && !generic)
+      hipLaunchKernelGGL(maxpool_bwd_k3s2_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / VEC))), dim3(256), 0, st, (const T*)dout, arg, (T*)dx, N, H, W,
+                         C, Ho, Wo);
+    else
+      hipLaunchKernelGGL(maxpool_bwd_kernel<T>, dim3(ew_grid((size_t)N * H * W * (C / VEC))), dim3(256), 0, st, (const T*)dout, arg,
+                         (T*)dx, N, H, W, C, Ho, Wo, ks, stride, pad);
   });
   CSS_CHECK_LAUNCH();
   return CSS_OK;
