@@ -383,6 +383,13 @@ int css_bn_apply_mask(const void* y, int ldy, const void* res, int ldr, void* ou
   ProfScope ps(8, (double)M * C * (dtype == CSS_BF16 ? 2 : 4) * (2 + (res ? 1 : 0)) + (mask ? (double)M * C / 8 : 0), S(stream));
   return css_launch_bn_apply(y, ldy, res, ldr, out, ldo, scale, shift, M, C, relu, Mg, mask, dtype, S(stream));
 }
+int css_bn_apply_maxpool(const void* y, void* out, uint8_t* argmax, const float* scale, const float* shift, int N, int H, int W, int C, int Ho, int Wo,
+                         int G, int relu, int dtype, int device, css_stream_t stream) {
+  set_dev(device);
+  const double e = dtype == CSS_BF16 ? 2 : 4;
+  ProfScope ps(8, (double)N * H * W * C * e + (double)N * Ho * Wo * C * (e + (argmax ? 1 : 0)), S(stream));
+  return css_launch_bn_apply_pool(y, out, argmax, scale, shift, N, H, W, C, Ho, Wo, G, relu, dtype, S(stream));
+}
 int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
                       const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, int dtype, int device,
                       css_stream_t stream) {

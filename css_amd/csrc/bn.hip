@@ -9,6 +9,7 @@
 //   bn_bwd_reduce sum(dz), sum(dz*xhat) with dz = da * (a > 0)
 //   bn_bwd_apply  dy = scale*(dz - mean(dz) - xhat*mean(dz*xhat)), optional residual grad
 #include "common.h"
+#include <type_traits>
 #include <cstdlib>
 
 // generic two-value per-channel reduction over rows ------------------------------------
@@ -657,6 +658,82 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
     else CSS_BN_APPLY_LAUNCH(false, false, false);
   }
 #undef CSS_BN_APPLY_LAUNCH
+  CSS_CHECK_LAUNCH();
+  return CSS_OK;
+}
+// bn_apply + ReLU + the 3x3 stride-2 pad-1 max pool that follows the stem's batch norm (resnet.py:186-190; torchvision's bn1 / relu / maxpool) in ONE pass:
+// the normalised activation is read by nothing but the pool, so it is never written (round 5: -540 MB per forward pass at c2).  Thread = one pooled
+// 16-byte vector; every tap is normalised in fp32, ROUNDED to T (what bn_apply would have stored), and compared exactly like maxpool_fwd_kernel (first
+// maximum in (r, s) order wins, NaN propagates): pooled values and arg-max bytes are bit-identical to bn_apply followed by maxpool_fwd.
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const T* __restrict__ y, T* __restrict__ out, uint8_t* __restrict__ arg,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift, int N, int H, int W, int C,
+                                                            int Ho, int Wo, int imgs_per_group, int relu) {
+  constexpr int VEC = 16 / sizeof(T);
+  const int CV = C / VEC;
+  const size_t total = (size_t)N * Ho * Wo * CV;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+    const int cv = (int)(idx % CV);
+    size_t p = idx / CV;
+    const int wo = (int)(p % Wo);
+    p /= Wo;
+    const int ho = (int)(p % Ho), n = (int)(p / Ho);
+    const int g = n / imgs_per_group, c = cv * VEC;
+    float sc[VEC], sh[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { sc[e] = scale[g * C + c + e]; sh[e] = shift[g * C + c + e]; }
+    Vec16<T> v[9];
+    bool ok[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s_ = 0; s_ < 3; ++s_) {
+        const int hi = ho * 2 - 1 + r, wi = wo * 2 - 1 + s_;
+        ok[r * 3 + s_] = (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W;
+        const size_t off = ok[r * 3 + s_] ? ((size_t)(n * H + hi) * W + wi) * C + c : (size_t)c;      // (clamped: all nine requests go out up front)
+        v[r * 3 + s_].load(y + off);
+      }
+    float best[VEC];
+    uint8_t bi[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { best[e] = -INFINITY; bi[e] = 0; }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      if (!ok[t]) continue;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        float f = v[t].f(e) * sc[e] + sh[e];                 // (the same expression as bn_apply_kernel: contracted to one fma there and here)
+        if (relu) f = fmaxf(f, 0.f);
+        f = ElemT<T>::to_f(ElemT<T>::from_f(f));             // the value bn_apply would have stored
+        if (f > best[e] || f != f) { best[e] = f; bi[e] = (uint8_t)t; }
+      }
+    }
+    Vec16<T> o;
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) o.set(e, best[e]);
+    const size_t ob = ((size_t)(n * Ho + ho) * Wo + wo) * C + c;
+    o.store(out + ob);
+    if (arg) {
+      union { uint8_t b[VEC]; typename std::conditional<VEC == 8, uint2, uint32_t>::type w; } pk;
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) pk.b[e] = bi[e];
+      *reinterpret_cast<decltype(pk.w)*>(arg + ob) = pk.w;
+    }
+  }
+}
+int css_launch_bn_apply_pool(const void* y, void* out, uint8_t* arg, const float* scale, const float* shift, int N, int H, int W, int C, int Ho, int Wo,
+                             int G, int relu, int dtype, hipStream_t st) {
+  if (N <= 0 || G <= 0 || N % G || H < 1 || W < 1 || Ho < 1 || Wo < 1 || (Ho - 1) * 2 - 1 >= H || (Wo - 1) * 2 - 1 >= W) return CSS_ERR_ARG;
+  if (dtype != CSS_BF16 && dtype != CSS_F32) return CSS_ERR_DTYPE;
+  const int vec = dtype == CSS_BF16 ? 8 : 4;
+  if (C % vec || (reinterpret_cast<uintptr_t>(y) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return CSS_ERR_ARG;
+  const size_t total = (size_t)N * Ho * Wo * (C / vec);
+  const size_t nb = (total + 255) / 256;
+  const dim3 g((unsigned)(nb < 1 ? 1 : (nb > 65536 ? 65536 : nb)));
+  if (dtype == CSS_BF16)
+    hipLaunchKernelGGL(bn_apply_pool_kernel<bf16_t>, g, dim3(256), 0, st, (const bf16_t*)y, (bf16_t*)out, arg, scale, shift, N, H, W, C, Ho, Wo, N / G, relu);
+  else
+    hipLaunchKernelGGL(bn_apply_pool_kernel<float>, g, dim3(256), 0, st, (const float*)y, (float*)out, arg, scale, shift, N, H, W, C, Ho, Wo, N / G, relu);
   CSS_CHECK_LAUNCH();
   return CSS_OK;
 }

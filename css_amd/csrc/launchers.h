@@ -94,6 +94,8 @@ int css_launch_bn_eval_coeff(const float* gamma, const float* beta, const float*
                              hipStream_t st);
 int css_launch_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
                         int relu, int Mg, unsigned char* mask, int dtype, hipStream_t st);
+int css_launch_bn_apply_pool(const void* y, void* out, uint8_t* arg, const float* scale, const float* shift, int N, int H, int W, int C, int Ho, int Wo,
+                             int G, int relu, int dtype, hipStream_t st);
 int css_launch_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,
                              const float* scale, const float* shift, int Mg, int G, int C, int relu, double* partial, const unsigned char* mask,
                              int dtype, hipStream_t st);

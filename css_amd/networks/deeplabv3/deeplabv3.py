@@ -80,8 +80,7 @@ class DeepLabv3Plus_with_rep(nn.Module):
 
     def forward_nhwc(self, x):
         """x: staged NHWC tensor -> (prediction, representation) NHWC."""
-        x = self.resnet_bn1(self.resnet_conv1(x), relu=True)
-        x = self.resnet_maxpool(x)
+        x = self.resnet_bn1(self.resnet_conv1(x), relu=True, pool=self.resnet_maxpool)      # (bn + ReLU + max pool in one pass)
         x_low = self.resnet_layer1(x)
         fuse = torch.is_grad_enabled() and x_low.requires_grad    # fold fan-out gradient sums into dgrad store passes (ops.conv2d taps)
         # decoder input = [project(x_low) | up-sampled ASPP feature]: both producers write into one buffer (no concat copy)

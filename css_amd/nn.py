@@ -84,11 +84,20 @@ class HipBatchNorm2d(nn.Module):
             b.num_batches_tracked.copy_(m.num_batches_tracked)
         return b
 
-    def forward(self, x, res=None, relu=False, out_into=None):
+    def forward(self, x, res=None, relu=False, out_into=None, pool=None):
+        """``pool``: a HipMaxPool2d(3, 2, 1) that follows this layer (the stem): applied inside the batch norm's apply pass
+        (ops.bn_act(pool=...): the normalised activation is never written); any other pool configuration runs as a pass of its own."""
         if self.training:
             ops.count_bn_batch(self.num_batches_tracked)
+        if pool is not None and not (ops.fused_stem_pool() and pool.kernel_size == 3 and pool.stride == 2 and pool.padding == 1 and res is None
+                                     and out_into is None):
+            return pool(ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, self.training, self.momentum, self.eps,
+                                   self.sync, out_into=out_into))
+        po = None
+        if pool is not None:
+            po = (ops.pool_out_size(x.shape[1], 3, 2, 1, pool.ceil_mode), ops.pool_out_size(x.shape[2], 3, 2, 1, pool.ceil_mode))
         return ops.bn_act(x, self.weight, self.bias, self.running_mean, self.running_var, res, relu, self.training,
-                          self.momentum, self.eps, self.sync, out_into=out_into)
+                          self.momentum, self.eps, self.sync, out_into=out_into, pool=po)
 
     def extra_repr(self):
         return f"{self.num_features}, eps={self.eps}, momentum={self.momentum}"

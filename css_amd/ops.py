@@ -506,7 +506,7 @@ class _BNAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync, groups, fused=None, out_into=None,
-                tap_link=None):
+                tap_link=None, pool=None):
         c = y.shape[-1]
         m = y.numel() // c
         dt = y.dtype
@@ -546,7 +546,17 @@ class _BNAct(torch.autograd.Function):
                      float(eps), mean, invstd, scale, shift, c, dev, st)
         else:
             call("css_bn_eval_coeff", gamma, beta, running_mean, running_var, float(eps), scale, shift, c, dev, st)
-        if out_into is not None:      # write straight into a channel slice of a concat buffer (cat_from_views): no copy later
+        arg = None
+        if pool is not None:
+            # the stem's batch norm + ReLU + 3x3 s2 p1 max pool in one pass (css_bn_apply_maxpool): the normalised activation is never written
+            assert res is None and out_into is None and y.dim() == 4
+            n_, h_, w_, _ = y.shape
+            ho_, wo_ = pool
+            out = torch.empty((n_, ho_, wo_, c), dtype=dt, device=y.device)
+            if training and any(ctx.needs_input_grad):
+                arg = torch.empty((n_, ho_, wo_, c), dtype=torch.uint8, device=y.device)
+            call("css_bn_apply_maxpool", y, out, arg, scale, shift, n_, h_, w_, c, ho_, wo_, g, int(relu), dc, dev, st)
+        elif out_into is not None:      # write straight into a channel slice of a concat buffer (cat_from_views): no copy later
             buf, off = out_into
             out, ldo = buf[..., off:off + c], buf.shape[-1]
             assert buf.is_contiguous() and buf.dtype == dt and buf.shape[:-1] == y.shape[:-1]
@@ -564,7 +574,7 @@ class _BNAct(torch.autograd.Function):
             # ReLU mask in backward: the bit mask (or `out`, CSS_BN_NO_MASK=1) when a residual was added, else recomputed from
             # y*scale+shift (no extra read at all)
             assert out_into is None or not (relu and res is not None)
-            ctx.save_for_backward(y, out if (relu and res is not None and mask is None) else None, mean, invstd, gamma, scale, shift, count_t, mask)
+            ctx.save_for_backward(y, out if (relu and res is not None and mask is None) else None, mean, invstd, gamma, scale, shift, count_t, mask, arg)
         ctx.beta_ref = beta
         ctx.cfg = (relu, training, count, sync, res is not None, g)
         # the residual came out of a tapped convolution: its backward applies this layer's ReLU mask to the gradient itself
@@ -576,8 +586,14 @@ class _BNAct(torch.autograd.Function):
         relu, training, count, sync, has_res, g = ctx.cfg
         if not training:
             raise _lib.CssHipError("backward through eval-mode batch norm is not part of the CSS hot path")
-        y, a, mean, invstd, gamma, scale, shift, count_t, mask = ctx.saved_tensors
+        y, a, mean, invstd, gamma, scale, shift, count_t, mask, arg = ctx.saved_tensors
         c = y.shape[-1]
+        if arg is not None:      # fused max pool: its adjoint first (the gradient of the pooled tensor -> the gradient of the normalised activation)
+            n_, h_, w_, _ = y.shape
+            dpool = da.contiguous()
+            da = torch.empty_like(y)
+            dev_, st_ = dev_stream(dpool)
+            call("css_maxpool_bwd", dpool, arg, da, n_, h_, w_, c, dpool.shape[1], dpool.shape[2], 3, 2, 1, dtype_code(y.dtype), dev_, st_)
         m = y.numel() // c
         mg = m // g
         dt = y.dtype
@@ -622,7 +638,7 @@ class _BNAct(torch.autograd.Function):
         else:
             call("css_bn_bwd_apply", da, ldda, a, c, y, c, dy, c, dres, c, mean, invstd, gamma, sums, scale, shift, count, count_t, m, c,
                  int(relu), mg, dc, dev, st)
-        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None, None, None
 
 
 _bn_groups = 1
@@ -659,10 +675,24 @@ def count_bn_batch(counter):
 
 
 def bn_act(y, gamma, beta, running_mean, running_var, res=None, relu=True, training=True, momentum=0.1, eps=BN_EPS, sync=True,
-           groups=None, out_into=None):
+           groups=None, out_into=None, pool=None):
+    """``pool = (Ho, Wo)``: the 3x3 stride-2 pad-1 max pool that follows the stem's batch norm, fused into the apply pass."""
     return _BNAct.apply(y, gamma, beta, running_mean, running_var, res, relu, training, momentum, eps, sync,
                         _bn_groups if groups is None else groups, getattr(y, "_css_bnstats", None), out_into,
-                        getattr(res, "_css_tap", None) if res is not None else None)
+                        getattr(res, "_css_tap", None) if res is not None else None, pool)
+
+
+def fused_stem_pool() -> bool:
+    """CSS_NO_BN_POOL=1: the stem's max pool as a pass of its own behind bn_apply (round-4 behaviour; A/B and parity tests)."""
+    return os.environ.get("CSS_NO_BN_POOL", "0") in ("", "0")
+
+
+def pool_out_size(i, ks, stride, pad, ceil_mode):
+    num = i + 2 * pad - ks
+    o = (-(-num // stride) if ceil_mode else num // stride) + 1
+    if ceil_mode and (o - 1) * stride >= i + pad:
+        o -= 1
+    return o
 
 
 # --------------------------------------------------------------------------

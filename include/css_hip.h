@@ -166,6 +166,12 @@ CSS_API int css_bn_eval_coeff(const float* gamma, const float* beta, const float
                               float* shift, int C, int device, css_stream_t stream);
 CSS_API int css_bn_apply(const void* y, int ldy, const void* res, int ldr, void* out, int ldo, const float* scale, const float* shift, int M, int C,
                          int relu, int Mg, int dtype, int device, css_stream_t stream);
+/* css_bn_apply + ReLU + the 3x3 stride-2 pad-1 max pool behind the stem's batch norm (/root/reference/generalframeworks/networks/resnet.py:186-190,
+ * torchvision's bn1 / relu / maxpool) in one pass: y [N][H][W][C] -> out [N][Ho][Wo][C] + argmax bytes (tap index r * 3 + s, NULL: not wanted); scale /
+ * shift [G][C] (group of image n = n / (N / G)).  Bit-identical to css_bn_apply followed by css_maxpool_fwd; backward = css_maxpool_bwd then the
+ * batch-norm backward entry points (the ReLU mask is recomputed from y). */
+CSS_API int css_bn_apply_maxpool(const void* y, void* out, uint8_t* argmax, const float* scale, const float* shift, int N, int H, int W, int C, int Ho,
+                                 int Wo, int G, int relu, int dtype, int device, css_stream_t stream);
 /* backward: `a` (the saved activation, for the ReLU mask) may be NULL for layers without a residual: the mask is then
  * recomputed as y*scale+shift > 0 from the forward's scale/shift ([G][C]), saving one full read of the layer tensor */
 CSS_API int css_bn_bwd_reduce(const void* da, int ldda, const void* a, int lda, const void* y, int ldy, const float* mean, const float* invstd,

@@ -185,6 +185,45 @@ def test_maxpool(shape, ceil, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape,ceil,groups", [((4, 33, 33, 64), False, 2), ((2, 34, 31, 128), True, 1), ((2, 129, 129, 64), False, 2),
+                                               ((2, 97, 97, 128), True, 2)])
+def test_bn_relu_maxpool_fused_equals_the_two_passes(shape, ceil, groups, dtype):
+    """The stem's batch norm + ReLU + 3x3 s2 p1 max pool in ONE pass (css_bn_apply_maxpool, round 5: the normalised activation is never written;
+    /root/reference/generalframeworks/networks/resnet.py:186-190) against bn_act followed by maxpool: pooled values, running statistics and - through
+    the arg-max bytes - every gradient BIT-IDENTICAL (ReLU output: many exact ties at 0, first maximum wins on both paths)."""
+    from css_amd import ops
+    from css_amd.nn import HipBatchNorm2d, HipMaxPool2d
+    n, h, w, c = shape
+    g = torch.Generator().manual_seed(h * 7 + c)
+    x = torch.randn(n, h, w, c, generator=g)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.3
+    res = []
+    for fused in (True, False):
+        bn = HipBatchNorm2d(c).to(dev()).train()
+        pool = HipMaxPool2d(3, 2, 1, ceil_mode=ceil)
+        with torch.no_grad():
+            bn.weight.copy_(gamma.to(dev())); bn.bias.copy_(beta.to(dev()))
+        xg = x.to(dev()).to(dtype).requires_grad_(True)
+        with ops.bn_groups(groups):
+            out = bn(xg, relu=True, pool=pool) if fused else pool(bn(xg, relu=True))
+        go = torch.randn(out.shape, generator=torch.Generator().manual_seed(9)).to(dev()).to(dtype)
+        out.backward(go)
+        res.append((out.detach().float().cpu(), xg.grad.float().cpu(), bn.weight.grad.cpu(), bn.bias.grad.cpu(), bn.running_mean.cpu(), bn.running_var.cpu()))
+    assert res[0][0].shape == res[1][0].shape and res[0][0].shape[1] == ops.pool_out_size(h, 3, 2, 1, ceil)
+    for a, b, name in zip(res[0], res[1], ("pooled", "dx", "dgamma", "dbeta", "running_mean", "running_var")):
+        assert torch.equal(a, b), (name, float((a - b).abs().max()))
+    # and the pooled tensor against torch-CPU on the same operands
+    xc = x.to(dtype).float().permute(0, 3, 1, 2)
+    parts = []
+    for gi in range(groups):
+        part = xc[gi * n // groups:(gi + 1) * n // groups]
+        m_, v_ = part.mean((0, 2, 3), keepdim=True), part.var((0, 2, 3), unbiased=False, keepdim=True)
+        parts.append(F.relu((part - m_) / torch.sqrt(v_ + 1e-5) * gamma.view(1, -1, 1, 1) + beta.view(1, -1, 1, 1)))
+    ref = F.max_pool2d(torch.cat(parts), 3, 2, 1, ceil_mode=ceil)
+    assert rel_err(res[0][0].permute(0, 3, 1, 2), ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("hs,hd,c", [(17, 65, 21), (9, 17, 256), (33, 129, 19), (5, 5, 8), (1, 4, 8), (7, 10, 16)])
 def test_bilinear(hs, hd, c, dtype):
     from css_amd import ops
