@@ -537,12 +537,19 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float*
 // estimate below (microseconds; the constants are the measured orders of magnitude, only their ratios matter) is minimised over s:
 //     rounds(s) x (steps(s) x t_step + t_fix)  +  tiles x s x t_slab,      steps = ceil(M / s / bp)
 // with at least four steps per slice.  (Any s is exact: the slabs of a tile are added in slice order whatever their number.)
+// Round 5: the Cout <= 64 layers (layer 1, the stems, `project`) on 64 x 64 weight tiles instead of 128 x 128 (of which they fill a half or a quarter):
+// twice / four times the useful share of every fragment read and MFMA, three workgroups per CU instead of two.  CSS_WGRAD_N64=0: the 128-wide tile.
+static bool wgrad_n64(int dtype, int Cd, bool big) {
+  static const bool on = !(getenv("CSS_WGRAD_N64") && atoi(getenv("CSS_WGRAD_N64")) == 0);
+  return on && dtype == CSS_BF16 && !big && Cd <= 64;
+}
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out) {
   static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
   const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
-  const int bn = dtype == CSS_BF16 ? (big ? 256 : 128) : 64, bkc = bn, bp = dtype == CSS_BF16 ? (big ? 32 : 64) : 16;
+  const bool n64 = wgrad_n64(dtype, Cd, big);            // bf16, Cout <= 64: 64 x 64 tiles (the 128-wide tile is half empty there)
+  const int bn = dtype == CSS_BF16 ? (big ? 256 : (n64 ? 64 : 128)) : 64, bkc = bn, bp = dtype == CSS_BF16 ? (big ? 32 : 64) : 16;
   const int tiles = cdiv(Ktot, bkc) * cdiv(Cd, bn);
-  const int places = n_cu * (big ? 1 : 2);
+  const int places = n_cu * (big ? 1 : (n64 ? 3 : 2));
   const double t_step = big ? 0.86 : (dtype == CSS_BF16 ? 1.1 : 1.0), t_fix = big ? 5.0 : 3.0;
   const double t_slab = (double)bn * bkc * 4 * 2 / 4.0e6;          // a slab written and read once at ~4 TB/s
   int best_s = 1;
@@ -568,7 +575,7 @@ size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
   int splits, mps;
   css_wgrad_plan_(M, Ktot, Cd, dtype, n_cu, &splits, &mps);
   const bool big = dtype == CSS_BF16 && Cd >= 256 && Ktot >= 256 && !no_256;
-  const int bn = big ? 256 : (dtype == CSS_BF16 ? 128 : 64);        // (square tiles: css_launch_wgrad)
+  const int bn = big ? 256 : (dtype == CSS_BF16 && !wgrad_n64(dtype, Cd, big) ? 128 : 64);        // (square tiles: css_launch_wgrad)
   return (size_t)cdiv(Ktot, bn) * cdiv(Cd, bn) * splits * ((size_t)bn * bn * sizeof(float));
 }
 
@@ -579,8 +586,9 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   int bn, bkc, bp;
   static const bool no_256 = getenv("CSS_NO_DMA256_WGRAD") != nullptr;
   const bool big = dtype == CSS_BF16 && a.Cd >= 256 && a.Ktot >= 256 && !no_256;   // 256x256 LDS-DMA kernel, one workgroup per CU
+  const bool n64 = wgrad_n64(dtype, a.Cd, big);
   if (dtype == CSS_BF16) {
-    bn = big ? 256 : 128; bkc = big ? 256 : 128; bp = big ? 32 : 64;
+    bn = big ? 256 : (n64 ? 64 : 128); bkc = bn; bp = big ? 32 : 64;
     if (a.Cs % 8 || a.ldx % 8 || a.ldy % 8 || a.Cd % 8) return CSS_ERR_ARG;
   } else if (dtype == CSS_F32) {
     bn = 64; bkc = 64; bp = 16;
@@ -609,6 +617,11 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
     hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
+  } else if (n64) {
+    hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64, 64, 64>), g, dim3(256), 0, st, a);
+    if (a.ws)
+      hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<64, 64>), dim3(64 / 16, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
+                         a.tiles_k, a.Cd, a.Ktot);
   } else if (dtype == CSS_BF16) {
     // (32 pixels per step - 40 KiB of LDS, four workgroups per CU instead of two - was measured and is slower: profiles/r04_small64_nst2_ab.txt)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
