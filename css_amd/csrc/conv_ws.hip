@@ -130,6 +130,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   const int nmy = stream < mt_total ? (mt_total - stream + nstreams - 1) / nstreams : 0;
   if (nmy == 0) return;
   const int n0w = panel * BN + wave * 32;
+#ifdef WS_DESYNC
+  // harness experiment (round 5): do the store bursts of all 256 CUs at once cost the skeleton its bandwidth?  Start the streams of a launch
+  // spread over WS_DESYNC x 64 cycles (the four panels of a pixel tile keep their common start)
+  for (int i = 0; i < ((stream * 37) % 16) * (WS_DESYNC / 16); ++i) __builtin_amdgcn_s_sleep(1);
+#endif
 
   unsigned long long src_p = (unsigned long long)a.src, wt_p = (unsigned long long)a.wt;
   int src_n = (int)a.src_bytes, wt_n = (int)a.wt_bytes;
