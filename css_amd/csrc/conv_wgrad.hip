@@ -538,9 +538,11 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float*
 //     rounds(s) x (steps(s) x t_step + t_fix)  +  tiles x s x t_slab,      steps = ceil(M / s / bp)
 // with at least four steps per slice.  (Any s is exact: the slabs of a tile are added in slice order whatever their number.)
 // Round 5: the Cout <= 64 layers (layer 1, the stems, `project`) on 64 x 64 weight tiles instead of 128 x 128 (of which they fill a half or a quarter):
-// twice / four times the useful share of every fragment read and MFMA, three workgroups per CU instead of two.  CSS_WGRAD_N64=0: the 128-wide tile.
+// twice / four times the useful share of every fragment read and MFMA, three workgroups per CU instead of two.  OPT-IN (CSS_WGRAD_N64=1): measured
+// -0.06 ms (c2) / -0.3 ms (c4) of weight-gradient time per step (profiles/r05_wgrad_n64_ab.txt) - inside the noise at the headline workload: these
+// layers are bound by streaming their two operands, not by the tile - and another summation order of those gradients (same bits run to run).
 static bool wgrad_n64(int dtype, int Cd, bool big) {
-  static const bool on = !(getenv("CSS_WGRAD_N64") && atoi(getenv("CSS_WGRAD_N64")) == 0);
+  static const bool on = getenv("CSS_WGRAD_N64") && atoi(getenv("CSS_WGRAD_N64")) != 0;
   return on && dtype == CSS_BF16 && !big && Cd <= 64;
 }
 void css_wgrad_plan_(int M, int Ktot, int Cd, int dtype, int n_cu, int* splits_out, int* mps_out) {

@@ -160,15 +160,15 @@ def test_eager_residual_gradient_switch_is_a_shipped_configuration():
     assert r.returncode == 0, r.stdout[-800:]
 
 
-@pytest.mark.parametrize("env,select", [({"CSS_MAXPOOL_BWD_GENERIC": "1"}, "maxpool"), ({"CSS_NO_BN_POOL": "1"}, "blocks"), ({"CSS_WGRAD_N64": "0"}, "stemconv")],
-                         ids=["CSS_MAXPOOL_BWD_GENERIC=1", "CSS_NO_BN_POOL=1", "CSS_WGRAD_N64=0"])
+@pytest.mark.parametrize("env,select", [({"CSS_MAXPOOL_BWD_GENERIC": "1"}, "maxpool"), ({"CSS_NO_BN_POOL": "1"}, "blocks"), ({"CSS_WGRAD_N64": "1"}, "stemconv")],
+                         ids=["CSS_MAXPOOL_BWD_GENERIC=1", "CSS_NO_BN_POOL=1", "CSS_WGRAD_N64=1"])
 def test_round5_stem_region_switches_are_shipped_configurations(env, select):
     """Round 5: CSS_MAXPOOL_BWD_GENERIC=1 (the generic max-pool adjoint instead of the 3x3 s2 p1 form: the pooling tests against F.max_pool2d) and
     CSS_NO_BN_POOL=1 (the stem's max pool as a pass of its own behind bn_apply: the stem block tests against the reference's golden vectors), each
     in a process of its own.  (CSS_NO_STEM_S2D=1 has its own two-process test in tests/test_conv_stem_gpu.py.)"""
     e = dict(os.environ)
     e.update(env)
-    # (CSS_WGRAD_N64=0: the Cout <= 64 weight gradients on 128 x 128 tiles again - the stem's weight gradient against torch-CPU)
+    # (CSS_WGRAD_N64=1: the Cout <= 64 weight gradients on 64 x 64 tiles - the stem's weight gradient against torch-CPU)
     target = {"maxpool": [os.path.join(ROOT, "tests", "test_ops_gpu.py"), "-k", "maxpool"],
               "blocks": [os.path.join(ROOT, "tests", "test_blocks_gpu.py"), "-k", "stem"],
               "stemconv": [os.path.join(ROOT, "tests", "test_conv_stem_gpu.py"), "-k", "forward_stats_and_wgrad"]}[select]
