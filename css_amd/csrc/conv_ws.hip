@@ -23,7 +23,7 @@
 // whole number of tiles (K = 512: eight stages per tile, ONE tile of look-ahead, 128 VGPRs of weights, no addend form).
 // tests/test_host_cpu.py replays the issue order against these counts and pins them from the ISA.
 // Compile-time switches (scripts/ws_bench.hip only; the library is built with none of them): WS_ABL_NOSTORE / _NOMFMA / _NODMA /
-// _PANEL_XCD and WS_STORE_AUX are timing ablations, WS_PP=1 is the ping-pong form of the K loop (waves 0-3 and 4-7 half a stage
+// _PANEL_XCD, _WRAP_SRC / _WRAP_DST (round 5: the stream from / into a cache-resident window), _STORE_ROWS (round 5: whole 512-byte rows per store instruction), WS_NT, WS_DESYNC and WS_STORE_AUX are timing ablations, WS_PP=1 is the ping-pong form of the K loop (waves 0-3 and 4-7 half a stage
 // apart: bit-identical, 10 % faster without stores, not faster with them - profiles/r02_ws_kernel.txt section 4 - so not shipped).
 #include "common.h"
 #include "launchers.h"
@@ -93,23 +93,48 @@ template <int BASE, int NST, int NLD> __device__ __forceinline__ void ws_wait_st
 // KS = K / 64 (stages per pixel tile).  grid = n_cu workgroups of 512 threads, (n_cu / 8) % (Cd / 256) == 0.
 template <int KS, bool STATS, bool ADD>
 __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
-  constexpr int NT = KS <= 4 ? 2 : 1;                            // whole tiles of look-ahead (K = 512: one - the ring is 160 KiB either way)
+  // Round 5 (profiles/r05_ws_skeleton.txt): the fill + store skeleton of this kernel costs MORE than its fill and its stores alone (24 + 44 us
+  // against 90) when every store instruction writes 16 half cache lines (64 bytes of 16 pixel rows - what a wave's 32 channels give), and 73
+  // when it writes whole 512-byte rows of the panel.  ROWS: the packed tile goes through a 64 KiB LDS buffer (written as the waves hold it,
+  // read back two whole rows per instruction) - the space comes from ONE tile of look-ahead at K = 256, which measures the same as two.
+#if WS_PP != 0 || defined(WS_NO_ROWS)
+  constexpr bool ROWS = false;
+#else
+  constexpr bool ROWS = KS <= 4;                                 // (K = 512: the ring takes all 160 KiB)
+#endif
+#ifdef WS_NT      // harness experiment: tiles of look-ahead
+  constexpr int NT = WS_NT;
+#else
+  constexpr int NT = (ROWS ? KS <= 2 : KS <= 4) ? 2 : 1;         // whole tiles of look-ahead (K = 512: one - the ring is 160 KiB either way)
+#endif
   constexpr int BM = 128, BN = 256, LA = NT * KS, NS = LA + 2;
   constexpr int STG = BM * 128;                                  // one stage: 128 pixels x 128 bytes (64 channels)
-#if defined(WS_ABL_NOSTORE)       // timing ablations (scripts/ws_bench.hip): results are garbage
-  constexpr bool ABL_NOSTORE = true, ABL_NOMFMA = false, ABL_NODMA = false;
-#elif defined(WS_ABL_NOMFMA)
-  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = true, ABL_NODMA = false;
-#elif defined(WS_ABL_NODMA)
-  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = true;
+#ifdef WS_ABL_NOSTORE              // timing ablations (scripts/ws_bench.hip; they combine): results are garbage
+  constexpr bool ABL_NOSTORE = true;
 #else
-  constexpr bool ABL_NOSTORE = false, ABL_NOMFMA = false, ABL_NODMA = false;
+  constexpr bool ABL_NOSTORE = false;
 #endif
-  constexpr int NLD = ADD ? 10 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS ? 4 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
+#ifdef WS_ABL_NOMFMA
+  constexpr bool ABL_NOMFMA = true;
+#else
+  constexpr bool ABL_NOMFMA = false;
+#endif
+#ifdef WS_ABL_NODMA
+  constexpr bool ABL_NODMA = true;
+#else
+  constexpr bool ABL_NODMA = false;
+#endif
+#ifdef WS_ABL_NOSTATSTORE          // (the statistics arithmetic without its four slab stores per tile and wave)
+  constexpr bool ABL_NOSTATSTORE = true;
+#else
+  constexpr bool ABL_NOSTATSTORE = false;
+#endif
+  constexpr int NLD = ADD ? 10 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS && !ABL_NOSTATSTORE ? 1 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
   constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
   constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + (NT >= 2 ? NLD : 0) + NST, W2 = W1 + (NT >= 2 ? NST : 0);   // vmcnt of the stage wait in tile 0, tile 1, later tiles
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG];
+  constexpr int OB = ROWS ? BM * 512 : 0;                        // the output tile of the panel: 128 rows x 512 bytes
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG + OB];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -164,7 +189,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int m = (stream + it_ti * nstreams) * BM + prow + 8 * i;
+#ifdef WS_ABL_WRAP_SRC      // timing ablation: the pixel stream from an L2- / MALL-resident window of WS_ABL_WRAP_SRC rows (results are garbage)
+      rowoff[i] = (it_ti < nmy && m < a.M) ? (unsigned)(m % WS_ABL_WRAP_SRC) * lds2 + (unsigned)((cch0 ^ ((i & 1) << 2)) * 16) : WS_OOB;
+#else
       rowoff[i] = (it_ti < nmy && m < a.M) ? (unsigned)m * lds2 + (unsigned)((cch0 ^ ((i & 1) << 2)) * 16) : WS_OOB;
+#endif
     }
   };
   auto issue_stage = [&]() {
@@ -203,56 +232,117 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   // ---------------- epilogue of a tile (rows m0e ..): no LDS, no barrier ----------------
   auto epilogue = [&](int m0e) {
     const int bnd = STATS ? (m0e / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
+    // sum and sum of squares of the bf16-ROUNDED outputs (what the batch norm will read), two values per instruction (v_pk_add_f32 /
+    // v_pk_fma_f32), accumulated in the loop that packs the tile (same order per lane as conv_igemm_p8_kernel: i = 0 .. 7, then the 16 pixels
+    // of a lane row); the row test only in a tile that straddles a statistics-group boundary (one tile per group)
+    ws_f32x2 s01[2], s23[2], q01[2], q23[2];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int m = m0e + 16 * i + l15;
-      unsigned lo0 = ws_pack2(acc[i][0][0], acc[i][0][1]), hi0 = ws_pack2(acc[i][0][2], acc[i][0][3]);
-      unsigned lo1 = ws_pack2(acc[i][1][0], acc[i][1][1]), hi1 = ws_pack2(acc[i][1][2], acc[i][1][3]);
-      ws_swap16(lo0, lo1);
-      ws_swap16(hi0, hi1);
-      ws_u32x4 v = {lo0, hi0, lo1, hi1};
-      if (ADD) {
-        ws_u32x4 r = radd[ADD ? i : 0];
-        const unsigned mw = (unsigned)__builtin_amdgcn_ds_bpermute(((i & 3) * 16 + l15) * 4, (int)rmk[ADD ? i >> 2 : 0]);
-        const unsigned mk = has_mask ? (mw >> (8 * (2 * (lg & 1) + (lg >> 1)))) & 0xFFu : 0xFFu;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(r[e]), ws_hi(v[e]) + ws_hi(r[e]));
-      }
-      if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
-      else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)nl) * 2u : WS_OOB), 0, WS_STORE_AUX);
-    }
-    if (STATS) {
-      // sum and sum of squares of the bf16-ROUNDED outputs (what the batch norm will read), two values per instruction (v_pk_add_f32 /
-      // v_pk_fma_f32); the row test only in a tile that straddles a statistics-group boundary (one tile per group)
-      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
-      const unsigned base = (unsigned)(m0e >> 7) * 2u * (unsigned)a.Cd * 4u;
-      const bool whole = m0e + BM <= bnd;
+    for (int j = 0; j < 2; ++j) s01[j] = s23[j] = q01[j] = q23[j] = ws_f32x2{0.f, 0.f};
+    const bool whole = m0e + BM <= bnd;
+    // pixel tile i: pack (the statistics see the packed values), exchange -> lane (l15, lg) holds 8 consecutive channels of pixel 16 i + l15
+    auto pack_tile = [&](int i, bool test) -> ws_u32x4 {
+      unsigned lo[2], hi[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        ws_f32x2 s01 = {0.f, 0.f}, s23 = {0.f, 0.f}, q01 = {0.f, 0.f}, q23 = {0.f, 0.f};
-        auto accum = [&](bool test) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) {
-            f32x4 t = acc[i][j];
-            asm volatile("" : "+v"(t));       // opaque: otherwise the packed values of the store loop stay alive (CSE) across the epilogue
-            const unsigned lo = ws_pack2(t[0], t[1]), hi = ws_pack2(t[2], t[3]);
-            ws_f32x2 v01 = {ws_lo(lo), ws_hi(lo)}, v23 = {ws_lo(hi), ws_hi(hi)};
-            if (test && !(m0e + 16 * i + l15 < bnd)) { v01 = ws_f32x2{0.f, 0.f}; v23 = ws_f32x2{0.f, 0.f}; }   // (rows >= M hold zeros already)
-            s01 += v01; s23 += v23;
-            q01 += v01 * v01; q23 += v23 * v23;
-          }
-        };
-        if (whole) accum(false);
-        else accum(true);
-        ws_f32x4 os = {ws_row16_sum(s01[0]), ws_row16_sum(s01[1]), ws_row16_sum(s23[0]), ws_row16_sum(s23[1])};
-        ws_f32x4 oq = {ws_row16_sum(q01[0]), ws_row16_sum(q01[1]), ws_row16_sum(q23[0]), ws_row16_sum(q23[1])};
-        const int n = n0w + 16 * j + 4 * lg;
-        const bool lane_ok = l15 == 0;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, os), rs_s, (int)(lane_ok ? base + (unsigned)n * 4u : WS_OOB), 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, oq), rs_s, (int)(lane_ok ? base + (unsigned)(a.Cd + n) * 4u : WS_OOB), 0, 0);
+        lo[j] = ws_pack2(acc[i][j][0], acc[i][j][1]);
+        hi[j] = ws_pack2(acc[i][j][2], acc[i][j][3]);
+        if (STATS) {
+          ws_f32x2 v01 = {ws_lo(lo[j]), ws_hi(lo[j])}, v23 = {ws_lo(hi[j]), ws_hi(hi[j])};
+          if (test && !(m0e + 16 * i + l15 < bnd)) { v01 = ws_f32x2{0.f, 0.f}; v23 = ws_f32x2{0.f, 0.f}; }   // (rows >= M hold zeros already)
+          s01[j] += v01; s23[j] += v23;
+          q01[j] += v01 * v01; q23[j] += v23 * v23;
+        }
       }
+      ws_swap16(lo[0], lo[1]);
+      ws_swap16(hi[0], hi[1]);
+      return ws_u32x4{lo[0], hi[0], lo[1], hi[1]};
+    };
+    if constexpr (ROWS) {
+      // registers -> LDS as the waves hold the tile (pixel 16 i + l15, 8 channels = one 16-byte chunk; chunk c of row r at position
+      // c ^ (r & 31): 16 lanes of a write cover the 64 banks once) -> one barrier -> two whole 512-byte rows per instruction
+      // (the LDS addresses do not depend on the tile: made opaque here, or the compiler keeps all 16 of them in registers across the K loop;
+      // row 16 i + l15 -> (r & 31) = 16 (i & 1) | l15, row 16 wave + 2 i + half -> 16 (wave & 1) | 2 i | half: the swizzle splits into a lane part
+      // and a constant XOR per i)
+      const int cc = wave * 4 + 2 * (lg & 1) + (lg >> 1);
+      int wb0 = NS * STG + l15 * 512 + ((cc ^ l15) << 4);
+      int rb0 = NS * STG + (16 * wave + (lane >> 5)) * 512 + ((((lane & 31) ^ (16 * (wave & 1) + (lane >> 5)))) << 4);
+      asm volatile("" : "+v"(wb0), "+v"(rb0));
+      auto to_lds = [&](bool test) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<ws_u32x4*>(smem + (wb0 ^ ((i & 1) << 8)) + i * 8192) = pack_tile(i, test);
+      };
+      if (!STATS || whole) to_lds(false);
+      else to_lds(true);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const int ch = lane & 31;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int r = 16 * wave + 2 * i + (lane >> 5);
+        const int m = m0e + r;
+        ws_u32x4 v = *reinterpret_cast<const ws_u32x4*>(smem + (rb0 ^ (i << 5)) + i * 1024);
+        if (ADD) {
+          ws_u32x4 q = radd[ADD ? i : 0];
+          // mask bytes: dword (row 8 q' + (lane >> 3), chunks 4 (lane & 7) ..) sits in rmk[q'] of lane 8 (row & 7) + (chunk >> 2)
+          const unsigned mw = (unsigned)__builtin_amdgcn_ds_bpermute((((2 * i + (lane >> 5)) & 7) * 8 + (ch >> 2)) * 4, (int)rmk[ADD ? i >> 2 : 0]);
+          const unsigned mk = has_mask ? (mw >> (8 * (ch & 3))) & 0xFFu : 0xFFu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) q[e] &= keep_mask_bf16x2(mk, e);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(q[e]), ws_hi(v[e]) + ws_hi(q[e]));
+        }
+        if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)(panel * BN + 8 * ch)) * 2u : WS_OOB), 0, WS_STORE_AUX);
+      }
+    } else {
+      auto to_mem = [&](bool test) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = m0e + 16 * i + l15;
+          ws_u32x4 v = pack_tile(i, test);
+          if (ADD) {
+            ws_u32x4 r = radd[ADD ? i : 0];
+            const unsigned mw = (unsigned)__builtin_amdgcn_ds_bpermute(((i & 3) * 16 + l15) * 4, (int)rmk[ADD ? i >> 2 : 0]);
+            const unsigned mk = has_mask ? (mw >> (8 * (2 * (lg & 1) + (lg >> 1)))) & 0xFFu : 0xFFu;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] &= keep_mask_bf16x2(mk, e);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(r[e]), ws_hi(v[e]) + ws_hi(r[e]));
+          }
+          if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+#ifdef WS_ABL_STORE_ROWS    // timing ablation: the same bytes of the same tile, but every store instruction covers 2 rows x 512 contiguous bytes (results are garbage)
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m0e + 16 * wave + 2 * i + (lane >> 5) < a.M ? ((unsigned)(m0e + 16 * wave + 2 * i + (lane >> 5)) * (unsigned)a.ldd + (unsigned)(panel * BN + 8 * (lane & 31))) * 2u : WS_OOB), 0, WS_STORE_AUX);
+#elif defined(WS_ABL_WRAP_DST)      // timing ablation: the output into a window of WS_ABL_WRAP_DST rows that stays in L2 / MALL (results are garbage)
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)(m % WS_ABL_WRAP_DST) * (unsigned)a.ldd + (unsigned)nl) * 2u : WS_OOB), 0, WS_STORE_AUX);
+#else
+          else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)nl) * 2u : WS_OOB), 0, WS_STORE_AUX);
+#endif
+        }
+      };
+      if (!STATS || whole) to_mem(false);
+      else to_mem(true);
+    }
+    if (STATS) {
+      // the wave's slab entry (32 channels: sums, then sums of squares) in ONE store: every lane of a row holds the row's sums after the
+      // DPP rotations; lane l15 = 0 / 1 / 2 / 3 of each lane row sends (sum, j = 0) / (squares, j = 0) / (sum, j = 1) / (squares, j = 1)
+      const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
+      const unsigned base = (unsigned)(m0e >> 7) * 2u * (unsigned)a.Cd * 4u;
+      ws_f32x4 o[2][2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        o[j][0] = ws_f32x4{ws_row16_sum(s01[j][0]), ws_row16_sum(s01[j][1]), ws_row16_sum(s23[j][0]), ws_row16_sum(s23[j][1])};
+        o[j][1] = ws_f32x4{ws_row16_sum(q01[j][0]), ws_row16_sum(q01[j][1]), ws_row16_sum(q23[j][0]), ws_row16_sum(q23[j][1])};
+      }
+      ws_f32x4 ov;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x0 = (l15 & 1) ? o[0][1][e] : o[0][0][e], x1 = (l15 & 1) ? o[1][1][e] : o[1][0][e];
+        ov[e] = (l15 & 2) ? x1 : x0;
+      }
+      const int n = (l15 & 1) * a.Cd + n0w + 16 * ((l15 >> 1) & 1) + 4 * lg;
+      if (ABL_NOSTATSTORE) asm volatile("" ::"v"(ov[0]), "v"(ov[1]), "v"(ov[2]), "v"(ov[3]));
+      else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(ws_u32x4, ov), rs_s, (int)(l15 < 4 ? base + (unsigned)n * 4u : WS_OOB), 0, 0);
     }
   };
   auto load_addend = [&](int m0e) {
@@ -261,6 +351,20 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     const __amdgpu_buffer_rsrc_t rs_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.addend), 0, (int)a.add_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.add_mask), 0, (int)a.mask_bytes, 0x00020000);
     // (always issued - the vmcnt bookkeeping counts NLD = 10 loads per tile; without a mask the offset is out of range and the dword unused)
+    if constexpr (ROWS) {
+      // the row form: my vectors are (row 16 wave + 2 i + (lane >> 5), chunk lane & 31) - whole lines of the addend, too
+#pragma unroll
+      for (int q = 0; q < (ADD ? 2 : 0); ++q) {
+        const int m = m0e + 16 * wave + 8 * q + (lane >> 3);
+        rmk[q] = (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rs_k, (int)((has_mask && m < a.M) ? (unsigned)m * ((unsigned)a.Cd >> 3) + (unsigned)(panel * 32 + 4 * (lane & 7)) : WS_OOB), 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < (ADD ? 8 : 0); ++i) {
+        const int m = m0e + 16 * wave + 2 * i + (lane >> 5);
+        radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)(panel * BN + 8 * (lane & 31))) * 2u : WS_OOB), 0, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < (ADD ? 2 : 0); ++q) {
       const int m = m0e + 16 * (lg + 4 * q) + l15;

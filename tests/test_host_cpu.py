@@ -375,8 +375,10 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
                    check=True, capture_output=True, timeout=600)
     lines = open(out).read().split("\n")
     # (KS, STATS, ADD) -> the vmcnt values of the stage wait in tile 0 / tile 1 / later tiles (conv_ws.hip: W0, W1, W2)
-    for ks, st, ad, waits in ((4, 1, 0, (14, 26, 38)), (4, 0, 1, (24, 42, 50)), (4, 0, 0, (14, 22, 30)), (2, 1, 0, (6, 18, 30)), (1, 0, 1, (12, 30, 38)),
-                              (8, 1, 0, (14, 26)), (8, 0, 0, (14, 22))):
+    # (round 5: K = 256 keeps ONE tile of look-ahead - the other 64 KiB of LDS hold the output tile of the row-form epilogue -
+    # and the statistics slab entry of a wave is ONE store per tile: 8 + 1 stores)
+    for ks, st, ad, waits in ((4, 1, 0, (6, 15)), (4, 0, 1, (16, 24)), (4, 0, 0, (6, 14)), (2, 1, 0, (6, 15, 24)), (1, 0, 1, (12, 30, 38)),
+                              (8, 1, 0, (14, 23)), (8, 0, 0, (14, 22))):
         sym = f"_Z14conv_ws_kernelILi{ks}ELb{st}ELb{ad}EEv8ConvArgs:"
         start = next(i for i, l in enumerate(lines) if l.startswith(sym))
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
@@ -387,7 +389,11 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
         assert not any("vmcnt(0)" in l for l in body[bar[0]:mfma[-1] + 1]), sym + " compiler drained the LDS-DMA pipeline inside the K loop"
         for wv in waits:
             assert any(f"s_waitcnt vmcnt({wv})" in l for l in body), (sym, wv)
-        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == ((2 if ks <= 4 else 1) * ks + 2) * 16384, sym
+        # the ring of LA + 2 stages, and for K <= 256 the 64 KiB output tile of the row-form epilogue
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == ((2 if ks <= 2 else 1) * ks + 2) * 16384 + (65536 if ks <= 4 else 0), sym
+        if ks <= 4:
+            # the row form: 8 ds_write_b128 + 8 ds_read_b128 per tile and wave around ONE extra barrier; 8 stores
+            assert sum("ds_write_b128" in l for l in body) >= 8, sym
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
 
 
@@ -401,9 +407,9 @@ def test_conv_ws_vmcnt_accounting_model():
         for stats, add in ((0, 0), (1, 0), (0, 1)):
             if ks == 8 and add:
                 continue
-            nt = 2 if ks <= 4 else 1
+            nt = 2 if ks <= 2 else 1
             la = nt * ks
-            nld, nst = (10 if add else 0), 8 + (4 if stats else 0)       # addend: 8 vectors + 2 dwords of mask bytes (always requested)
+            nld, nst = (10 if add else 0), 8 + (1 if stats else 0)       # addend: 8 vectors + 2 dwords of mask bytes (always requested); statistics: one slab store
             w0 = 2 * (la - 1) + nld
             w1 = w0 + (nld if nt >= 2 else 0) + nst
             w2 = w1 + (nst if nt >= 2 else 0)
@@ -543,6 +549,50 @@ def test_conv_ws_index_maps():
             assert (l15, c) not in covered
             covered[(l15, c)] = lane
     assert len(covered) == 16 * 32
+    # (4) the row form of the epilogue (K <= 256): wave w, lane (l15, lg) writes its chunk (8 channels: panel chunk 4 w + 2 (lg & 1) + (lg >> 1))
+    # of row 16 i + l15 at position chunk ^ (row & 31) of the 512-byte LDS row; then lane reads (row 16 w + 2 i + (lane >> 5), chunk lane & 31).
+    # Every (row, chunk) written once and read once, the read returns what the store of that lane sends to row / chunk, and both are
+    # spread evenly over the 64 banks (a write: the 16 lanes of one lg cover them once)
+    ob = {}
+    for w in range(8):
+        for i in range(8):
+            slots = []
+            for lane in range(64):
+                l15, lg = lane & 15, lane >> 4
+                cc = w * 4 + 2 * (lg & 1) + (lg >> 1)
+                wb0 = l15 * 512 + ((cc ^ l15) << 4)
+                addr = (wb0 ^ ((i & 1) << 8)) + i * 8192
+                row = 16 * i + l15
+                assert addr == row * 512 + ((cc ^ (row & 31)) << 4)
+                assert addr not in ob
+                ob[addr] = (row, cc)
+                slots.append(addr)
+            for g in range(4):
+                banks = [((a_ // 4) + d) % 64 for a_ in slots[16 * g:16 * g + 16] for d in range(4)]
+                assert sorted(banks) == list(range(64)), (w, i, g)
+    assert len(ob) == 128 * 32
+    seen = set()
+    for w in range(8):
+        for i in range(8):
+            slots = []
+            for lane in range(64):
+                half, ch = lane >> 5, lane & 31
+                rb0 = (16 * w + half) * 512 + ((ch ^ (16 * (w & 1) + half)) << 4)
+                addr = (rb0 ^ (i << 5)) + i * 1024
+                row = 16 * w + 2 * i + half
+                assert ob[addr] == (row, ch), (w, i, lane)
+                seen.add(addr)
+                slots.append(addr)
+            banks = [((a_ // 4) + d) % 64 for a_ in slots for d in range(4)]
+            assert all(banks.count(b) == 4 for b in range(64))
+    assert len(seen) == 128 * 32
+    # the mask byte of (row, chunk) in the addend form: dword (row 16 w + 8 q + (lane >> 3), chunks 4 (lane & 7) ..) is loaded by that lane
+    for i in range(8):
+        for lane in range(64):
+            half, ch = lane >> 5, lane & 31
+            rl = 2 * i + half
+            src_lane, q = ((rl & 7) * 8 + (ch >> 2)), i >> 2
+            assert 8 * q + (src_lane >> 3) == rl and 4 * (src_lane & 7) + (ch & 3) == ch
 
 
 def test_statistics_slab_protocol_model():
