@@ -99,15 +99,19 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   // read back two whole rows per instruction) - the space comes from ONE tile of look-ahead at K = 256, which measures the same as two.
 #if WS_PP != 0 || defined(WS_NO_ROWS)
   constexpr bool ROWS = false;
+#elif defined(WS_NO_ROWS8)
+  constexpr bool ROWS = KS <= 4;
 #else
-  constexpr bool ROWS = KS <= 4;                                 // (K = 512: the ring takes all 160 KiB)
+  constexpr bool ROWS = true;
 #endif
 #ifdef WS_NT      // harness experiment: tiles of look-ahead
   constexpr int NT = WS_NT;
 #else
-  constexpr int NT = (ROWS ? KS <= 2 : KS <= 4) ? 2 : 1;         // whole tiles of look-ahead (K = 512: one - the ring is 160 KiB either way)
+  constexpr int NT = (ROWS ? KS <= 2 : KS <= 4) ? 2 : 1;         // whole tiles of look-ahead
 #endif
-  constexpr int BM = 128, BN = 256, LA = NT * KS, NS = LA + 2;
+  // stages of look-ahead: whole tiles, except K = 512 in the row form - HALF a tile (four stages, 64 KiB in flight as at K = 256), which
+  // leaves the 64 KiB of the output tile
+  constexpr int BM = 128, BN = 256, LA = (ROWS && KS == 8) ? 4 : NT * KS, NS = LA + 2;
   constexpr int STG = BM * 128;                                  // one stage: 128 pixels x 128 bytes (64 channels)
 #ifdef WS_ABL_NOSTORE              // timing ablations (scripts/ws_bench.hip; they combine): results are garbage
   constexpr bool ABL_NOSTORE = true;
@@ -132,6 +136,9 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   constexpr int NLD = ADD ? 10 : 0, NST = (ABL_NOSTORE ? 0 : 8) + (STATS && !ABL_NOSTATSTORE ? 1 : 0);    // vector-memory operations of a tile besides its LDS-DMA pieces
   constexpr int NPC = ABL_NODMA ? 0 : 2;                          // LDS-DMA pieces per stage and wave
   constexpr int W0 = NPC * (LA - 1) + NLD, W1 = W0 + (NT >= 2 ? NLD : 0) + NST, W2 = W1 + (NT >= 2 ? NST : 0);   // vmcnt of the stage wait in tile 0, tile 1, later tiles
+  // (LA < KS: the pieces of slice k were issued LA slices earlier - in the previous tile, ahead of its epilogue's stores, for k < LA only)
+  constexpr int WH0 = NPC * (LA - 1), WH1 = WH0 + NST;
+  static_assert(LA >= KS || !ADD, "the half-tile look-ahead has no addend form");
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
   constexpr int OB = ROWS ? BM * 512 : 0;                        // the output tile of the panel: 128 rows x 512 bytes
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG + OB];
@@ -313,6 +320,12 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
           if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 #ifdef WS_ABL_STORE_ROWS    // timing ablation: the same bytes of the same tile, but every store instruction covers 2 rows x 512 contiguous bytes (results are garbage)
           else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m0e + 16 * wave + 2 * i + (lane >> 5) < a.M ? ((unsigned)(m0e + 16 * wave + 2 * i + (lane >> 5)) * (unsigned)a.ldd + (unsigned)(panel * BN + 8 * (lane & 31))) * 2u : WS_OOB), 0, WS_STORE_AUX);
+#elif defined(WS_ABL_STORE_SEG)      // timing ablation: as _STORE_ROWS with segments of WS_ABL_STORE_SEG bytes (128: 8 rows x one cache line per instruction; 256: 4 rows x two)
+          else {
+            constexpr int SPR = 512 / WS_ABL_STORE_SEG, LPS = WS_ABL_STORE_SEG / 16, RPI = 64 / LPS;      // segments per panel row, lanes per segment, rows per instruction
+            const int mr = m0e + (wave / SPR) * (128 / (8 / SPR)) + RPI * i + lane / LPS;
+            __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(mr < a.M ? ((unsigned)mr * (unsigned)a.ldd + (unsigned)(panel * BN + (wave % SPR) * (WS_ABL_STORE_SEG / 2) + 8 * (lane % LPS))) * 2u : WS_OOB), 0, WS_STORE_AUX);
+          }
 #elif defined(WS_ABL_WRAP_DST)      // timing ablation: the output into a window of WS_ABL_WRAP_DST rows that stays in L2 / MALL (results are garbage)
           else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)(m % WS_ABL_WRAP_DST) * (unsigned)a.ldd + (unsigned)nl) * 2u : WS_OOB), 0, WS_STORE_AUX);
 #else
@@ -465,9 +478,14 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       WS_T(wt0);
       // my two pieces of this stage have landed (see the header for the counts)
-      if (ti >= 2) ws_wait_vm<W2>();
-      else if (ti == 1) ws_wait_vm<W1>();
-      else ws_wait_vm<W0>();
+      if constexpr (LA < KS) {
+        if (ti >= 1 && k < LA) ws_wait_vm<WH1>();
+        else ws_wait_vm<WH0>();
+      } else {
+        if (ti >= 2) ws_wait_vm<W2>();
+        else if (ti == 1) ws_wait_vm<W1>();
+        else ws_wait_vm<W0>();
+      }
       WS_T(wt1); WS_ACC(k == 0 ? 0 : 5, wt1, wt0);
       __builtin_amdgcn_s_barrier();       // everybody's pieces have landed; everybody is done reading the previous stages
       asm volatile("" ::: "memory");
