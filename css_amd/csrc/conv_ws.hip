@@ -8,23 +8,33 @@
 //   * a workgroup owns ONE 256-channel panel of the output for its whole life and keeps the panel's weights in REGISTERS as MFMA
 //     operands: wave w holds channels 32 w .. 32 w + 31 for all of K (K = 256: 16 fragments = 64 VGPRs), loaded once per launch;
 //   * the only LDS traffic from global memory is the pixel stream: tiles of 128 pixels, one 16 KiB stage per 64 channels, a ring of
-//     LA + 2 stages with LA = 2 tiles' worth in flight (K = 256: 10 stages = 160 KiB, 128 KiB in flight per CU) - half the bytes per
-//     FLOP of the 256x256 tiling, and none of them weights;
+//     LA + 2 stages (K <= 128: LA = two tiles; K = 256: one tile = 4 stages; K = 512: half a tile = 4 stages - 64 KiB in flight per CU either
+//     way, which measures the same as 128) - half the bytes per FLOP of the 256x256 tiling, and none of them weights;
 //   * every wave reads the whole pixel stage (128 x 64) and multiplies it with its own 32 channels: 16 ds_read_b128 + 32
 //     v_mfma_f32_16x16x32_bf16 per stage and wave, ONE barrier per stage;
 //   * the 4 (Cout / 256) panels of a pixel tile are worked on at the same time by 4 CUs of one XCD (the tile is fetched from HBM once
 //     and hits that XCD's L2 three times); 128-row tiles quantise to the chip well enough (1057 tiles x 4 panels on 256 CUs = 16.5
 //     rounds) that there is no leftover launch;
-//   * the epilogue is conv_pp64's (registers -> bf16 -> v_permlane16_swap -> 16-byte stores, 64 contiguous bytes per pixel; BN
-//     statistics slabs of 128 rows, which a wave owns whole; the residual-gradient addend of css_conv2d_dgrad_add), with the addend
-//     requested at the START of the tile so that its wait does not drain the LDS-DMA queue.
+//   * the epilogue (round 5: the ROW form) packs the tile to bf16 in registers (v_permlane16_swap: 8 consecutive channels per lane),
+//     accumulates the BN statistics of the packed values in the same loop (slabs of 128 rows, which a wave owns whole: ONE 16-lane store
+//     per wave and tile), passes the tile through a 64 KiB LDS buffer (one barrier) and stores it two whole 512-byte panel rows per
+//     instruction.  Why: a store instruction that writes 16 HALF cache lines (what a wave's 32 channels give) slows the in-order
+//     vector-memory path that the LDS-DMA stream shares - the fill + store skeleton of the kernel cost 90 us where its fill alone takes 24
+//     and its stores alone 44; with whole lines it is 73 (profiles/r05_ws_skeleton*.txt, r05_ws_seg.txt: 128-byte segments already give all
+//     of it).  The residual-gradient addend of css_conv2d_dgrad_add is requested at the START of the tile, in the row form as well (whole
+//     lines), so that its wait does not drain the LDS-DMA queue.
 // vmcnt bookkeeping: loads, stores and LDS-DMA retire in order, so the wait for "my two pieces of stage s" is a COUNT of what the
-// wave has issued since: 2 (LA - 1) pieces + the epilogue stores (+ addend loads) of the two tiles in between - a constant because LA is a
-// whole number of tiles (K = 512: eight stages per tile, ONE tile of look-ahead, 128 VGPRs of weights, no addend form).
+// wave has issued since: 2 (LA - 1) pieces + the epilogue stores (+ addend loads) of the tiles in between - a constant when LA is a
+// whole number of tiles; K = 512 (LA = half a tile, 128 VGPRs of weights, no addend form) counts by slice: the previous tile's stores
+// lie between issue and wait for the first LA slices of a tile only.
 // tests/test_host_cpu.py replays the issue order against these counts and pins them from the ISA.
-// Compile-time switches (scripts/ws_bench.hip only; the library is built with none of them): WS_ABL_NOSTORE / _NOMFMA / _NODMA /
-// _PANEL_XCD, _WRAP_SRC / _WRAP_DST (round 5: the stream from / into a cache-resident window), _STORE_ROWS (round 5: whole 512-byte rows per store instruction), WS_NT, WS_DESYNC and WS_STORE_AUX are timing ablations, WS_PP=1 is the ping-pong form of the K loop (waves 0-3 and 4-7 half a stage
-// apart: bit-identical, 10 % faster without stores, not faster with them - profiles/r02_ws_kernel.txt section 4 - so not shipped).
+// Compile-time switches (scripts/ws_bench.hip only; the library is built with none of them): timing ablations whose results are garbage -
+// WS_ABL_NOSTORE / _NOMFMA / _NODMA / _NOSTATSTORE (they combine), _PANEL_XCD, _WRAP_SRC / _WRAP_DST (the stream from / into a cache-resident
+// window), _STORE_ROWS / _STORE_SEG=128|256 (the old epilogue's bytes in whole rows / segments per store instruction), WS_NT, WS_DESYNC,
+// WS_STORE_AUX - and bit-identical variants: WS_NO_ROWS (the round-4 epilogue: 64 bytes per pixel straight from registers, two tiles of
+// look-ahead at K = 256), WS_NO_ROWS8 (that, for K = 512 only), WS_PP=1 (the ping-pong form of the K loop, waves 0-3 and 4-7 half a stage
+// apart, K <= 256: 10 % faster without stores, not faster with them in either store form - profiles/r02_ws_kernel.txt section 4,
+// r05_ws_pp_rows.txt - so not shipped).
 #include "common.h"
 #include "launchers.h"
 #include <cstdlib>
@@ -408,7 +418,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   unsigned long long wsum[8] = {0, 0, 0, 0, 0, 0, 0, 0}, wt0 = 0, wt1 = 0;
 #endif
   if constexpr (WS_PP != 0) {
-    static_assert(NT == 2, "the ping-pong variant counts two tiles of look-ahead");
+    static_assert(NT == 2 || KS == 8, "the ping-pong variant counts two tiles of look-ahead (K <= 256 only)");
     // ---- ping-pong: waves 0-3 and waves 4-7 (one of each per SIMD) run half a stage apart - READ segment (last tile's epilogue,
     // fragment reads, next LDS-DMA pieces, waits) of one group beside the MFMA segment of the other, two barriers per stage ----
     const int grp = wave >> 2;

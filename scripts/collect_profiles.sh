@@ -37,4 +37,8 @@ F=$(find /tmp/prof_fetch4 -name "*.db" | head -1); W=$(find /tmp/prof_write4 -na
 rm -rf /tmp/prof_stats
 timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- python3 $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /tmp/prof_stats.log 2>&1 || echo "stats: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt
 S=$(find /tmp/prof_stats -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_bench_kernel_stats.csv
+# the same for the Cityscapes-shaped workload (the narrow-layer / deep-stem kernels at c4, from the final tree)
+rm -rf /tmp/prof_stats4
+timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats4 -o s -- python3 $ROOT/bench.py --workload c4 --steps 2 --warmup 1 --no-cpu-baseline --no-extra > /tmp/prof_stats4.log 2>&1 || echo "stats4: rocprofv3 failed or timed out" >> $OUT/${TAG}_profile_errors.txt
+S=$(find /tmp/prof_stats4 -name "*kernel_stats.csv" | head -1); [ -n "$S" ] && cp $S $OUT/${TAG}_c4_kernel_stats.csv
 ls -la $OUT/${TAG}_* 2>/dev/null
