@@ -256,6 +256,21 @@ int css_conv_ws_applies(int M, int K, int ld_src, int N, int ld_dst, int R, int 
   a.bias = has_bias ? dummy : nullptr;
   return css_conv_ws_supported(a, n_cu > 0 ? n_cu : 256) ? 1 : 0;
 }
+int css_conv_c64_applies(int N, int H, int W, int Cin, int ld_src, int Cout, int ld_dst, int R, int Sk, int stride, int pad, int dil, int has_addend,
+                         int has_bias, int dtype) {
+  static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr;
+  if (no_dma) return 0;
+  alignas(16) static float dummy[4];
+  ConvArgs a = {};
+  a.N = N; a.Hs = a.Hd = H; a.Ws = a.Wd = W; a.M = N * H * W;
+  a.Cs = Cin; a.lds = ld_src; a.Cd = Cout; a.ldd = ld_dst; a.Ktot = R * Sk * Cin;
+  a.R = R; a.S = Sk; a.stride = stride; a.pad = pad; a.dil = dil;
+  a.src = a.wt = dummy; a.dst = dummy;
+  a.addend = has_addend ? dummy : nullptr;
+  a.bias = has_bias ? dummy : nullptr;
+  return css_conv_c64_supported(a, dtype) ? 1 : 0;
+}
+int css_conv_c64_set_enabled(int on) { return css_conv_c64_set_enabled_(on); }
 int css_wgrad_splits(int M, int Ktot, int Cout, int dtype, int n_cu) {
   int splits = 0, mps = 0;
   css_wgrad_plan_(M, Ktot, Cout, dtype, n_cu > 0 ? n_cu : 256, &splits, &mps);

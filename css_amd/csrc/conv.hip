@@ -852,7 +852,12 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
       return CSS_ERR_ARG;
     static const bool no_dma = getenv("CSS_NO_DMA_CONV") != nullptr;
     const ConvPlan plan = conv_plan(a, dtype, n_cu);
-    if (plan == PLAN_WS) {
+    if (!no_dma && css_conv_c64_supported(a, dtype)) {
+      // 3x3 stride 1 on 64 input channels (layer 1's conv2 and its data gradient, the deep stem): the patch-in-LDS kernel, every row in one launch (conv_c64.hip)
+      P0(false, 1.0);
+      css_launch_conv_c64(a, n_cu, st);
+      P1();
+    } else if (plan == PLAN_WS) {
       // short-K 1x1 (conv3 of a Bottleneck forward, conv1 backward): weight-stationary kernel, every row in one launch (conv_ws.hip)
       P0(true, 1.0, true);
       css_launch_conv_ws(a, n_cu, st);

@@ -58,6 +58,9 @@ struct LaunchProf {
 int css_launch_conv(const ConvArgs& a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof = nullptr);
 bool css_conv_pp_supported(const ConvArgs& a);
+bool css_conv_c64_supported(const ConvArgs& a, int dtype);      // conv_c64.hip: 3x3 s1 p1, 64 input channels, 64 / 128 output channels
+void css_launch_conv_c64(ConvArgs a, int n_cu, hipStream_t st);
+int css_conv_c64_set_enabled_(int on);                           // returns the previous state
 int css_conv_pp_plan(const ConvArgs& a, int n_cu);
 void css_launch_conv_pp(ConvArgs a, int grid, hipStream_t st);
 int css_conv_tile_rows_(const ConvArgs& a, int dtype, int n_cu);

@@ -68,6 +68,14 @@ CSS_API int css_conv2d_forward_bnstats_tile_rows(const void* x, const void* w, v
  * 0 when it takes the 256x256-tile kernels.  M = output rows, ld_* = row pitches in elements, n_cu = css_device_cu_count(). */
 CSS_API int css_conv_ws_applies(int M, int K, int ld_src, int N, int ld_dst, int R, int S, int stride, int pad, int has_stats, int has_addend,
                                 int ld_add, int has_bias, int dtype, int n_cu);
+/* host-side query (no launch): 1 when css_conv2d_forward[_bnstats] / css_conv2d_dgrad run this product on the patch-in-LDS kernel of the 3x3
+ * stride-1 pad-1 convolutions with 64 input channels (csrc/conv_c64.hip: conv2 of the layer-1 Bottlenecks - resnet.py:126-129 - forward and
+ * data gradient, the deep stem's second and third convolution - resnet.py:177-190), 0 when it takes the implicit-GEMM kernels.  Cin / Cout =
+ * channels of the gathered tensor / of the result; ld_* = row pitches in elements.  css_conv_c64_set_enabled(0) sends these shapes back to the
+ * implicit-GEMM kernels (the A/B reference of tests/test_conv_c64_gpu.py; CSS_NO_C64_CONV=1 is the process-wide form) and returns the old state. */
+CSS_API int css_conv_c64_applies(int N, int H, int W, int Cin, int ld_src, int Cout, int ld_dst, int R, int S, int stride, int pad, int dil,
+                                 int has_addend, int has_bias, int dtype);
+CSS_API int css_conv_c64_set_enabled(int on);
 /* w_t: weights re-laid out as [Cin][R][S][Cout] (css_weight_layout dgrad=1); stride 1 or 2 */
 CSS_API int css_conv2d_dgrad(const void* dy, const void* w_t, void* dx, int N, int H, int W, int Cin, int lddx, int Ho, int Wo, int Cout, int lddy,
                              int R, int S, int stride, int pad, int dil, double alg_flops, int dtype, int device, css_stream_t stream);

@@ -5,6 +5,7 @@
 #include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
+#include "../css_amd/csrc/conv_c64.hip"
 #include <cstdio>
 #include <vector>
 #include <cstdlib>

@@ -8,6 +8,7 @@
 #include "proto/conv_pp64.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
+#include "../css_amd/csrc/conv_c64.hip"
 #define G8_NO_MAIN
 #include "gemm8p.hip"
 #include <algorithm>

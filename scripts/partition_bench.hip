@@ -15,6 +15,7 @@
 #include "../css_amd/csrc/conv_pp.hip"
 #include "../css_amd/csrc/conv_p8.hip"
 #include "../css_amd/csrc/conv_ws.hip"
+#include "../css_amd/csrc/conv_c64.hip"
 #include "../css_amd/csrc/bn.hip"
 #include <chrono>
 #include <cstdio>

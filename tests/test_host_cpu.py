@@ -397,6 +397,90 @@ def test_conv_ws_kernel_isa_and_shape_rules(tmp_path):
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
 
 
+def test_conv_c64_kernel_isa(tmp_path):
+    """conv3x3_c64_kernel (csrc/conv_c64.hip): the double-buffered patch in ONE LDS object (2 x 56 KiB: 51 pieces + 5 of padding, + 2 KiB of statistics carry), 144 VGPRs
+    of weights and no scratch in any instance, 18 K blocks x (2 or 4 pixel tiles) x 2 channel tiles of v_mfma_f32_16x16x32_bf16, the counted wait
+    for the patch (the stores of the previous tile stay in flight: vmcnt = stores per tile and wave) and no compiler-inserted drain inside the K loop."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "css_amd", "csrc", "conv_c64.hip")
+    out = str(tmp_path / "conv_c64.s")
+    subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-munsafe-fp-atomics", "-S", "--cuda-device-only", src, "-o", out],
+                   check=True, capture_output=True, timeout=600)
+    lines = open(out).read().split("\n")
+    for nwc, st, dg in ((2, 1, 0), (2, 0, 0), (4, 1, 0), (4, 0, 0), (2, 0, 1)):
+        sym = f"_Z18conv3x3_c64_kernelILi{nwc}ELb{st}ELb{dg}EEv8ConvArgs:"
+        start = next(i for i, l in enumerate(lines) if l.startswith(sym))
+        end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+        body = lines[start:end]
+        ni = 8 // (8 // nwc)           # pixel tiles per wave: 128 / (8 / nwc) / 16
+        mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
+        assert len(mfma) in (18 * ni * 2, 2 * 18 * ni * 2), (sym, len(mfma))          # (the K loop exists twice: with and without the validity mask)
+        bar = [i for i, l in enumerate(body) if "s_barrier" in l]
+        # every vmcnt wait of the kernel is accounted for: the 36 waits of the weight fragments in the prologue (vmcnt(42) .. vmcnt(7): the first
+        # patch stays in flight), the loop-top wait of the first tile (0) and of the later ones (the stores of a tile), and the drain before
+        # s_endpgm - a wait the compiler adds inside the K loop (it did, before the LDS was ONE object) would make it 40
+        waits = [l.split("vmcnt(")[1].split(")")[0] for l in body if "s_waitcnt" in l and "vmcnt(" in l]
+        assert sorted(map(int, waits)) == sorted(list(range(7, 43)) + [0, 0, ni + (4 if st else 0)]), (sym, waits)
+        nst = ni + (4 if st else 0)
+        assert any(f"s_waitcnt vmcnt({nst})" in l for l in body), (sym, nst)
+        assert len(bar) >= (2 if st else 1) and len(bar) % (2 if st else 1) == 0, (sym, len(bar))      # (the compiler peels the first tile)
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 2 * 56 * 1024 + (2048 if st else 0), sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
+
+
+def test_conv_c64_index_maps():
+    """The index arithmetic of conv3x3_c64_kernel, replayed on the host: (1) the LDS-DMA pieces of a tap row put source chunk c of range position p
+    at 16-byte position c ^ ((p >> 1) & 7) of LDS row p, every (position < 136, chunk) exactly once; (2) the fragment read of lane (l15, lg), pixel
+    group pg, pixel tile i, column tap b, channel half hh returns position pxw pg + 16 i + l15 + b, chunk 4 hh + lg, from three lane registers, and
+    the 64 lanes of one ds_read_b128 spread evenly over the 64 banks; (3) range position <-> image pixel: position p of tap row a of tile t is
+    pixel t 128 + (a - 1) W - 1 + p, i.e. output pixel m reads (y + a - 1, x + b - 1) at position (m - 128 t) + b when that pixel is inside the image."""
+    lds = {}
+    for wave in range(8):
+        for i in range(7):
+            p = wave * 7 + i
+            if p >= 51:
+                continue
+            ar, c = divmod(p, 17)
+            for lane in range(64):
+                pos = 8 * c + (lane >> 3)
+                chunk = (lane & 7) ^ ((pos >> 1) & 7)
+                addr = p * 1024 + lane * 16
+                assert addr == ar * 17408 + pos * 128 + (lane & 7) * 16
+                assert addr not in lds
+                lds[addr] = (ar, pos, chunk)
+    assert len(lds) == 3 * 136 * 8
+    for pxw in (32, 64):
+        for pg in range(128 // pxw):
+            for i in range(pxw // 16):
+                for ar in range(3):
+                    for b in range(3):
+                        for hh in range(2):
+                            slots = []
+                            for lane in range(64):
+                                l15, lg = lane & 15, lane >> 4
+                                lb = (l15 + b) * 128 + ((lg ^ (((l15 + b) >> 1) & 7)) << 4)
+                                addr = pxw * pg * 128 + (lb ^ (hh << 6)) + ar * 17408 + i * 2048
+                                assert lds[addr] == (ar, pxw * pg + 16 * i + l15 + b, 4 * hh + lg), (pxw, pg, i, ar, b, hh, lane)
+                                slots.append(addr)
+                            banks = [((a_ // 4) + d) % 64 for a_ in slots for d in range(4)]
+                            assert all(banks.count(k) == 4 for k in range(64))
+    import random
+    rnd = random.Random(5)
+    for _ in range(2000):
+        h, w, n = rnd.randint(1, 40), rnd.randint(1, 40), rnd.randint(1, 3)
+        m = rnd.randrange(n * h * w)
+        t, a, b = m // 128, rnd.randrange(3), rnd.randrange(3)
+        img, r = divmod(m, h * w)
+        y, x = divmod(r, w)
+        pix = t * 128 + (a - 1) * w - 1 + (m - 128 * t) + b
+        if 0 <= y + a - 1 < h and 0 <= x + b - 1 < w:
+            assert pix == (img * h + (y + a - 1)) * w + (x + b - 1)
+
+
 def test_conv_ws_vmcnt_accounting_model():
     """conv_ws_kernel waits for "my two LDS-DMA pieces of stage s" with s_waitcnt vmcnt(W): vector-memory operations retire in order, so
     the wait is correct iff W <= the number of operations the wave issued AFTER those pieces, and free of unnecessary stalls iff W equals

@@ -160,8 +160,9 @@ def test_eager_residual_gradient_switch_is_a_shipped_configuration():
     assert r.returncode == 0, r.stdout[-800:]
 
 
-@pytest.mark.parametrize("env,select", [({"CSS_MAXPOOL_BWD_GENERIC": "1"}, "maxpool"), ({"CSS_NO_BN_POOL": "1"}, "blocks"), ({"CSS_WGRAD_N64": "1"}, "stemconv")],
-                         ids=["CSS_MAXPOOL_BWD_GENERIC=1", "CSS_NO_BN_POOL=1", "CSS_WGRAD_N64=1"])
+@pytest.mark.parametrize("env,select", [({"CSS_MAXPOOL_BWD_GENERIC": "1"}, "maxpool"), ({"CSS_NO_BN_POOL": "1"}, "blocks"), ({"CSS_WGRAD_N64": "1"}, "stemconv"),
+                                        ({"CSS_NO_C64_CONV": "1"}, "layer1")],
+                         ids=["CSS_MAXPOOL_BWD_GENERIC=1", "CSS_NO_BN_POOL=1", "CSS_WGRAD_N64=1", "CSS_NO_C64_CONV=1"])
 def test_round5_stem_region_switches_are_shipped_configurations(env, select):
     """Round 5: CSS_MAXPOOL_BWD_GENERIC=1 (the generic max-pool adjoint instead of the 3x3 s2 p1 form: the pooling tests against F.max_pool2d) and
     CSS_NO_BN_POOL=1 (the stem's max pool as a pass of its own behind bn_apply: the stem block tests against the reference's golden vectors), each
@@ -171,7 +172,10 @@ def test_round5_stem_region_switches_are_shipped_configurations(env, select):
     # (CSS_WGRAD_N64=1: the Cout <= 64 weight gradients on 64 x 64 tiles - the stem's weight gradient against torch-CPU)
     target = {"maxpool": [os.path.join(ROOT, "tests", "test_ops_gpu.py"), "-k", "maxpool"],
               "blocks": [os.path.join(ROOT, "tests", "test_blocks_gpu.py"), "-k", "stem"],
-              "stemconv": [os.path.join(ROOT, "tests", "test_conv_stem_gpu.py"), "-k", "forward_stats_and_wgrad"]}[select]
+              "stemconv": [os.path.join(ROOT, "tests", "test_conv_stem_gpu.py"), "-k", "forward_stats_and_wgrad"],
+              # (CSS_NO_C64_CONV=1: layer 1's 3x3 convolutions and the deep stem back on the implicit-GEMM kernels - the Bottleneck and stem blocks
+              # against the reference's golden vectors)
+              "layer1": [os.path.join(ROOT, "tests", "test_blocks_gpu.py")]}[select]
     r = subprocess.run([sys.executable, "-m", "pytest"] + target + ["-q", "-x", "-m", "gpu"], env=e, capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-600:], r.stderr[-400:])
     assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-800:]
