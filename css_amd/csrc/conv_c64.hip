@@ -108,7 +108,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
       const int pos = 8 * c + (lane >> 3);
       const int P = m0 + (ar - 1) * W - 1 + pos;
       const bool ok = p < NPIECE && t < ntiles && P >= 0 && P < M;
+#ifndef C6_ABL_NODMA      // (timing ablations for scripts/conv_bench.hip: C6_ABL_NODMA / _NOMFMA / _NOSTORE; results are garbage)
       c6_dma16(rs_a, base + p * 1024, ok ? (unsigned)P * lds2 + (unsigned)(((lane & 7) ^ ((pos >> 1) & 7)) * 16) : C6_OOB);
+#else
+      (void)base; (void)ok;
+#endif
     }
   };
   int t = pos0;
@@ -165,23 +169,36 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 
     const unsigned char* const pb = smem + cur * BUF + (PXW * pg) * 128;
-#pragma unroll
-    for (int q = 0; q < KB; ++q) {
+    // the fragments of K block q + 1 are requested BEFORE the MFMAs of block q (two sets of NI registers): with 4 or 8 MFMAs per block and
+    // wave the LDS latency would otherwise be exposed once per block
+    auto read_frags = [&](int q, bf16x8 (&fa)[NI]) {
       const int tp = DGRAD ? 8 - (q >> 1) : (q >> 1), ar = tp / 3, b = tp - 3 * ar, hh = q & 1;
-      bf16x8 fa[NI];
 #pragma unroll
       for (int i = 0; i < NI; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(pb + (lb[b] ^ (hh << 6)) + ar * RB + i * 2048);
-      if (!all_in) {
+    };
+    auto mask_frags = [&](int q, bf16x8 (&fa)[NI]) {
+      const int tp = DGRAD ? 8 - (q >> 1) : (q >> 1);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          const bool ok = (vm[i] >> tp) & 1u;
-          c6_u32x4 u = __builtin_bit_cast(c6_u32x4, fa[i]);
+      for (int i = 0; i < NI; ++i) {
+        const bool ok = (vm[i] >> tp) & 1u;
+        c6_u32x4 u = __builtin_bit_cast(c6_u32x4, fa[i]);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
-          fa[i] = __builtin_bit_cast(bf16x8, u);
-        }
+        for (int e = 0; e < 4; ++e) u[e] = ok ? u[e] : 0u;
+        fa[i] = __builtin_bit_cast(bf16x8, u);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_block = [&](int q, const bf16x8 (&fa)[NI]) {
+#ifdef C6_ABL_NOMFMA
+      if (q == 0) {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int i = 0; i < NI; ++i) asm volatile("" ::"v"(fa[i]));
+      return;
+#endif
       if (q == 0) {
         const f32x4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -194,7 +211,34 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[q][j], fa[i], acc[i][j], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+    };
+    if constexpr (NI <= 2) {
+      bf16x8 fa0[NI], fa1[NI];
+      read_frags(0, fa0);
+#pragma unroll
+      for (int q = 0; q < KB; q += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        read_frags(q + 1, fa1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!all_in) mask_frags(q, fa0);
+        mfma_block(q, fa0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 2 < KB) read_frags(q + 2, fa0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!all_in) mask_frags(q + 1, fa1);
+        mfma_block(q + 1, fa1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {        // (four pixel tiles per wave: a second fragment set would spill; eight MFMAs per block cover more of the latency)
+#pragma unroll
+      for (int q = 0; q < KB; ++q) {
+        bf16x8 fa[NI];
+        read_frags(q, fa);
+        if (!all_in) mask_frags(q, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_block(q, fa);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     cur ^= 1;
 
@@ -223,7 +267,11 @@ __global__ __launch_bounds__(512) void conv3x3_c64_kernel(const ConvArgs a) {
         c6_swap16(lo[0], lo[1]);
         c6_swap16(hi[0], hi[1]);
         const c6_u32x4 vv = {lo[0], hi[0], lo[1], hi[1]};
+#ifdef C6_ABL_NOSTORE
+        __builtin_amdgcn_raw_buffer_store_b128(vv, rs_d, (int)C6_OOB, 0, 0);
+#else
         __builtin_amdgcn_raw_buffer_store_b128(vv, rs_d, (int)(m < M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)nl) * 2u : C6_OOB), 0, 0);
+#endif
       }
     };
     if (!STATS || whole) out_tiles(false);
