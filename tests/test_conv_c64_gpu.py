@@ -121,3 +121,29 @@ def test_c64_no_statistics_and_repeatability():
     assert s1 is None
     assert rel_err(y1, y_ref) < 2e-2 and rel_err(dx1, dx_ref) < 2e-2
     assert torch.equal(y1, y2) and torch.equal(dx1, dx2)
+
+
+def test_c64_row_pitches_through_the_abi():
+    """The gathered tensor and the result may be slices of wider rows (a concat buffer, a padded channel count): css_conv2d_forward straight
+    through the C ABI with ld_src = 96 and ld_dst = 80 against the contiguous call - bit for bit - and nothing written outside the 64 channels."""
+    from css_amd import _lib
+    from css_amd._lib import call, dev_stream
+    n, h, w = 2, 37, 41
+    g = torch.Generator().manual_seed(5)
+    x = bf16_round(torch.randn(n, h, w, 64, generator=g))
+    wt = bf16_round(torch.randn(64, 3, 3, 64, generator=g) / 24.0)
+    xw = torch.full((n, h, w, 96), 7.0).to(dev(), torch.bfloat16)
+    xw[..., :64] = x.to(dev(), torch.bfloat16)
+    xc = x.to(dev(), torch.bfloat16).contiguous()
+    wg = wt.to(dev(), torch.bfloat16).contiguous()            # [Cout][R][S][Cin]: the forward layout
+    yw = torch.full((n, h, w, 80), -3.0, device=dev(), dtype=torch.bfloat16)
+    yc = torch.empty((n, h, w, 64), device=dev(), dtype=torch.bfloat16)
+    d, st = dev_stream(xc)
+    assert _lib.query("css_conv_c64_applies", n, h, w, 64, 96, 64, 80, 3, 3, 1, 1, 1, 0, 0, 1) == 1
+    call("css_conv2d_forward", xw, wg, None, yw, n, h, w, 64, 96, h, w, 64, 80, 3, 3, 1, 1, 1, 0.0, 1, d, st)
+    call("css_conv2d_forward", xc, wg, None, yc, n, h, w, 64, 64, h, w, 64, 64, 3, 3, 1, 1, 1, 0.0, 1, d, st)
+    torch.cuda.synchronize()
+    assert torch.equal(yw[..., :64], yc)
+    assert bool((yw[..., 64:] == -3.0).all())
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wt.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert rel_err(yc.float().cpu(), ref) < 2e-2
