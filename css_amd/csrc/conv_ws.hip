@@ -151,6 +151,11 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   static_assert(LA >= KS || !ADD, "the half-tile look-ahead has no addend form");
   static_assert(W2 <= 63, "vmcnt is a 6-bit counter");
   constexpr int OB = ROWS ? BM * 512 : 0;                        // the output tile of the panel: 128 rows x 512 bytes
+#ifdef WS_NO_MFMA_STATS      // (harness: the statistics of every tile on the VALU path, as the first row-form build)
+  constexpr bool MSTAT = false;
+#else
+  constexpr bool MSTAT = STATS && ROWS;
+#endif
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STG + OB];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -257,13 +262,13 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
     for (int j = 0; j < 2; ++j) s01[j] = s23[j] = q01[j] = q23[j] = ws_f32x2{0.f, 0.f};
     const bool whole = m0e + BM <= bnd;
     // pixel tile i: pack (the statistics see the packed values), exchange -> lane (l15, lg) holds 8 consecutive channels of pixel 16 i + l15
-    auto pack_tile = [&](int i, bool test) -> ws_u32x4 {
+    auto pack_tile = [&](int i, bool test, bool accumulate = true) -> ws_u32x4 {
       unsigned lo[2], hi[2];
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         lo[j] = ws_pack2(acc[i][j][0], acc[i][j][1]);
         hi[j] = ws_pack2(acc[i][j][2], acc[i][j][3]);
-        if (STATS) {
+        if (STATS && accumulate) {
           ws_f32x2 v01 = {ws_lo(lo[j]), ws_hi(lo[j])}, v23 = {ws_lo(hi[j]), ws_hi(hi[j])};
           if (test && !(m0e + 16 * i + l15 < bnd)) { v01 = ws_f32x2{0.f, 0.f}; v23 = ws_f32x2{0.f, 0.f}; }   // (rows >= M hold zeros already)
           s01[j] += v01; s23[j] += v23;
@@ -284,12 +289,60 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       int wb0 = NS * STG + l15 * 512 + ((cc ^ l15) << 4);
       int rb0 = NS * STG + (16 * wave + (lane >> 5)) * 512 + ((((lane & 31) ^ (16 * (wave & 1) + (lane >> 5)))) << 4);
       asm volatile("" : "+v"(wb0), "+v"(rb0));
-      auto to_lds = [&](bool test) {
+      auto to_lds = [&](bool test, bool accumulate) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) *reinterpret_cast<ws_u32x4*>(smem + (wb0 ^ ((i & 1) << 8)) + i * 8192) = pack_tile(i, test);
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<ws_u32x4*>(smem + (wb0 ^ ((i & 1) << 8)) + i * 8192) = pack_tile(i, test, accumulate);
       };
-      if (!STATS || whole) to_lds(false);
-      else to_lds(true);
+      if (!STATS || (MSTAT && whole)) to_lds(false, false);
+      else if (whole) to_lds(false, true);
+      else to_lds(true, true);
+      if constexpr (MSTAT) {
+        if (whole) {
+          // Round 5: the statistics of a whole tile on the MATRIX pipe (idle in the epilogue) instead of ~190 VALU instructions per wave: my 128 pixels x 32
+          // channels come back from the LDS tile TRANSPOSED (ds_read_b64_tr_b16: lane (l15, lg) gets channel 16 j + l15 of pixels 8 lg .. 8 lg + 7 of a
+          // 32-pixel block - the A operand of v_mfma_f32_16x16x32_bf16 with K = pixels, and equally its B operand); per 16 channels and 32 pixels
+          // D_sq += F x F (the Gram matrix: its diagonal is the sum of squares) and D_sum += F x ones (every column the channel sums).  The sums arrive in
+          // the lanes the DPP path leaves them in; the diagonal is fetched with four ds_bpermute.  bf16 x bf16 products are exact in fp32, so this is
+          // the same quantity summed in another (fixed) order; a tile that straddles a statistics-group boundary keeps the VALU path with its row test.
+          // (inline asm on purpose: through the builtin the waitcnt pass sees an LDS read that may alias the LDS-DMA pieces in flight and drains
+          // them all - s_waitcnt vmcnt(0) once per tile - as csrc/conv_wgrad.hip found; the tile read here was written by this wave's own ds_writes)
+          const int q4 = l15 >> 2, p4 = l15 & 3, R = 8 * lg + q4;
+          unsigned tb0 = (unsigned)(uintptr_t)(ws_lds_void*)(smem + NS * STG) + (unsigned)(R * 512 + (((4 * wave + (p4 >> 1)) ^ R) << 4) + 8 * (p4 & 1));
+          asm volatile("" : "+v"(tb0));
+          const bf16x8 ones = __builtin_bit_cast(bf16x8, ws_u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const unsigned ta = tb0 ^ (unsigned)(32 * j), tb = ta ^ 64u;
+            s16x4 fa4[4], fb4[4];
+            asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:2048\n\t"
+                         "ds_read_b64_tr_b16 %2, %8 offset:16384\n\tds_read_b64_tr_b16 %3, %9 offset:18432\n\t"
+                         "ds_read_b64_tr_b16 %4, %8 offset:32768\n\tds_read_b64_tr_b16 %5, %9 offset:34816\n\t"
+                         "ds_read_b64_tr_b16 %6, %8 offset:49152\n\tds_read_b64_tr_b16 %7, %9 offset:51200\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(fa4[0]), "=&v"(fb4[0]), "=&v"(fa4[1]), "=&v"(fb4[1]), "=&v"(fa4[2]), "=&v"(fb4[2]), "=&v"(fa4[3]), "=&v"(fb4[3])
+                         : "v"(ta), "v"(tb)
+                         : "memory");
+            f32x4 dsum = {0.f, 0.f, 0.f, 0.f}, dsq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+              union { struct { s16x4 a, b; } h; bf16x8 f; } u;
+              u.h.a = fa4[kc];
+              u.h.b = fb4[kc];
+              dsq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f, u.f, dsq, 0, 0, 0);
+              dsum = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f, ones, dsum, 0, 0, 0);
+            }
+            // D[channel 4 lg + r][column l15]: every column of dsum is the channel sums; the diagonal of dsq sits in lane l15 = 4 lg + r, register r
+            const float dg = p4 == 0 ? dsq[0] : p4 == 1 ? dsq[1] : p4 == 2 ? dsq[2] : dsq[3];
+            s01[j] = ws_f32x2{dsum[0], dsum[1]};
+            s23[j] = ws_f32x2{dsum[2], dsum[3]};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const float v = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((20 * lg + r) * 4, __builtin_bit_cast(int, dg)));
+              if (r == 0) q01[j][0] = v; else if (r == 1) q01[j][1] = v; else if (r == 2) q23[j][0] = v; else q23[j][1] = v;
+            }
+          }
+        }
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -352,10 +405,18 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
       const __amdgpu_buffer_rsrc_t rs_s = __builtin_amdgcn_make_buffer_rsrc(a.stats, 0, (int)a.stat_bytes, 0x00020000);
       const unsigned base = (unsigned)(m0e >> 7) * 2u * (unsigned)a.Cd * 4u;
       ws_f32x4 o[2][2];
+      if (MSTAT && whole) {      // (the matrix-pipe path left the totals in every lane of a lane row already)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        o[j][0] = ws_f32x4{ws_row16_sum(s01[j][0]), ws_row16_sum(s01[j][1]), ws_row16_sum(s23[j][0]), ws_row16_sum(s23[j][1])};
-        o[j][1] = ws_f32x4{ws_row16_sum(q01[j][0]), ws_row16_sum(q01[j][1]), ws_row16_sum(q23[j][0]), ws_row16_sum(q23[j][1])};
+        for (int j = 0; j < 2; ++j) {
+          o[j][0] = ws_f32x4{s01[j][0], s01[j][1], s23[j][0], s23[j][1]};
+          o[j][1] = ws_f32x4{q01[j][0], q01[j][1], q23[j][0], q23[j][1]};
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          o[j][0] = ws_f32x4{ws_row16_sum(s01[j][0]), ws_row16_sum(s01[j][1]), ws_row16_sum(s23[j][0]), ws_row16_sum(s23[j][1])};
+          o[j][1] = ws_f32x4{ws_row16_sum(q01[j][0]), ws_row16_sum(q01[j][1]), ws_row16_sum(q23[j][0]), ws_row16_sum(q23[j][1])};
+        }
       }
       ws_f32x4 ov;
 #pragma unroll
