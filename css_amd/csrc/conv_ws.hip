@@ -16,9 +16,10 @@
 //     and hits that XCD's L2 three times); 128-row tiles quantise to the chip well enough (1057 tiles x 4 panels on 256 CUs = 16.5
 //     rounds) that there is no leftover launch;
 //   * the epilogue (round 5: the ROW form) packs the tile to bf16 in registers (v_permlane16_swap: 8 consecutive channels per lane),
-//     accumulates the BN statistics of the packed values in the same loop (slabs of 128 rows, which a wave owns whole: ONE 16-lane store
-//     per wave and tile), passes the tile through a 64 KiB LDS buffer (one barrier) and stores it two whole 512-byte panel rows per
-//     instruction.  Why: a store instruction that writes 16 HALF cache lines (what a wave's 32 channels give) slows the in-order
+//     passes the tile through a 64 KiB LDS buffer (one barrier) and stores it two whole 512-byte panel rows per instruction; the BN statistics
+//     (slabs of 128 rows, which a wave owns whole: ONE 16-lane store per wave and tile) come from the LDS tile on the MATRIX pipe - transposed
+//     reads of the wave's own 128 x 32 block, Gram diagonal + product with ones - or, for the one tile per statistics group that straddles its
+//     boundary, from the packing loop.  Why: a store instruction that writes 16 HALF cache lines (what a wave's 32 channels give) slows the in-order
 //     vector-memory path that the LDS-DMA stream shares - the fill + store skeleton of the kernel cost 90 us where its fill alone takes 24
 //     and its stores alone 44; with whole lines it is 73 (profiles/r05_ws_skeleton*.txt, r05_ws_seg.txt: 128-byte segments already give all
 //     of it).  The residual-gradient addend of css_conv2d_dgrad_add is requested at the START of the tile, in the row form as well (whole
