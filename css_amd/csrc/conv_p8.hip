@@ -92,7 +92,18 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #ifdef P8_PSTAMPS
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + 8 * 256];     // + 64 stamp words per wave (diagnostic build)
 #else
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF];     // [buffer 0 / 1][A0, A1, B0, B1]
+  // Round 5: the statistics of a whole slab on the MATRIX pipe (conv_ws.hip's form; profiles/r05_p8_mstat.txt): the 32 KiB of LDS beside the ring hold one
+  // 32-pixel x 64-channel slice of the packed tile per wave, written as the store loop produces it and read back transposed (ds_read_b64_tr_b16: the A - and
+  // B - operand of v_mfma_f32_16x16x32_bf16 with K = pixels); per 16 channels F x F (Gram matrix: the diagonal is the sum of squares) and F x ones (the
+  // sums), four slices per tile: 16 ds_write_b128 + 32 transposed reads + 32 MFMAs instead of ~450 VALU instructions per wave.  Same quantity in another
+  // fixed summation order (slabs equal to 3e-7 of their magnitude, outputs untouched); a slab that straddles a statistics-group boundary keeps the
+  // VALU path.  P8_NO_MFMA_STATS (scripts/p8_bench.hip): every slab on the VALU path.
+#ifdef P8_NO_MFMA_STATS
+  constexpr bool MSTAT = false;
+#else
+  constexpr bool MSTAT = STATS;
+#endif
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + (MSTAT ? 8 * 4096 : 0)];     // [buffer 0 / 1][A0, A1, B0, B1]
 #endif
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -464,6 +475,21 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
     // the stores holds the CU until the whole chip's output burst - 256 tiles x 128 KiB at once - has drained: 5-20 % of a launch
     // in profiles/r03_store_stall.txt.)
     if (ti == nmy - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // ---- sums / sums of squares of a WHOLE slab on the matrix pipe (see MSTAT above) ----
+    const bool whole_m = MSTAT && mrow0 + 128 <= bnd;
+    f32x4 dsum[MSTAT ? 4 : 1], dsq[MSTAT ? 4 : 1];
+    unsigned mwb = 0, mtb = 0;
+    if constexpr (MSTAT) {
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) dsum[cb] = dsq[cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const unsigned sbase = (unsigned)(uintptr_t)(p8_lds_void*)(smem + 8 * HALF) + (unsigned)wave * 4096u;
+      // write side: row 16 (i & 1) + l15, chunk 2 (lg & 1) + (lg >> 1) [+ 4 for the second channel pair] at position chunk ^ ((row >> 1) & 7)
+      mwb = sbase + (unsigned)(l15 * 128 + (((2 * (lg & 1) + (lg >> 1)) ^ ((l15 >> 1) & 7)) << 4));
+      // read side (ds_read_b64_tr_b16): lane 4 q + p of lane group lg -> row 8 lg + q, channels 4 p .. of the 16-channel block
+      const int q4 = l15 >> 2, p4 = l15 & 3, R = 8 * lg + q4;
+      mtb = sbase + (unsigned)(R * 128 + ((((p4 >> 1) ^ ((R >> 1) & 7))) << 4) + 8 * (p4 & 1));
+      asm volatile("" : "+v"(mwb), "+v"(mtb));
+    }
     p8_u32x4 radd[ADD ? 8 : 1][2];
     unsigned rmk[ADD ? 8 : 1][2];
     const bool has_mask = ADD && a.add_mask != nullptr;
@@ -511,6 +537,37 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #else
         __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(ok ? rowb + (unsigned)n * 2u : P8_OOB), 0, 0);
 #endif
+        if constexpr (MSTAT) {
+          if (whole_m) {
+            // (row 16 (i & 1) + l15: (row >> 1) & 7 = 8 (i & 1) | (l15 >> 1) -> & 7 = (l15 >> 1) & 7: the lane part covers both i; second pair: chunk + 4 = bit 6)
+            if (i & 1) asm volatile("ds_write_b128 %0, %1 offset:2048" ::"v"((mwb ^ (unsigned)(jp << 5))), "v"(v) : "memory");
+            else asm volatile("ds_write_b128 %0, %1" ::"v"((mwb ^ (unsigned)(jp << 5))), "v"(v) : "memory");
+          }
+        }
+      }
+      if constexpr (MSTAT) {
+        if (whole_m && (i & 1)) {
+          // the slice (pixel tiles i - 1, i: 32 pixels x 64 channels) is in LDS: per 16-channel block one transposed fragment, Gram + ones
+          const bf16x8 ones = __builtin_bit_cast(bf16x8, p8_u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
+          s16x4 fa4[4], fb4[4];
+          const unsigned t0 = mtb, t1 = mtb ^ 32u, t2 = mtb ^ 64u, t3 = mtb ^ 96u;
+          asm volatile("ds_read_b64_tr_b16 %0, %8\n\tds_read_b64_tr_b16 %1, %9 offset:512\n\t"
+                       "ds_read_b64_tr_b16 %2, %9\n\tds_read_b64_tr_b16 %3, %8 offset:512\n\t"
+                       "ds_read_b64_tr_b16 %4, %10\n\tds_read_b64_tr_b16 %5, %11 offset:512\n\t"
+                       "ds_read_b64_tr_b16 %6, %11\n\tds_read_b64_tr_b16 %7, %10 offset:512\n\t"
+                       "s_waitcnt lgkmcnt(0)"
+                       : "=&v"(fa4[0]), "=&v"(fb4[0]), "=&v"(fa4[1]), "=&v"(fb4[1]), "=&v"(fa4[2]), "=&v"(fb4[2]), "=&v"(fa4[3]), "=&v"(fb4[3])
+                       : "v"(t0), "v"(t1), "v"(t2), "v"(t3)
+                       : "memory");
+#pragma unroll
+          for (int cb = 0; cb < 4; ++cb) {
+            union { struct { s16x4 a, b; } h; bf16x8 f; } u;
+            u.h.a = fa4[cb];
+            u.h.b = fb4[cb];
+            dsq[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f, u.f, dsq[cb], 0, 0, 0);
+            dsum[cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(u.f, ones, dsum[cb], 0, 0, 0);
+          }
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -535,12 +592,22 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
             q01 += v01 * v01; q23 += v23 * v23;
           }
         };
-        if (whole) accum(false);
-        else accum(true);
-        const float ss[4] = {s01[0], s01[1], s23[0], s23[1]}, qq[4] = {q01[0], q01[1], q23[0], q23[1]};
         p8_f32x4 os, oq;
+        if (MSTAT && whole_m) {
+          const int p4 = l15 & 3;
+          const float dg = p4 == 0 ? dsq[MSTAT ? j : 0][0] : p4 == 1 ? dsq[MSTAT ? j : 0][1] : p4 == 2 ? dsq[MSTAT ? j : 0][2] : dsq[MSTAT ? j : 0][3];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { os[r] = p8_row16_sum(ss[r]); oq[r] = p8_row16_sum(qq[r]); }
+          for (int r = 0; r < 4; ++r) {
+            os[r] = dsum[MSTAT ? j : 0][r];
+            oq[r] = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((20 * lg + r) * 4, __builtin_bit_cast(int, dg)));
+          }
+        } else {
+          if (whole) accum(false);
+          else accum(true);
+          const float ss[4] = {s01[0], s01[1], s23[0], s23[1]}, qq[4] = {q01[0], q01[1], q23[0], q23[1]};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { os[r] = p8_row16_sum(ss[r]); oq[r] = p8_row16_sum(qq[r]); }
+        }
         const int n = n0w + 16 * j + 4 * lg;
         const bool lane_ok = l15 == 0 && n < a_Cd && mrow0 < a_M;
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(p8_u32x4, os), rs_s, (int)(lane_ok ? base + (unsigned)n * 4u : P8_OOB), 0, 0);

@@ -1,6 +1,6 @@
 // conv_igemm_p8_kernel (conv_p8.hip) against conv_igemm_pp64_kernel (conv_pp64.hip) on the bench shapes, same launch schedule:
-//   * parity: outputs (and statistics slabs / addend form) must be BIT-IDENTICAL (same MFMA instruction on the same K blocks in the
-//     same order), compared element by element;
+//   * parity: outputs (and the addend form) must be BIT-IDENTICAL (same MFMA instruction on the same K blocks in the same order), compared
+//     element by element; the statistics slabs to 1e-5 of their magnitude (round 5: summed on the matrix pipe; -DP8_NO_MFMA_STATS: bit-identical);
 //   * race screen: P8_RACE (default 50) repeated launches of the new kernel must reproduce its first result bit for bit;
 //   * timing: both kernels in interleaved rounds in one process (min / median over rounds), uniform random operands in [-1, 1).
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics scripts/p8_bench.hip -o build/p8_bench && ./build/p8_bench
@@ -14,6 +14,7 @@
 #define G8_NO_MAIN
 #include "gemm8p.hip"
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -99,11 +100,21 @@ int main() {
       size_t mism = 0;
       for (size_t i = 0; i < ny; ++i) mism += h0[i] != h1[i];
       size_t smism = 0;
+      double srel = 0;         // largest difference of a statistics entry relative to the largest entry (P8_MFMA_STATS: another summation order)
       if (ep == 1) {
         std::vector<float> s0(nstat), s1(nstat);
         hipMemcpy(s0.data(), dstat[0], nstat * 4, hipMemcpyDeviceToHost);
         hipMemcpy(s1.data(), dstat[1], nstat * 4, hipMemcpyDeviceToHost);
-        for (size_t i = 0; i < nstat; ++i) smism += memcmp(&s0[i], &s1[i], 4) != 0;
+        double smax = 0, sd = 0;
+        for (size_t i = 0; i < nstat; ++i) {
+          smism += memcmp(&s0[i], &s1[i], 4) != 0;
+          if (fabs((double)s0[i]) > smax) smax = fabs((double)s0[i]);
+          if (!(fabs((double)s0[i] - (double)s1[i]) <= sd)) sd = fabs((double)s0[i] - (double)s1[i]);
+        }
+        srel = sd / (smax + 1e-30);
+#ifndef P8_NO_MFMA_STATS     // (the shipped kernel sums a slab on the matrix pipe: the same quantity in another order than pp64's VALU sums)
+        if (srel <= 1e-5) smism = 0;
+#endif
       }
       int racebad = 0;
       for (int r = 0; r < (ep == 0 ? nrace : 5); ++r) {
@@ -137,9 +148,9 @@ int main() {
       const double flops = 2.0 * M * s.Cout * a.Ktot;
       const bool ok = mism == 0 && smism == 0 && racebad == 0;
       bad_total += !ok;
-      printf("%-32s %-6s M=%d K=%d N=%d  pp64 %8.1f us (%6.1f TF)  p8 %8.1f us (%6.1f TF)  median p8/pp64 %.3f  mismatch %zu stats %zu racebad %d  %s\n", s.name,
+      printf("%-32s %-6s M=%d K=%d N=%d  pp64 %8.1f us (%6.1f TF)  p8 %8.1f us (%6.1f TF)  median p8/pp64 %.3f  mismatch %zu stats %zu (rel %.2g) racebad %d  %s\n", s.name,
              ep == 0 ? "plain" : ep == 1 ? "stats" : "addend", M, a.Ktot, s.Cout, us[0][0], flops / us[0][0] * 1e-6, us[1][0], flops / us[1][0] * 1e-6,
-             us[1][rounds / 2] / us[0][rounds / 2], mism, smism, racebad, ok ? "OK" : "FAIL");
+             us[1][rounds / 2] / us[0][rounds / 2], mism, smism, srel, racebad, ok ? "OK" : "FAIL");
       printf("%-32s        one workgroup per tile: p8 %8.1f us (%6.1f TF) median / pp64 persistent %.3f;  pp64 %8.1f us (%6.1f TF) median / pp64 persistent %.3f\n", "",
              us[3][0], flops / us[3][0] * 1e-6, us[3][rounds / 2] / us[0][rounds / 2], us[4][0], flops / us[4][0] * 1e-6, us[4][rounds / 2] / us[0][rounds / 2]);
       if (gemm) printf("%-32s        gemm8p (yardstick, one workgroup per tile) %8.1f us (%6.1f TF)  median gemm8p/pp64 %.3f  mismatch vs pp64 %zu\n", "", us[2][0],

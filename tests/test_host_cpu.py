@@ -254,13 +254,18 @@ def test_conv_p8_kernel_isa(tmp_path):
         end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
         body = lines[start:end]
         mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
-        assert len(mfma) == 4 * 16, (sym, len(mfma))
-        assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1]), sym       # (the only vmcnt(0) is the one before s_endpgm)
+        stats = "ILb1ELb0EE" in sym
+        # (the statistics instance carries 4 x 8 more in its epilogue: the slab's sums and sums of squares on the matrix pipe, round 5)
+        assert len(mfma) == 4 * 16 + (32 if stats else 0), (sym, len(mfma))
+        mfma = mfma[:64]                                                               # the K loop
+        assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1]), sym       # (the only vmcnt(0) are the last tile's drain and the one before s_endpgm)
+        if stats:
+            assert sum("ds_read_b64_tr_b16" in l for l in body) == 32 and sum("ds_write_b128" in l for l in body) == 16, sym
         assert sum("s_waitcnt vmcnt(6)" in l for l in body) >= 2, sym                  # prologue + phase 4 of the K loop
         assert not any("s_setprio" in l for l in body), sym                            # (measured slower here: conv_p8.hip)
         assert sum("s_barrier" in l for l in body[mfma[0]:mfma[-1] + 1]) >= 6, sym       # (+ the two around the loop edge)
         assert not any("scratch_" in l for l in body), sym
-        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 8 * 128 * 128, sym
+        assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 8 * 128 * 128 + (8 * 4096 if stats else 0), sym
         assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0, sym
 
 
