@@ -90,6 +90,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   constexpr int HALF = 128 * 128;                                // one half-tile: 128 rows of 128 bytes
   constexpr int NEPI = 16 + (STATS ? 8 : 0);                     // store instructions of an epilogue (the addend loads of ADD are consumed inside it)
 #ifdef P8_PSTAMPS
+  constexpr bool MSTAT = false;                                  // (the diagnostic build keeps its stamp words where the statistics slices would sit)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[8 * HALF + 8 * 256];     // + 64 stamp words per wave (diagnostic build)
 #else
   // Round 5: the statistics of a whole slab on the MATRIX pipe (conv_ws.hip's form; profiles/r05_p8_mstat.txt): the 32 KiB of LDS beside the ring hold one
