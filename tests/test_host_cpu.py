@@ -489,6 +489,82 @@ def test_conv_c64_index_maps():
             assert pix == (img * h + (y + a - 1)) * w + (x + b - 1)
 
 
+def _tr16_gather(addr_of_lane, element_at):
+    """ds_read_b64_tr_b16 of one 16-lane group (cdna_hip_programming.md T10): lane 4 q + p supplies the address of row q, columns 4 p .. 4 p + 3 of a 4 x 16
+    block of 16-bit elements; lane i receives column i of the four rows (row q in its element q)."""
+    block = [[None] * 16 for _ in range(4)]
+    for q in range(4):
+        for p in range(4):
+            a0 = addr_of_lane(4 * q + p)
+            assert a0 % 8 == 0
+            for t in range(4):
+                block[q][4 * p + t] = element_at(a0 + 2 * t)
+    return [[block[q][i] for q in range(4)] for i in range(16)]
+
+
+def test_matrix_pipe_statistics_index_maps():
+    """The batch-norm statistics of conv_ws_kernel and conv_igemm_p8_kernel on the matrix pipe (round 5), replayed on the host: the epilogue's LDS image of
+    the packed tile, read back with ds_read_b64_tr_b16 through the kernels' address arithmetic (one base register, XOR constants for the channel block and the
+    second four rows, immediates for the 32-pixel blocks), must hand lane (l15, lg) the eight pixels 8 lg .. 8 lg + 7 of a 32-pixel block for channel
+    16 j + l15 - the A (and B) operand of v_mfma_f32_16x16x32_bf16 with K = pixels; and the ds_bpermute addresses must fetch the Gram diagonal."""
+    # ---- conv_ws_kernel: the 128 x 256 output tile of the row form, chunk c of row r at position c ^ (r & 31) ----
+    img = {}
+    for w in range(8):
+        for i in range(8):
+            for lane in range(64):
+                l15, lg = lane & 15, lane >> 4
+                r, cc = 16 * i + l15, 4 * w + 2 * (lg & 1) + (lg >> 1)
+                for e in range(8):
+                    img[r * 512 + ((cc ^ (r & 31)) << 4) + 2 * e] = (r, 8 * cc + e)          # (pixel, channel of the panel)
+    assert len(img) == 128 * 256
+    for w in range(8):
+        for j in range(2):
+            for kc in range(4):
+                for lg in range(4):
+                    got = []
+                    for h in range(2):
+                        def addr(l16, h=h):
+                            q4, p4 = l16 >> 2, l16 & 3
+                            R = 8 * lg + q4
+                            tb0 = R * 512 + (((4 * w + (p4 >> 1)) ^ R) << 4) + 8 * (p4 & 1)
+                            return (tb0 ^ (32 * j) ^ (64 * h)) + 2048 * h + 16384 * kc
+                        got.append(_tr16_gather(addr, lambda a_: img[a_]))
+                    for l15 in range(16):
+                        frag = got[0][l15] + got[1][l15]
+                        assert frag == [(32 * kc + 8 * lg + e, 32 * w + 16 * j + l15) for e in range(8)], (w, j, kc, lg, l15)
+    # ---- conv_igemm_p8_kernel: one 32-pixel x 64-channel slice per wave, chunk c of row r at position c ^ ((r >> 1) & 7) ----
+    img = {}
+    for ii in range(2):
+        for jp in (0, 2):
+            for lane in range(64):
+                l15, lg = lane & 15, lane >> 4
+                mwb = l15 * 128 + (((2 * (lg & 1) + (lg >> 1)) ^ ((l15 >> 1) & 7)) << 4)
+                a0 = (mwb ^ (jp << 5)) + 2048 * ii
+                r, c = 16 * ii + l15, 2 * (lg & 1) + (lg >> 1) + 2 * jp          # the vector holds channels nl + 16 jp .. + 7, nl = 16 (lg & 1) + 8 (lg >> 1)
+                assert a0 == r * 128 + ((c ^ ((r >> 1) & 7)) << 4)
+                for e in range(8):
+                    img[a0 + 2 * e] = (r, 8 * c + e)
+    assert len(img) == 32 * 64
+    for cb in range(4):
+        for lg in range(4):
+            got = []
+            for h in range(2):
+                def addr(l16, h=h):
+                    q4, p4 = l16 >> 2, l16 & 3
+                    R = 8 * lg + q4
+                    mtb = R * 128 + (((p4 >> 1) ^ ((R >> 1) & 7)) << 4) + 8 * (p4 & 1)
+                    return ((mtb ^ (32 * cb)) ^ (32 * h)) + 512 * h
+                got.append(_tr16_gather(addr, lambda a_: img[a_]))
+            for l15 in range(16):
+                assert got[0][l15] + got[1][l15] == [(8 * lg + e, 16 * cb + l15) for e in range(8)], (cb, lg, l15)
+    # ---- the Gram diagonal: D[channel 4 lg + r][column l15] sits in lane (l15 = 4 lg + r, lg), register r; lane (any l15, lg) fetches register r's
+    # value `dg` (= its own register l15 & 3) from lane 20 lg + r ----
+    for lg in range(4):
+        for r in range(4):
+            src = 20 * lg + r
+            assert src >> 4 == lg and (src & 15) == 4 * lg + r and ((src & 15) & 3) == r
+
+
 def test_conv_ws_vmcnt_accounting_model():
     """conv_ws_kernel waits for "my two LDS-DMA pieces of stage s" with s_waitcnt vmcnt(W): vector-memory operations retire in order, so
     the wait is correct iff W <= the number of operations the wave issued AFTER those pieces, and free of unnecessary stalls iff W equals
