@@ -471,6 +471,7 @@ int css_colsum(const void* x, int ld, long M, int C, float* out, float* ws, int 
   return css_launch_colsum(x, ld, M, C, out, ws, dtype, S(stream));
 }
 int css_stem_s2d_enabled(void) { return css_stem_s2d_enabled_(); }
+int css_conv2d_stem_s2d_tile_rows(void) { return css_stem_s2d_tile_rows_(); }
 int css_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, int device, css_stream_t stream) {
   set_dev(device);
   return css_launch_nchw_to_s2d(x, out, N, C, H, W, S(stream));

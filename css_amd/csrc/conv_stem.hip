@@ -67,10 +67,12 @@ struct StemArgs {
   FastDiv fd_hw, fd_w;
 };
 
+constexpr int STEM_TILE_ROWS = 256;   // pixels per tile = rows per pair of statistics slabs (css_conv2d_stem_s2d_tile_rows reports it to the host)
+
 // grid = 2 n_cu workgroups of 256 threads; tile t = blockIdx.x, blockIdx.x + gridDim.x, ...
 template <int TA, bool STATS>
 __global__ __launch_bounds__(256, 2) void conv_stem_s2d_kernel(const StemArgs a) {
-  constexpr int OFF = TA / 2, KB = TA * TA / 2, BT = 256, NPR = 2 * TA;      // K blocks of 32; plane-rows (tap row, 16-byte half)
+  constexpr int OFF = TA / 2, KB = TA * TA / 2, BT = STEM_TILE_ROWS, NPR = 2 * TA;      // K blocks of 32; plane-rows (tap row, 16-byte half)
   constexpr int BUF = NPR * 4096 + 1024;                                   // plane-rows of 256 pixels x 16 bytes + the shared tail piece
   constexpr int NPW = NPR;                                                 // full pieces per wave and tile (4 NPR pieces / 4 waves)
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUF + (STATS ? 2048 : 0)];
@@ -322,6 +324,7 @@ __global__ __launch_bounds__(256) void stem_s2d_fold_wgrad_kernel(const float* _
 }  // namespace
 
 static int g_stem_off = -1;      // -1: read CSS_NO_STEM_S2D on first use
+int css_stem_s2d_tile_rows_() { return STEM_TILE_ROWS; }
 int css_stem_s2d_enabled_() {
   if (g_stem_off < 0) {
     const char* e = getenv("CSS_NO_STEM_S2D");

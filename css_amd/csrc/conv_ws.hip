@@ -252,7 +252,10 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
   // one register per vector sends the K = 256 instance to scratch) and the epilogue takes its byte from the owner with ds_bpermute
   unsigned rmk[ADD ? 2 : 1];
   const bool has_mask = ADD && a.add_mask != nullptr;
-  // ---------------- epilogue of a tile (rows m0e ..): no LDS, no barrier ----------------
+  // ---------------- epilogue of a tile (rows m0e ..) ----------------
+  // ROWS form (the default): the packed tile is written to the 64 KiB LDS output buffer and read back as whole 512-byte rows behind an
+  // s_barrier - EVERY wave of the workgroup must call the epilogue, for the same tile, in uniform control flow (the persistent loop
+  // guarantees it: the tile index is workgroup-uniform).  Only the WS_NO_ROWS / WS_PP forms store straight from registers without LDS or barrier.
   auto epilogue = [&](int m0e) {
     const int bnd = STATS ? (m0e / a.stat_Mg + 1) * a.stat_Mg : 0x7fffffff;     // rows >= bnd: next statistics group (stage 2 sums them)
     // sum and sum of squares of the bf16-ROUNDED outputs (what the batch norm will read), two values per instruction (v_pk_add_f32 /

@@ -74,6 +74,7 @@ size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu);
 
 // conv_stem.hip: the stride-2 stem convolutions on the space-to-depth image (round 5)
 int css_stem_s2d_enabled_();
+int css_stem_s2d_tile_rows_();
 int css_launch_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, hipStream_t st);
 int css_launch_stem_s2d_weights(const float* w, void* out, int Cout, int R, hipStream_t st);
 int css_launch_stem_s2d_fold_wgrad(const float* dw2, float* dw, int Cout, int R, hipStream_t st);

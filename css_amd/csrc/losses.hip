@@ -18,11 +18,18 @@ constexpr float CE_FIX = 4294967296.f;               // 2^32
 constexpr double CE_UNFIX = 1.0 / 4294967296.0;
 typedef unsigned long long ce_acc_t;                  // (two's complement: losses are >= 0 up to rounding, negative partials wrap correctly)
 // A NON-FINITE pixel loss (diverged logits) must surface as NaN like the reference's fp32 mean does (float -> integer conversion of
-// NaN is 0 on AMDGPU, so the fixed-point sum stayed finite while the network was NaN): every non-finite partial adds CE_POISON to the
-// image's NVALID word - counts live in its low 40 bits (an image has < 2^40 pixels), the number of poisoned partials in the high 24 -
-// still an integer add, still order-independent; ce_finalize / ohem_init turn a non-zero high part into NaN.
+// NaN is 0 on AMDGPU, so the fixed-point sum stayed finite while the network was NaN): a non-finite partial marks the image's NVALID word -
+// counts live in its low 40 bits (an image has < 2^40 pixels); a workgroup counts its poisoned partials above them in LDS (<= 256 per tile)
+// and ce_flush ORs ONE bit (bit 40) into the global word, so the mark saturates instead of wrapping - integer add + bit OR, still
+// order-independent.  ce_finalize turns a non-zero high part into a NaN loss (every mode ends there: OHEM's final loss too); ohem_init only
+// masks the high part off the count (in mode 0 coef[b] stays the finite 1 / NV while the loss is NaN).
 constexpr ce_acc_t CE_POISON = 1ull << 40;
 constexpr ce_acc_t CE_COUNT_MASK = CE_POISON - 1;
+__device__ __forceinline__ void ce_flush(ce_acc_t* dst, int which, ce_acc_t v) {
+  if (which != ST_NVALID) { if (v) atomicAdd(dst, v); return; }
+  if (v & CE_COUNT_MASK) atomicAdd(dst, v & CE_COUNT_MASK);
+  if (v >> 40) atomicOr(dst, CE_POISON);
+}
 __device__ __forceinline__ ce_acc_t ce_fix(float v) { return isfinite(v) ? (ce_acc_t)(long long)(v * CE_FIX) : (ce_acc_t)0; }
 
 template <bool BWD>
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(256) void ce_kernel(const float* __restrict__ logit
     if (!BWD) {
       if (stats && tid < 8) {
         const int s = tid >> 2, b = b_first + s;
-        if (sacc[s][tid & 3] != 0) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], sacc[s][tid & 3]);
+        ce_flush(&stats[(size_t)b * 4 + (tid & 3)], tid & 3, sacc[s][tid & 3]);
       }
     } else {
       float* dst = dlogits + p0 * K;
@@ -258,7 +265,7 @@ __global__ __launch_bounds__(256) void ce_small_fwd_kernel(const T* __restrict__
     __syncthreads();
     if (stats && tid < 8) {
       const int s = tid >> 2, b = b_first + s;
-      if (sacc[s][tid & 3] != 0) atomicAdd(&stats[(size_t)b * 4 + (tid & 3)], sacc[s][tid & 3]);
+      ce_flush(&stats[(size_t)b * 4 + (tid & 3)], tid & 3, sacc[s][tid & 3]);
     }
   }
 }
@@ -371,7 +378,7 @@ __global__ __launch_bounds__(256) void ce_small_fwd_tile_kernel(const T* __restr
       atomicAdd(&sacc[ST_NCONF], (ce_acc_t)a_nc);
     }
     __syncthreads();
-    if (tid < 4 && sacc[tid] != 0) atomicAdd(&stats[(size_t)b * 4 + tid], sacc[tid]);
+    if (tid < 4) ce_flush(&stats[(size_t)b * 4 + tid], tid, sacc[tid]);
   }
 }
 

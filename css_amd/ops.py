@@ -336,10 +336,11 @@ class _StemS2D(torch.autograd.Function):
         stats, mg = None, 0
         if stat_groups and m % stat_groups == 0 and m // stat_groups >= 128:
             mg = m // stat_groups
-            stats = torch.empty((2 * ((m + 255) // 256), 2, cout), dtype=torch.float32, device=xs.device)
+            bt = _lib.query("css_conv2d_stem_s2d_tile_rows")           # the kernel's tile height: asked of the library, never hard-coded here
+            stats = torch.empty((2 * ((m + bt - 1) // bt), 2, cout), dtype=torch.float32, device=xs.device)
         call("css_conv2d_stem_s2d_forward", xs, w2, y, stats, mg, n, hs, ws, cout, r, flops, dev, st)
         if stats is not None:
-            _conv_stats_out = (stats, mg, stat_groups, cout, 256)
+            _conv_stats_out = (stats, mg, stat_groups, cout, bt)
         ctx.save_for_backward(xs, weight)
         ctx.flops = flops
         return y

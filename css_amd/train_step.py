@@ -71,7 +71,7 @@ class MixTrainer:
         # The verdict of a step, agreed across ranks with one MAX all-reduce: non-zero when some rank's gradient reports did not fit the bucket
         # plan OR (CSS_SYNCBN=peer) an exchange of some rank gave up waiting for a peer.  It (a) stops the step's optimizer on the device
         # (css_sgd_ema's skip_flag: weights, momentum and teacher stay those of the last valid step - on EVERY rank, so replicas stay
-        # equal) and (b) travels to a pinned host word behind an event that later steps POLL (never wait for) - see _check_verdicts.
+        # equal) and (b) travels to a pinned host word behind an event that step k + VERDICT_LAG reads on every rank - see _check_verdicts.
         self._flags = [torch.zeros(2, device=self.flat_g.device) for _ in range(2)]   # [agreed verdict, this rank's own reason code]
         self._verdicts = []                    # pending (pinned [verdict, local reason], event, iteration) in step order
         self._pinned_pool = []
@@ -127,7 +127,8 @@ class MixTrainer:
         when every span of buckets 0..b has received ALL its recorded reports - never on a count of reports alone - and always in
         bucket order, so every rank issues the same sequence of collectives whatever the timing.  A report that does not fit the
         record (a span completes twice, an unknown span, a span that stays incomplete) is a violation: the remaining buckets are still
-        launched in order, the ranks agree on the flag with one small all-reduce, and every rank raises at the same point (the start of its next step)."""
+        launched in order, the ranks agree on the flag with one small all-reduce, and every rank raises at the same point (the start of
+        step k + VERDICT_LAG, or finish() / state_dict())."""
         sync = ops.collectives_on()
         overlap = sync and self.bucket_mb > 0
         self._skip_flag = None
@@ -240,37 +241,49 @@ class MixTrainer:
             ev.record()
         self._verdicts.append((host, ev, self.it))
 
+    VERDICT_LAG = 2                            # the verdict of step k is read at the start of step k + VERDICT_LAG - on every rank
+
     def _check_verdicts(self, block=False):
-        """Raise - on every rank - when the agreed verdict of an earlier step was non-zero.  Inside a run the pinned copies are POLLED
-        (``event.query()``: ADVICE r04 - a wait here blocked the host until the previous backward had drained, so it could never queue the
-        next forward ahead of the GPU); a verdict that has not landed yet is looked at by a later step, `finish()` or `state_dict()`
-        (``block=True``).  Late is safe: the step was already skipped on the device.  On a violation the iteration counter, the EMA step
-        counter and the bucket plan go back to the state of the last APPLIED step before the exception leaves."""
+        """Raise - on every rank, AT THE SAME STEP - when the agreed verdict of an earlier step was non-zero.  Inside a run the verdict of
+        step k is read at a FIXED lag: at the start of step k + VERDICT_LAG, after ``event.synchronize()`` (a poll made the discovery
+        point depend on how far each rank's host had run ahead, so ranks raised at different steps, re-recorded their bucket plans at different
+        steps and issued different collective sequences).  The copy of step k has long landed by then (the device is at most in step k + 1), so
+        the host still never waits for the previous backward; it only cannot run more than VERDICT_LAG steps ahead.  ``finish()``
+        and ``state_dict()`` read everything that is pending (``block=True``) - callers reach them at the same step on every rank.  Late is
+        safe: an invalid step was already skipped on the device.  On a violation every pending verdict is drained (their pinned words go back
+        to the pool), and the iteration counter and the EMA step counter go back by the number of steps that were skipped on the device - the
+        lr schedule and the EMA decay continue from the last APPLIED step - before the exception leaves."""
         while self._verdicts:
             host, ev, it = self._verdicts[0]
-            if ev is not None and not ev.query():
-                if not block:
-                    return
+            if not block and it > self.it - self.VERDICT_LAG:
+                return
+            if ev is not None:
                 ev.synchronize()
             self._verdicts.pop(0)
             verdict, mine = float(host[0]), int(host[1])
             self._pinned_pool.append(host)
             if verdict != 0.0:
+                skipped = 1
+                for h2, ev2, _ in self._verdicts:        # the steps queued behind it: were they applied or skipped as well?
+                    if ev2 is not None:
+                        ev2.synchronize()
+                    skipped += int(float(h2[0]) != 0.0)
+                    self._pinned_pool.append(h2)
                 self._verdicts.clear()
                 self._buckets = None
-                self.it -= 1                     # that step changed nothing: lr schedule and EMA decay continue from the last valid step
-                self.model.step -= 1
+                self.it -= skipped                   # those steps changed nothing: lr schedule and EMA decay continue from the last applied step
+                self.model.step -= skipped
                 why = {0: "another rank reported it", 1: "this rank's gradient reports did not fit the recorded bucket plan",
                        2: "a SyncBN peer exchange of this rank timed out waiting for a peer (CSS_PEER_TIMEOUT_S)",
                        3: "bucket-plan violation and peer-exchange timeout on this rank"}.get(mine, str(mine))
                 raise RuntimeError(f"training step {it} was invalid and has been skipped on every rank ({why}): gradient readiness changed "
                                    "between steps on some rank (a span reported more or less often than on the first step) or SyncBN "
-                                   "statistics were incomplete; buckets were reset on every rank, weights / momentum / teacher are those of "
-                                   "the last valid step (batch-norm running statistics of the skipped step are not rolled back) - rebuild the "
-                                   "trainer or resume from the last checkpoint")
+                                   f"statistics were incomplete; {skipped} step(s) were skipped on the device, buckets were reset on every rank, "
+                                   "weights / momentum / teacher are those of the last valid step (batch-norm running statistics of a skipped "
+                                   "step are not rolled back) - rebuild the trainer or resume from the last checkpoint")
 
     def _check_bucket_flag(self):
-        """(kept for direct callers of _backward_and_reduce: the non-blocking poll)"""
+        """(kept for direct callers of _backward_and_reduce: the fixed-lag read)"""
         self._check_verdicts(False)
 
     def finish(self):
@@ -288,7 +301,7 @@ class MixTrainer:
 
     def step(self, l_img, l_lab, u_img, ramp=1.0, _injected=None):
         m = self.model
-        self._check_verdicts(False)                                          # (a poll: the host never waits for the device here)
+        self._check_verdicts(False)                                          # (fixed lag: the verdict of step it - 2; the device is past it)
         self.flat_g.zero_()                                                  # optimizer.zero_grad()
         # student logits come back at LOW resolution (NHWC): the losses fold the bilinear up-sampling in whenever its factor
         # allows (>= 2: 513/129, 769/193 in the reference's configs), else they are up-sampled here like ddp_model.py:141,144

@@ -224,10 +224,12 @@ CSS_API int css_colsum(const void* x, int ld, long M, int C, float* out, float* 
  * s2d pixel (ys, xs) = image(c, 2 ys + py, 2 xs + px), zero outside the image and in channels 12..15.
  * css_stem_s2d_weights: fp32 master [64][R][R][3] -> bf16 [64][TA][TA][16], TA = (R + 1) / 2: w2[a][b][(2 py + px) 3 + c] = w[2 a + py - 1][2 b + px - 1][c].
  * css_conv2d_stem_s2d_forward: y [N][Hs][Ws][64] bf16 = the R x R stride-2 pad R/2 convolution; stats (optional) = the batch-norm statistics slabs
- * of css_conv2d_forward_bnstats (fp32 [2 ceil(M / 256)][2][64], tile rows 256), Mg rows per statistics group.
+ * of css_conv2d_forward_bnstats (fp32 [2 ceil(M / BT)][2][64], BT = css_conv2d_stem_s2d_tile_rows() - the value stage 2 must be given), Mg rows
+ * per statistics group.
  * css_stem_s2d_fold_wgrad: the weight gradient computed in s2d space (css_conv2d_wgrad on the s2d image: TA x TA taps, stride 1, pad TA / 2,
  * 16 channels) dw2 fp32 [64][TA][TA][16] ADDED into dw fp32 [64][R][R][3].  css_stem_s2d_enabled: 0 under CSS_NO_STEM_S2D=1 (the gather kernels). */
 CSS_API int css_stem_s2d_enabled(void);
+CSS_API int css_conv2d_stem_s2d_tile_rows(void);
 CSS_API int css_nchw_to_s2d(const float* x, void* out, int N, int C, int H, int W, int device, css_stream_t stream);
 CSS_API int css_stem_s2d_weights(const float* w, void* out, int Cout, int R, int device, css_stream_t stream);
 CSS_API int css_stem_s2d_fold_wgrad(const float* dw2, float* dw, int Cout, int R, int device, css_stream_t stream);

@@ -146,7 +146,7 @@ def _bucket_worker(rank, world, port, q, mode="plain"):
     tr.it = 0
     errs = []
     raised = []
-    for step in range(3 if mode == "plain" else 4):
+    for step in range(3 if mode == "plain" else 5):
         tr.it = step
         flat_g.zero_()
         x = torch.full((), float(rank + 1 + step), requires_grad=True)
@@ -203,7 +203,9 @@ def test_world2_bucketed_gradient_all_reduce_equals_one_all_reduce():
 def test_world2_bucket_plan_violation_raises_on_every_rank_without_hanging():
     """when the graph of ONE rank changes (a layer stops reporting), that rank must not stop issuing the
     collectives the other rank is waiting in, and both ranks must learn about it at the same point of the protocol: the start of
-    the next step, from the agreed flag."""
+    step k + MixTrainer.VERDICT_LAG (a fixed lag - ADVICE r05: never a poll, whose outcome depends on each host's run-ahead), from the
+    agreed flag.  Step 3 (queued behind the invalid step 2, its graph intact again on both ranks but recorded plan unchanged) is valid:
+    exactly one step is rolled back."""
     os.environ["CSS_FORCE_COLLECTIVES"] = "0"
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -216,8 +218,9 @@ def test_world2_bucket_plan_violation_raises_on_every_rank_without_hanging():
         p.join(60)
         assert p.exitcode == 0
     (r0, errs0, _, _, _, raised0), (r1, errs1, _, _, _, raised1) = res
-    assert raised1 == [(3, True)], raised1                           # the rank whose graph changed
-    assert raised0 == [(3, True)], raised0                           # the other rank: same step, from the agreed flag
+    assert raised1 == [(4, True)], raised1                           # the rank whose graph changed: step 2 + the fixed lag
+    assert raised0 == [(4, True)], raised0                           # the other rank: same step, from the agreed flag
+    assert len(errs0) == 4 and len(errs1) == 4                       # steps 0-3 ran to completion on both ranks (2 skipped on the device only)
     assert errs0[:2] == [0.0, 0.0] and errs1[:2] == [0.0, 0.0]       # the steps before the change were exact
 
 

@@ -266,6 +266,81 @@ def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
     assert torch.equal(torch.tensor(a["rm"]), torch.tensor(b["rm"]))                 # SyncBN: global statistics on both ranks
 
 
+VIOLATE_WORKER = r'''
+import os, sys, json
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from css_amd.networks import resnet
+from css_amd.networks.ddp_model import Model_mix
+from css_amd.train_step import MixTrainer
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda:0")
+dist.init_process_group("gloo", rank=rank, world_size=world)
+K, S = 21, 65
+torch.manual_seed(11)
+cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix", "device_aug": "identity"}}
+m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
+m.model.train(); m.ema_model.train()
+m.set_compute_dtype(torch.bfloat16)
+tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
+g = torch.Generator().manual_seed(100 + rank)
+import numpy as np
+np.random.seed(5)
+raised, its, call_no = [], [], 0
+while call_no < 7:
+    l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
+    u = torch.randn(2, 3, S, S, generator=g).to(dev)
+    poked = None
+    if call_no == 2 and rank == 1:           # ONE rank's gradient reports stop fitting the recorded plan: a span waits for a report that never comes
+        poked = next(iter(tr._span_reports))
+        tr._span_reports[poked] += 1
+    try:
+        out = tr.step(l, y, u)
+        if rank == 0:
+            float(out["sup"])                # rank 0's host waits for the device every step; rank 1's host runs ahead as far as it can
+    except RuntimeError as e:
+        raised.append([call_no, tr.it, m.step, "skipped on every rank" in str(e), "1 step(s)" in str(e)])
+    if poked is not None:
+        tr._span_reports[poked] -= 1
+    its.append(tr.it)
+    call_no += 1
+tr.finish()
+torch.cuda.synchronize()
+probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
+ema = tr.flat_ema[:: tr.flat_ema.numel() // 4096][:4096].double().cpu()
+json.dump(dict(raised=raised, its=its, p=probe.tolist(), ema=ema.tolist(), it=tr.it, step=m.step, pool=len(tr._pinned_pool),
+               buckets=len(tr._buckets) if tr._buckets else 0), open(sys.argv[1] + str(rank), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_invalid_step_is_discovered_at_the_same_step_on_both_ranks(tmp_path):
+    """ADVICE r05 (medium): the agreed verdict of step k is read at the start of step k + MixTrainer.VERDICT_LAG on EVERY rank - not whenever a
+    rank's host happens to see the copy.  Two ranks on one GPU (gloo), rank 0's host blocked on the device every step and rank 1's running
+    ahead; rank 1's plan is violated at call 2.  Both ranks must raise at call 4 with the same counters, the callers continue (as SKIP_WORKER
+    does): both re-record their bucket plan in the same call, issue the same collective sequence (no hang) and end with bit-identical weights
+    and teacher; exactly one step is rolled back; every pinned verdict word is back in the pool."""
+    import json
+    import torch
+    out = str(tmp_path / "v_")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29583", CSS_GRAD_BUCKET_MB="8")
+        procs.append(subprocess.Popen([sys.executable, "-c", VIOLATE_WORKER % ROOT, out], env=env))
+    for p in procs:
+        assert p.wait(timeout=900) == 0
+    a, b = json.load(open(out + "0")), json.load(open(out + "1"))
+    print(a["raised"], b["raised"], a["its"], b["its"])
+    assert a["raised"] == b["raised"] and len(a["raised"]) == 1
+    call_no, it_after, step_after, msg_ok, one_step = a["raised"][0]
+    assert call_no == 2 + 2 and msg_ok and one_step               # VERDICT_LAG = 2; step 3 (queued behind the invalid one) was valid
+    assert it_after == 3 and step_after == 3                      # calls 0, 1, 3 were applied; 2 was skipped on the device
+    assert a["its"] == b["its"] and a["it"] == b["it"] == 5 and a["step"] == b["step"] == 5
+    assert a["buckets"] == b["buckets"] and a["buckets"] >= 10    # re-recorded (call 5) and bucketed again (call 6) on both ranks
+    assert torch.equal(torch.tensor(a["p"]), torch.tensor(b["p"])) and torch.equal(torch.tensor(a["ema"]), torch.tensor(b["ema"]))
+    assert a["pool"] >= 1 and b["pool"] >= 1
+
+
 RCCL_WORKER = r'''
 import os, sys, json
 sys.path.insert(0, %r)
