@@ -527,7 +527,9 @@ def contrast_loss(rep, label, mask, prob, prototypes, num_queries, num_negatives
                 record["negative"].append(None)
             continue
         if injected is not None:
-            sample_idx = torch.as_tensor(injected["anchor"][i], dtype=torch.long)
+            # (modulo: a no-op for draws recorded on these very lists; lets the draws of a neighbouring evaluation - a 1-ulp-perturbed re-run
+            # whose hard list is one pixel shorter - be replayed, with the rule css_contrast_resolve applies on the device)
+            sample_idx = torch.as_tensor(injected["anchor"][i], dtype=torch.long) % len(rep_hard_list[i])
         else:
             sample_idx = torch.randint(len(rep_hard_list[i]), size=(num_queries,))
         anchor_rep = rep_hard_list[i][sample_idx]
@@ -544,6 +546,8 @@ def contrast_loss(rep, label, mask, prob, prototypes, num_queries, num_negatives
                 negative_num_list = num_list[i + 1:] + num_list[:i]
                 negative_index = negative_index_sampler(samp_num, negative_num_list)
             negative_rep_all = torch.cat(rep_all_list[i + 1:] + rep_all_list[:i])
+            if injected is not None:
+                negative_index = (torch.as_tensor(negative_index, dtype=torch.long) % len(negative_rep_all)).tolist()
             negative_rep = negative_rep_all[negative_index].reshape(num_queries, num_negatives, num_feat)
             positive_rep = proto_rep[i].unsqueeze(0).unsqueeze(0).repeat(num_queries, 1, 1)
             all_rep = torch.cat((positive_rep, negative_rep), dim=1)

@@ -82,53 +82,68 @@ def test_c1_config_logits_vs_oracle_fp32():
     assert pred.shape == po.shape and e_p < 1e-3 and e_r < 1e-3
 
 
-def _step_vs_oracle(S, B, dtype, Q, N, seed, blocks):
+def _step_vs_oracle(S, B, dtype, Q, N, seed, blocks, weak=0.0, gain=0.25, floor_runs=0):
     """One MixTrainer.step on the HIP path against oracle.train_step_mix (mix_label.py:162-196) on the same seeded inputs and weights
-    (bn3 gains x0.25: the conditioning of a trained network), the oracle's sampler draws injected.  Returns (hip result, oracle result,
-    trainer, oracle state)."""
+    (``gain`` 0.25: bn3 gains x0.25, the conditioning of a trained network; 1.0: undamped), the oracle's sampler draws injected.
+    ``weak``: the valid-mask threshold of mix_label.py:176 (0.7 in the reference's configs and in bench.py: with these weights about a third of
+    the unlabeled pixels pass it; 0.0: every unlabeled pixel is valid).  Returns (hip result, oracle result, trainer, oracle state) and, with
+    ``floor_runs`` > 0, a fifth item: the same oracle step re-evaluated with 1-ulp relative perturbations of the images (same injected draws) -
+    what two correct fp32 implementations of this step differ by."""
     from css_amd.networks import resnet
     from css_amd.networks.ddp_model import Model_mix
     from css_amd.train_step import MixTrainer
     from oracle import css_oracle as O
-    K, gain = 21, 0.25
+    K = 21
     cfg = {"Dataset": {"crop_size": (S, S), "scale_size": (1.0, 1.0), "mix_mode": "none", "device_aug": "identity"}}
     g = torch.Generator().manual_seed(seed)
     l_img, u_img = torch.randn(B, 3, S, S, generator=g), torch.randn(B, 3, S, S, generator=g)
     cell = -(-S // blocks)
     l_lab = torch.randint(0, K, (B, blocks, blocks), generator=g).repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :S, :S].clone()
     l_lab[:, : cell // 2, : cell] = -1                        # some ignored pixels, like the reference's 255 -> -1 border
-    args = dict(lr=1e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97, num_queries=Q, num_negatives=N)
+    args = dict(lr=1e-3, temp_model=0.5, strong_threshold=0.8, weak_threshold=weak, un_threshold=0.97, num_queries=Q, num_negatives=N)
     st = O.MixState("tv", K, 256, seed, gain)
     rec = {}
     torch.manual_seed(0)
     np.random.seed(0)
     ro = O.train_step_mix(st, l_img, l_lab, u_img, record=rec, **args)
+    floors = []
+    for i in range(floor_runs):
+        gp = torch.Generator().manual_seed(1000 + i)
+        st_i = O.MixState("tv", K, 256, seed, gain)
+        rec_i = {}
+        r_i = O.train_step_mix(st_i, l_img * (1 + 1e-7 * torch.randn(l_img.shape, generator=gp)), l_lab,
+                               u_img * (1 + 1e-7 * torch.randn(u_img.shape, generator=gp)), injected=dict(rec), record=rec_i, **args)
+        assert rec_i["present"] == rec["present"]            # (same classes present: the injected draws mean the same thing)
+        floors.append((r_i, st_i))
     m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.5)
     sd = O.init_state("tv", K, 256, seed, gain)
     m.model.load_state_dict(sd)
     m.ema_model.load_state_dict(sd)
     m = m.to(dev()).train().set_compute_dtype(dtype)
-    tr = MixTrainer(m, K, lr=1e-3, total_iter=100, num_queries=Q, num_negatives=N, strong_threshold=0.8, weak_threshold=0.0, un_threshold=0.97)
+    tr = MixTrainer(m, K, lr=1e-3, total_iter=100, num_queries=Q, num_negatives=N, strong_threshold=0.8, weak_threshold=weak, un_threshold=0.97)
     # the class lists the draws index into depend on the hard flags (own-class probability < 0.8): where a pixel near the threshold
     # changes sides the injected indices are taken modulo the list lengths by the kernel (css_contrast_resolve)
     r = tr.step(l_img.to(dev()), l_lab.to(dev()), u_img.to(dev()), _injected=dict(anchor=rec["anchor"], negative=rec["negative"]))
     torch.cuda.synchronize()
-    return r, ro, tr, st
+    return (r, ro, tr, st, floors) if floor_runs else (r, ro, tr, st)
 
 
-def test_c1_full_step_vs_oracle_fp32():
+@pytest.mark.parametrize("weak", [0.0, 0.7], ids=["every_unlabeled_pixel_valid", "weak_threshold_0.7"])
+def test_c1_full_step_vs_oracle_fp32(weak):
     """BASELINE configs[0] as a STEP: 321x321, B = 2 + 2, fp32, tv-R101, K = 21, Q = 256, N = 512 - teacher x2, student
     forward / backward x2, the three losses, the prototype EMA, SGD + EMA teacher - against oracle.train_step_mix with injected draws:
-    losses 1e-3, prototypes 1e-3, pseudo labels < 0.5 % mismatching, the updated student weights on a probe."""
-    r, ro, tr, st = _step_vs_oracle(321, 2, torch.float32, 256, 512, 11, 10)
+    ALL THREE losses 1e-3 (the unsupervised loss was asserted 1000x looser than measured), prototypes 1e-3, pseudo labels
+    < 0.5 % mismatching, the updated student weights on a probe.  Second case: the reference's and bench.py's weak threshold 0.7
+    (mix_label.py:176), so the valid-mask branch ``u_logits_cls >= weak_thr`` meets the oracle at size with both sides populated."""
+    r, ro, tr, st = _step_vs_oracle(321, 2, torch.float32, 256, 512, 11, 10, weak=weak)
     for key in ("sup", "unsup", "contrast"):
         a, b = float(r[key]), float(ro[key])
-        print(f"c1 step fp32 {key}: hip {a:.6f} oracle {b:.6f} rel {abs(a - b) / max(1.0, abs(b)):.2e}")
+        print(f"c1 step fp32 weak={weak} {key}: hip {a:.6f} oracle {b:.6f} rel {abs(a - b) / max(1.0, abs(b)):.2e}")
     for key in ("sup", "contrast"):
         a, b = float(r[key]), float(ro[key])
         assert abs(a - b) < 1e-3 * max(1.0, abs(b)), (key, a, b)
     a, b = float(r["unsup"]), float(ro["unsup"])             # a mean over the few pixels above the 0.97 confidence threshold
-    assert (math.isnan(a) and math.isnan(b)) or abs(a - b) < 3e-2 * max(1.0, abs(b)), (a, b)
+    assert (math.isnan(a) and math.isnan(b)) or abs(a - b) < 1e-3 * max(1.0, abs(b)), (a, b)
     e = ((tr.prototypes.cpu() - st.prototypes).abs().max() / st.prototypes.abs().max()).item()
     mism = (r["pseudo"].cpu() != ro["pseudo"]).float().mean().item()
     print(f"c1 step fp32: prototypes rel {e:.2e}, pseudo labels mismatching {mism:.2e}")
@@ -171,8 +186,35 @@ def test_bf16_step_vs_oracle_with_injected_draws():
     _bf16_step_checks(*_step_vs_oracle(65, 2, torch.bfloat16, 64, 128, 7, 5), "65^2 B=2+2")
 
 
-def test_bf16_step_vs_oracle_129_b4():
+@pytest.mark.parametrize("weak", [0.0, 0.7], ids=["every_unlabeled_pixel_valid", "weak_threshold_0.7"])
+def test_bf16_step_vs_oracle_129_b4(weak):
     """The same at 129x129, B = 4 + 4, Q = 256, N = 512: here the BN / loss / contrast kernels of the bench dtype
     run multi-tile launches (M = 8 x 17^2 ... 8 x 65^2 rows per layer, two statistics groups of 4 images) against an oracle, not
-    only against properties."""
-    _bf16_step_checks(*_step_vs_oracle(129, 4, torch.bfloat16, 256, 512, 13, 6), "129^2 B=4+4")
+    only against properties.  Also at the reference's weak threshold 0.7.  This is the largest size at which the bench
+    dtype meets the ORACLE; at 513^2 / 769^2 the bf16 step is covered by properties and bit-reproducibility (test_full_size_step_properties)."""
+    _bf16_step_checks(*_step_vs_oracle(129, 4, torch.bfloat16, 256, 512, 13, 6, weak=weak), f"129^2 B=4+4 weak={weak}")
+
+
+def test_undamped_step_vs_oracle_65_fp32():
+    """One whole step with UNDAMPED weights (bn3 gains 1.0: activations grow through the 33 residual blocks, the conditioning of a fresh random
+    network rather than a trained one) at 65x65, fp32, weak threshold 0.7, against the oracle - judged like test_network_gpu.py judges the
+    undamped networks: against max(1e-3, 2 x floor), the floor being what the ORACLE ITSELF moves by under 1-ulp relative perturbations of
+    its input images (three draws, same injected sampler draws) - i.e. what two correct fp32 implementations of this step differ by."""
+    r, ro, tr, st, floors = _step_vs_oracle(65, 2, torch.float32, 64, 128, 7, 5, weak=0.7, gain=1.0, floor_runs=3)
+    rel = lambda a, b: abs(a - b) / max(1.0, abs(b))
+    for key in ("sup", "unsup", "contrast"):
+        a, b = float(r[key]), float(ro[key])
+        if math.isnan(b):
+            assert math.isnan(a), (key, a, b)
+            continue
+        fl = max(rel(float(ri[key]), b) for ri, _ in floors)
+        bound = max(1e-3, 2 * fl)
+        print(f"undamped 65^2 step fp32 {key}: hip {a:.6f} oracle {b:.6f} rel {rel(a, b):.2e}; oracle's own 1-ulp floor {fl:.2e}; bound {bound:.2e}")
+        assert rel(a, b) < bound, (key, a, b, fl)
+    pn = st.prototypes.abs().max()
+    e = ((tr.prototypes.cpu() - st.prototypes).abs().max() / pn).item()
+    fl = max(((si.prototypes - st.prototypes).abs().max() / pn).item() for _, si in floors)
+    mism = (r["pseudo"].cpu() != ro["pseudo"]).float().mean().item()
+    fl_m = max((ri["pseudo"] != ro["pseudo"]).float().mean().item() for ri, _ in floors)
+    print(f"undamped 65^2 step fp32: prototypes rel {e:.2e} (floor {fl:.2e}), pseudo labels mismatching {mism:.2e} (floor {fl_m:.2e})")
+    assert e < max(1e-3, 2 * fl) and mism < max(5e-3, 2 * fl_m), (e, fl, mism, fl_m)
