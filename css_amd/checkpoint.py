@@ -78,21 +78,29 @@ def load_lr_scheduler_state_dict(trainer, sd: dict) -> None:
         trainer.base_lr = float(sd["base_lrs"][0])
 
 
-def state_for_save(trainer, epoch: int) -> dict:
-    """The dict the reference passes to torch.save (mix_label.py:139-146)."""
+def state_for_save(trainer, epoch: int, exact_resume: bool = False) -> dict:
+    """The dict the reference passes to torch.save (mix_label.py:139-146).  ``exact_resume=True`` adds ONE key the reference's resume code
+    never reads (it picks its six keys by name, mix_label.py:107-112): 'css_amd_resume' = the two counters the reference's format loses -
+    the EMA warm-up counter ``Model_mix.step`` (ddp_model.py:93-97) and the position of the contrastive sampler's stream - so that
+    ``load_checkpoint(..., exact_resume=True)`` continues a run bit for bit (tests/test_mini_training_gpu.py)."""
+    trainer.finish()                         # a step whose gradients were invalid raises here instead of being saved
     m = trainer.model
-    return {"epoch": epoch + 1, "model": m.model.state_dict(), "ema_model": m.ema_model.state_dict(),
-            "optimizer": optimizer_state_dict(trainer), "lr_scheduler": lr_scheduler_state_dict(trainer),
-            "prototypes": trainer.prototypes.data.cpu().numpy()}
+    sd = {"epoch": epoch + 1, "model": m.model.state_dict(), "ema_model": m.ema_model.state_dict(),
+          "optimizer": optimizer_state_dict(trainer), "lr_scheduler": lr_scheduler_state_dict(trainer),
+          "prototypes": trainer.prototypes.data.cpu().numpy()}
+    if exact_resume:
+        sd["css_amd_resume"] = {"ema_step": int(m.step), "sampler_calls": int(trainer.crit_contrast._calls)}
+    return sd
 
 
-def save_checkpoint(path: str, trainer, epoch: int) -> None:
-    torch.save(state_for_save(trainer, epoch), path)
+def save_checkpoint(path: str, trainer, epoch: int, exact_resume: bool = False) -> None:
+    torch.save(state_for_save(trainer, epoch, exact_resume), path)
 
 
-def load_checkpoint(path_or_dict, trainer) -> int:
+def load_checkpoint(path_or_dict, trainer, exact_resume: bool = False) -> int:
     """Resume like mix_label.py:104-112; returns start_epoch.  Accepts the reference's files (keys with or without the
-    DistributedDataParallel 'module.' prefix)."""
+    DistributedDataParallel 'module.' prefix).  ``exact_resume=True``: also restore the two counters of 'css_amd_resume' when the file has
+    them (default False = the reference's behaviour, below)."""
     ck = torch.load(path_or_dict, map_location="cpu", weights_only=False) if isinstance(path_or_dict, str) else path_or_dict
 
     def strip(sd):
@@ -106,5 +114,9 @@ def load_checkpoint(path_or_dict, trainer) -> int:
     # resumed run starts it at 0 again, so its first ema_update copies the student into the teacher (decay = 0)
     proto = torch.as_tensor(np.asarray(ck["prototypes"]), dtype=torch.float32)
     trainer.prototypes.copy_(proto.to(trainer.prototypes.device))
+    extra = ck.get("css_amd_resume") if exact_resume else None
+    if extra is not None:
+        m.step = int(extra["ema_step"])
+        trainer.crit_contrast._calls = int(extra["sampler_calls"])
     m.refresh_weights()                      # parameters changed behind the weight cache
     return int(ck["epoch"])
