@@ -267,6 +267,27 @@ __device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0,
 // prow and prow + 16 of a stage, i.e. piece i IS half i, so a half is restaged two phases after its last read (the template's rule),
 // and `vmcnt(10)` (five phases' pieces stay in flight) retires the half that the NEXT phase reads.  Same MFMA order per accumulator
 // as conv_wgrad_dma256_kernel: bit-identical results.
+#ifdef WG_STAMP
+// Diagnostic build only (scripts/wgrad_bench.hip -DWG_STAMP; in the library no stamp executes): s_memtime / s_memrealtime around the K loop of
+// every workgroup -> [workgroup][4] in a buffer of their own; the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md,
+// DVFS give-back item 6).
+__device__ unsigned long long* wg_stamp_buf = nullptr;
+#define WG_STAMP_BEGIN()                                                                                                        \
+  unsigned long long st_c0, st_r0;                                                                                              \
+  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0)::"memory")
+#define WG_STAMP_END()                                                                                                          \
+  do {                                                                                                                          \
+    unsigned long long st_c1, st_r1;                                                                                            \
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1)::"memory");              \
+    if (threadIdx.x == 0 && wg_stamp_buf) {                                                                                     \
+      unsigned long long* o_ = wg_stamp_buf + (size_t)blockIdx.x * 4;                                                           \
+      o_[0] = st_c0; o_[1] = st_r0; o_[2] = st_c1; o_[3] = st_r1;                                                               \
+    }                                                                                                                           \
+  } while (0)
+#else
+#define WG_STAMP_BEGIN()
+#define WG_STAMP_END()
+#endif
 __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
   constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
   constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
@@ -389,6 +410,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
     u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
     return u.f;
   };
+  WG_STAMP_BEGIN();
   int st_c = 0, st_i = 3;
   for (int it = 0; it < nit; ++it) {
 #pragma unroll
@@ -433,6 +455,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
     st_c = (st_c + 1) & 3;
     st_i = (st_i + 1) & 3;
   }
+  WG_STAMP_END();
   if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
   const int l31 = lane & 31, lh = lane >> 5;
@@ -481,9 +504,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 // of the step: a 32-lane half reads rows 8 n + q and 8 n + 8 + q of the SAME 16 channels, so on top of the 64-byte block swizzle by (row & 3)
 // the two 16-byte chunks pairs of a block swap with bit 3 of the row (chunk ^= ((row >> 3) & 1) << 1): 4 rows x 2 half-blocks = 64 banks once.
 // Another (fixed) summation order than conv_wgrad_p8_kernel: equal to rounding, bit-reproducible run to run.
-#ifdef WG_STAMP
-__device__ unsigned long long* wg_stamp_buf = nullptr;     // diagnostic build only (scripts/wgrad_bench.hip): [workgroup][4] = memtime, memrealtime before / after the loop
-#endif
 template <bool MF16>
 __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) {
   static_assert(MF16, "the 32x32x16 form is conv_wgrad_p8_kernel");
@@ -498,10 +518,22 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
   int zz, t;
   if (!wgrad_work_item(a, per_z, zz, t)) return;
   const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * 256;
-  const int m_begin = zz * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
+  // live-row compaction (WgradArgs): the tile lies inside ONE tap (Cs % 256 == 0), so its kernel row is workgroup-uniform; the pixel index of
+  // this kernel runs over the live output rows of every image: j -> image j / L, row row_lo + (j % L) / Wd, L = live rows x Wd
+  const int trow = a.compact ? (k0 / a.Cs) / a.S : 0;
+  const int hlo = a.compact ? a.row_lo[trow] : 0, nrows = a.compact ? a.row_n[trow] : a.Hd;
+  const FastDiv fdL = a.compact ? a.fd_L[trow] : a.fd_hw;
+  const int L = nrows * a.Wd, mps = a.compact ? a.row_mps[trow] : a.m_per_split;
+  const int m_begin = zz * mps;
+  const int m_end = min(a.N * L, m_begin + mps);
   const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit <= 0) return;
+  if (nit <= 0) {                                              // (an empty slice of a compacted tile: its slab is still summed by the reduction)
+    if (a.ws) {
+      float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
+      for (int e = tid; e < 256 * 256 / 4; e += 512) reinterpret_cast<f32x4*>(slab)[e] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    return;
+  }
 
   const int prow = tid >> 5;                                    // my two LDS-DMA rows: pixel rows prow and prow + 16 of a stage
   const int schunk = (tid & 31) ^ ((prow & 3) << 2) ^ (((prow >> 3) & 1) << 1);     // the source chunk that lands in LDS position tid & 31
@@ -516,28 +548,30 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
 
   const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
   const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;
-  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
+  const int d_n = (int)fdiv((uint32_t)BP, fdL), d_h = q_w - d_n * nrows;
   const int xrow = a.ldx * 2;
   const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
   const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;
-  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;
-  const int ystep = BP * a.ldy * 2;
+  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - nrows * sx_h;
+  const int Yh = (a.Hd * a.Wd - L) * a.ldy * 2;                  // dY: the dead rows between two images' live rows
+  const int ystep = BP * a.ldy * 2 + d_n * Yh;
   int r_m[2], r_hs[2], r_ws[2];
   unsigned r_xo[2], r_yo[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int m = m_begin + prow + i * 16;
-    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
-    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
-    const uint32_t hd = fdiv(rem, a.fd_w);
-    const uint32_t wd = rem - hd * a.fd_w.d;
+    const uint32_t n_img = fdiv((uint32_t)m, fdL);
+    const uint32_t rem = (uint32_t)m - n_img * (uint32_t)L;
+    const uint32_t hq = fdiv(rem, a.fd_w);
+    const uint32_t wd = rem - hq * a.fd_w.d;
+    const int hd = hlo + (int)hq;
     r_m[i] = m;
-    r_hs[i] = (int)hd * a.stride + dh;
+    r_hs[i] = hd * a.stride + dh;
     r_ws[i] = (int)wd * a.stride + dw_;
     r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
-    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
+    r_yo[i] = (unsigned)((((int)n_img * a.Hd + hd) * a.Wd + (int)wd) * a.ldy + ncol) * 2u;
   }
-  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;
+  const int hs_hi = (hlo + nrows - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;
   const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
   auto row_offsets = [&](int i, unsigned& vy, unsigned& vx) {
     vy = (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB;
@@ -545,7 +579,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     vx = ok ? r_xo[i] : OOB;
     asm volatile("" : "+v"(vy), "+v"(vx));     // (pinned: the optimizer must not sink this into the load segment that uses it)
     r_m[i] += BP;
-    r_yo[i] += (unsigned)ystep;
     int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
     int dx = D0;
     const bool cw = ws > ws_hi;
@@ -553,11 +586,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     hs += cw ? a.stride : 0;
     dx += cw ? Dw : 0;
     const bool ch = hs > hs_hi;
-    hs -= ch ? a.Hd * a.stride : 0;
+    hs -= ch ? nrows * a.stride : 0;
     dx += ch ? Dh : 0;
     r_ws[i] = ws;
     r_hs[i] = hs;
     r_xo[i] += (unsigned)dx;
+    r_yo[i] += (unsigned)(ystep + (ch ? Yh : 0));
   };
   auto stage_half = [&](int stage, int i, unsigned vy, unsigned vx) {
     const unsigned sy = lds0 + (unsigned)stage * ST_BYTES + (unsigned)i * 8192u;
@@ -605,10 +639,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
     return u.f;
   };
-#ifdef WG_STAMP
-  unsigned long long st_c0, st_r0;
-  asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c0), "=s"(st_r0)::"memory");
-#endif
+  WG_STAMP_BEGIN();
   int st_c = 0, st_i = 3;
   for (int it = 0; it < nit; ++it) {
     bf16x8 fx[TK], fy[4];
@@ -672,16 +703,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     st_c = (st_c + 1) & 3;
     st_i = (st_i + 1) & 3;
   }
-#ifdef WG_STAMP
-  {
-    unsigned long long st_c1, st_r1;
-    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_c1), "=s"(st_r1)::"memory");
-    if (tid == 0 && wg_stamp_buf) {
-      unsigned long long* o = wg_stamp_buf + (size_t)blockIdx.x * 4;
-      o[0] = st_c0; o[1] = st_r0; o[2] = st_c1; o[3] = st_r1;
-    }
-  }
-#endif
+  WG_STAMP_END();
   if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
   // D: lane & 15 = cout within the fragment, 4 (lane >> 4) + r = k column within the fragment
@@ -829,6 +851,7 @@ size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
   return (size_t)cdiv(Ktot, bn) * cdiv(Cd, bn) * splits * ((size_t)bn * bn * sizeof(float));
 }
 
+int css_wgrad_mfma_override_ = 0;     // harnesses: 16 / 32 forces the MFMA shape of the 256 x 256 kernel (0: CSS_WGRAD_MFMA, default 16)
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   if (a.M <= 0) return CSS_OK;
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
@@ -860,12 +883,33 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.splits = splits;
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
+  a.compact = 0;
+  {
+    static const bool env32 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 32;
+    static const bool no_compact = getenv("CSS_WGRAD_NO_COMPACT") != nullptr;
+    const bool mf32 = css_wgrad_mfma_override_ ? css_wgrad_mfma_override_ == 32 : env32;
+    if (big && !mf32 && !no_compact && a.R > 1 && a.R <= 3 && a.stride == 1 && a.Cs % 256 == 0) {
+      bool any = false;
+      for (int r = 0; r < a.R; ++r) {
+        const int dh = r * a.dil - a.pad;
+        int lo = dh < 0 ? -dh : 0, hi = a.Hd - 1 < a.Hs - 1 - dh ? a.Hd - 1 : a.Hs - 1 - dh;
+        if (hi < lo) { lo = 0; hi = a.Hd - 1; }                    // (kernel row entirely in the padding: computed as zeros over all rows)
+        a.row_lo[r] = lo;
+        a.row_n[r] = hi - lo + 1;
+        a.row_mps[r] = cdiv(cdiv(a.N * a.row_n[r] * a.Wd, splits), bp) * bp;
+        a.fd_L[r] = make_fastdiv((uint32_t)(a.row_n[r] * a.Wd));
+        any = any || a.row_n[r] < a.Hd;
+      }
+      a.compact = any ? 1 : 0;
+    }
+  }
   dim3 g(cdiv((long)a.tiles_k * a.tiles_n * splits, 8) * 8);      // (wgrad_work_item: XCD x takes work items [x W8, (x + 1) W8))
   if (prof) prof->begin(big, 1.0, false);
   if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
   if (big) {
     // the MFMA shape of the 256 x 256 kernel: 16x16x32 (default since round 6: profiles/r06_wgrad_mfma_shape_ab.txt) or 32x32x16 (CSS_WGRAD_MFMA=32)
-    static const bool mf32 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 32;
+    static const bool env32 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 32;
+    const bool mf32 = css_wgrad_mfma_override_ ? css_wgrad_mfma_override_ == 32 : env32;
     if (mf32) hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(conv_wgrad_p16_kernel<true>, g, dim3(512), 0, st, a);
     if (a.ws)
