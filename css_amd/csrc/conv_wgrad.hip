@@ -1,6 +1,6 @@
 // Weight gradient of the NHWC convolutions on gfx950 (CDNA4): dW[n][k] += sum_m dY[m][n] * X(m, k), k = (r, s, c).
 //   conv_wgrad_kernel            : 128x128 (bf16) / 64x64 (fp32) tiles, register-staged (narrow layers, the fp32 parity path)
-//   conv_wgrad_p8_kernel         : 256x256 tiles, LDS-DMA, two-phase steps (Cout >= 256: the bulk of the network)
+//   conv_wgrad_p8_kernel<MF16>   : 256x256 tiles, LDS-DMA, two-phase steps, live-row compaction for dilated 3x3 (Cout >= 256: the bulk of the network)
 //   wgrad_slab_reduce*_kernel    : every pixel slice stores its partial tile as a slab; these add the slabs in slice order (bit-reproducible)
 // Replaces the weight-gradient half of the cuDNN backward the reference reaches through nn.Conv2d in
 //   generalframeworks/networks/resnet.py:119-139, deeplabv3/aspp.py:17-72, deeplabv3/deeplabv3.py:115-133.
@@ -255,7 +255,7 @@ __device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0,
 }
 
 // --------------------------------------------------------------------------
-// conv_wgrad_p8_kernel (r03): the 256x256 tile, fragments, walk and epilogue described above on the phase structure of conv_p8.hip
+// conv_wgrad_p8_kernel<false> (r03; the default form): the 256x256 tile, fragments, walk and epilogue described above on the phase structure of conv_p8.hip
 // (its one-barrier-per-step predecessors conv_wgrad_dma256_kernel<STAG> live in scripts/proto/conv_wgrad_dma256.hip as the A/B reference).
 // What the yardstick GEMM and conv_igemm_p8_kernel taught (profiles/r03_p8_phase_stamps.txt): a load segment must hold nothing but
 // the fragment reads and the LDS-DMA issue - every VALU / SALU instruction and branch in it delays the barrier its SIMD partner's MFMA
@@ -267,6 +267,24 @@ __device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0,
 // prow and prow + 16 of a stage, i.e. piece i IS half i, so a half is restaged two phases after its last read (the template's rule),
 // and `vmcnt(10)` (five phases' pieces stay in flight) retires the half that the NEXT phase reads.  Same MFMA order per accumulator
 // as conv_wgrad_dma256_kernel: bit-identical results.
+// --------------------------------------------------------------------------
+// conv_wgrad_p8_kernel<true> (r06; CSS_WGRAD_MFMA=16): the same 256 x 256 tile, four-stage LDS-DMA ring, row walk and two-phase step as the 32x32x16 form, on
+// v_mfma_f32_16x16x32_bf16 - the shape the chip holds a higher clock on under load (MI355X_MICROARCH.md DVFS give-back item 7; the forward
+// kernel made this move in round 3).  An MFMA now reduces over ALL 32 pixels of a step, so the two phases of a step split the wave's
+// 128 (cout) x 64 (k column) tile by cout instead of by pixel:
+//     phase A [8 + 8 transposed reads: X fragments 0-3 (kept for phase B), dY fragments 0-3 | pieces of half 0 of step t+3]           s_barrier
+//             [lgkmcnt(0) | 16 MFMAs 16x16x32, the walk of pixel row 1 between them]                                                    s_barrier
+//     phase B [8 transposed reads: dY fragments 4-7 | pieces of half 1 of step t+3 | vmcnt(8): ALL of stage t+1 landed | lgkmcnt(0)]  s_barrier
+//             [16 MFMAs, the walk of pixel row 0 and the next stage's read addresses between them]                                      s_barrier
+// Phase B reads all 32 pixel rows of the stage, and the very next phase (phase A of the next step; for the other cout half of the workgroup,
+// which runs one barrier behind, the same barrier slot) restages its half 0: phase B therefore completes its reads BEFORE its barrier.
+// Operand roles: A = X^T (rows = k columns), B = dY (columns = cout), so D has cout on the lane and 4 consecutive k columns in the 4
+// registers of an accumulator - the slab rows are written with 16-byte stores.  MFMA lane group g (lane >> 4) takes pixel rows 8 g .. 8 g + 7
+// of the step: a 32-lane half reads rows 8 n + q and 8 n + 8 + q of the SAME 16 channels, so on top of the 64-byte block swizzle by (row & 3)
+// the two 16-byte chunks pairs of a block swap with bit 3 of the row (chunk ^= ((row >> 3) & 1) << 1): 4 rows x 2 half-blocks = 64 banks once.
+// Pixel rows reach an accumulator in the same order as in the 32x32x16 form (rows 0-7, 8-15, 16-23, 24-31 of a step): on the harness data the two
+// forms agree BIT FOR BIT on every launch shape of the step (profiles/r06_wgrad_mfma_shape_check.txt).  Measured (profiles/r06_wgrad_mfma_shape_ab.txt):
+// the in-kernel clock rises by 30 % (1.43 -> 1.87 GHz on the layer-4 3x3), the cycles of the K loop by 46 %, wall time +7 %: the 32x32x16 form stays the default.
 #ifdef WG_STAMP
 // Diagnostic build only (scripts/wgrad_bench.hip -DWG_STAMP; in the library no stamp executes): s_memtime / s_memrealtime around the K loop of
 // every workgroup -> [workgroup][4] in a buffer of their own; the in-kernel clock is d(memtime) / d(memrealtime) x 100 MHz (MI355X_MICROARCH.md,
@@ -288,228 +306,11 @@ __device__ unsigned long long* wg_stamp_buf = nullptr;
 #define WG_STAMP_BEGIN()
 #define WG_STAMP_END()
 #endif
-__global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
-  constexpr int BN_ = 256, BKC = 256, BP = 32, NST = 4;
-  constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
-  constexpr int WTN = 128, WTK = 64, TN = 4, TK = 2;
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave >> 2, wk = wave & 3;
-  const int per_z = a.tiles_k * a.tiles_n;
-  int zz, t;
-  if (!wgrad_work_item(a, per_z, zz, t)) return;
-  const int k0 = (t % a.tiles_k) * BKC, n0 = (t / a.tiles_k) * BN_;
-  const int m_begin = zz * a.m_per_split;
-  const int m_end = min(a.M, m_begin + a.m_per_split);
-  const int nit = (m_end - m_begin + BP - 1) / BP;
-  if (nit <= 0) return;
-
-  const int prow = tid >> 5;
-  const int schunk = ((((tid & 31) >> 2) ^ (prow & 3)) << 2) | (tid & 3);
-  const int kcol = k0 + schunk * 8;
-  const bool k_ok = kcol < a.Ktot;
-  const int tap = k_ok ? kcol / a.Cs : 0;
-  const int xc = k_ok ? kcol - tap * a.Cs : 0;
-  const int tr = tap / a.S, ts = tap - tr * a.S;
-  const int dh = tr * a.dil - a.pad, dw_ = ts * a.dil - a.pad;
-  const int ncol = n0 + schunk * 8;
-  const bool n_ok = ncol < a.Cd;
-
-  const u32x4 rs_x = raw_rsrc(a.x, a.x_bytes), rs_y = raw_rsrc(a.dy, a.dy_bytes);
-  const int q_w = (int)fdiv((uint32_t)BP, a.fd_w), d_w = BP - q_w * a.Wd;
-  const int d_n = (int)fdiv((uint32_t)BP, a.fd_hw), d_h = q_w - d_n * a.Hd;
-  const int xrow = a.ldx * 2;
-  const int sx_w = a.stride * xrow, sx_h = a.stride * a.Ws * xrow, sx_n = a.Hs * a.Ws * xrow;
-  const int D0 = d_n * sx_n + d_h * sx_h + d_w * sx_w;
-  const int Dw = sx_h - a.Wd * sx_w, Dh = sx_n - a.Hd * sx_h;
-  const int ystep = BP * a.ldy * 2;
-  int r_m[2], r_hs[2], r_ws[2];
-  unsigned r_xo[2], r_yo[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int m = m_begin + prow + i * 16;
-    const uint32_t n_img = fdiv((uint32_t)m, a.fd_hw);
-    const uint32_t rem = (uint32_t)m - n_img * a.fd_hw.d;
-    const uint32_t hd = fdiv(rem, a.fd_w);
-    const uint32_t wd = rem - hd * a.fd_w.d;
-    r_m[i] = m;
-    r_hs[i] = (int)hd * a.stride + dh;
-    r_ws[i] = (int)wd * a.stride + dw_;
-    r_xo[i] = (unsigned)(((int)n_img * a.Hs * a.Ws + r_hs[i] * a.Ws + r_ws[i]) * a.ldx + xc) * 2u;
-    r_yo[i] = (unsigned)(m * a.ldy + ncol) * 2u;
-  }
-  const int hs_hi = (a.Hd - 1) * a.stride + dh, ws_hi = (a.Wd - 1) * a.stride + dw_;
-  const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)(lds_void*)smem) + (unsigned)wave * 1024u;
-  // offsets of pixel row i as it stands (OOB: past the slice / padding / tail columns -> zeros), then the row moves on by BP pixels
-  auto row_offsets = [&](int i, unsigned& vy, unsigned& vx) {
-    vy = (n_ok && r_m[i] < m_end) ? r_yo[i] : OOB;
-    const bool ok = k_ok && r_m[i] < m_end && (unsigned)r_hs[i] < (unsigned)a.Hs && (unsigned)r_ws[i] < (unsigned)a.Ws;
-    vx = ok ? r_xo[i] : OOB;
-    asm volatile("" : "+v"(vy), "+v"(vx));     // (pinned: the optimizer must not sink this into the load segment that uses it)
-    r_m[i] += BP;
-    r_yo[i] += (unsigned)ystep;
-    int ws = r_ws[i] + d_w * a.stride, hs = r_hs[i] + d_h * a.stride;
-    int dx = D0;
-    const bool cw = ws > ws_hi;
-    ws -= cw ? a.Wd * a.stride : 0;
-    hs += cw ? a.stride : 0;
-    dx += cw ? Dw : 0;
-    const bool ch = hs > hs_hi;
-    hs -= ch ? a.Hd * a.stride : 0;
-    dx += ch ? Dh : 0;
-    r_ws[i] = ws;
-    r_hs[i] = hs;
-    r_xo[i] += (unsigned)dx;
-  };
-  auto stage_half = [&](int stage, int i, unsigned vy, unsigned vx) {
-    const unsigned sy = lds0 + (unsigned)stage * ST_BYTES + (unsigned)i * 8192u;
-    dma16_lds(rs_y, sy, vy);
-    dma16_lds(rs_x, sy + T_BYTES, vx);
-  };
-
-  f32x16 acc[TN][TK];
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  // prologue: steps 0, 1, 2 (data phases 0..5); offsets of data phase 6 ready for the first phase's issue
-  unsigned vy, vx;
-#pragma unroll
-  for (int st = 0; st < 3; ++st)
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      row_offsets(i, vy, vx);
-      stage_half(st, i, vy, vx);
-    }
-  row_offsets(0, vy, vx);
-  asm volatile("s_waitcnt vmcnt(10)" ::: "memory");    // data phase 0 has landed
-  __builtin_amdgcn_s_barrier();
-  if (wn == 1) __builtin_amdgcn_s_barrier();            // the second cout half runs one barrier behind
-  asm volatile("" ::: "memory");
-
-  // LDS byte addresses of my fragment reads in the stage being multiplied (half 0; half 1 = 16 rows = + 8192), see wg_frag_sw; they move
-  // on to the next stage inside phase 1's MFMA segment
-  unsigned fad[TN + TK];
-  {
-    const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
-    const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * (g >> 1) + q) * 512u;
-#pragma unroll
-    for (int k = 0; k < TN + TK; ++k) {
-      const int C = (k < TN ? wn * WTN + k * 32 : wk * WTK + (k - TN) * 32) + 16 * (g & 1) + 4 * pp;
-      fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
-    }
-  }
-  typedef __attribute__((address_space(3))) s16x4 wgp_lds_v4;
-  auto frag = [&](unsigned ad) {
-    union { struct { s16x4 a, b; } s; bf16x8 f; } u;
-    u.s.a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)ad);
-    u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
-    return u.f;
-  };
-  WG_STAMP_BEGIN();
-  int st_c = 0, st_i = 3;
-  for (int it = 0; it < nit; ++it) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      bf16x8 fy[TN], fx[TK];
-      // ---- load segment: fragments of half h, pieces of half h of step it+3, one counted wait ----
-#pragma unroll
-      for (int i = 0; i < TN; ++i) fy[i] = frag(fad[i] + h * 8192);
-#pragma unroll
-      for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j] + h * 8192);
-      __builtin_amdgcn_sched_barrier(0);
-      stage_half(st_i, h, vy, vx);
-      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // the half the NEXT phase reads has landed
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- MFMA segment: 8 MFMAs + the walk of the row the next phase issues (+ the next stage's read addresses) ----
-      row_offsets(h ^ 1, vy, vx);
-      if (h == 1) {
-        const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
-#pragma unroll
-        for (int k = 0; k < TN + TK; ++k) {
-          fad[k] += d;
-          asm volatile("" : "+v"(fad[k]));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
-#pragma unroll
-      for (int g_ = 0; g_ < 8; ++g_) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    st_c = (st_c + 1) & 3;
-    st_i = (st_i + 1) & 3;
-  }
-  WG_STAMP_END();
-  if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
-  const int l31 = lane & 31, lh = lane >> 5;
-  if (a.ws) {
-    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-      for (int j = 0; j < TK; ++j) {
-        const int kl = wk * WTK + j * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[nl * 256 + kl] = acc[i][j][r];
-        }
-      }
-    return;
-  }
-#pragma unroll
-  for (int i = 0; i < TN; ++i)
-#pragma unroll
-    for (int j = 0; j < TK; ++j) {
-      const int k = k0 + wk * WTK + j * 32 + l31;
-      if (k >= a.Ktot) continue;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
-      }
-    }
-}
-
-// --------------------------------------------------------------------------
-// conv_wgrad_p16_kernel (r06): the same 256 x 256 tile, four-stage LDS-DMA ring, row walk and two-phase step as conv_wgrad_p8_kernel, on
-// v_mfma_f32_16x16x32_bf16 - the shape the chip holds a higher clock on under load (MI355X_MICROARCH.md DVFS give-back item 7; the forward
-// kernel made this move in round 3).  An MFMA now reduces over ALL 32 pixels of a step, so the two phases of a step split the wave's
-// 128 (cout) x 64 (k column) tile by cout instead of by pixel:
-//     phase A [8 + 8 transposed reads: X fragments 0-3 (kept for phase B), dY fragments 0-3 | pieces of half 0 of step t+3]           s_barrier
-//             [lgkmcnt(0) | 16 MFMAs 16x16x32, the walk of pixel row 1 between them]                                                    s_barrier
-//     phase B [8 transposed reads: dY fragments 4-7 | pieces of half 1 of step t+3 | vmcnt(8): ALL of stage t+1 landed | lgkmcnt(0)]  s_barrier
-//             [16 MFMAs, the walk of pixel row 0 and the next stage's read addresses between them]                                      s_barrier
-// Phase B reads all 32 pixel rows of the stage, and the very next phase (phase A of the next step; for the other cout half of the workgroup,
-// which runs one barrier behind, the same barrier slot) restages its half 0: phase B therefore completes its reads BEFORE its barrier.
-// Operand roles: A = X^T (rows = k columns), B = dY (columns = cout), so D has cout on the lane and 4 consecutive k columns in the 4
-// registers of an accumulator - the slab rows are written with 16-byte stores.  MFMA lane group g (lane >> 4) takes pixel rows 8 g .. 8 g + 7
-// of the step: a 32-lane half reads rows 8 n + q and 8 n + 8 + q of the SAME 16 channels, so on top of the 64-byte block swizzle by (row & 3)
-// the two 16-byte chunks pairs of a block swap with bit 3 of the row (chunk ^= ((row >> 3) & 1) << 1): 4 rows x 2 half-blocks = 64 banks once.
-// Another (fixed) summation order than conv_wgrad_p8_kernel: equal to rounding, bit-reproducible run to run.
 template <bool MF16>
-__global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) {
-  static_assert(MF16, "the 32x32x16 form is conv_wgrad_p8_kernel");
+__global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
   constexpr int BKC = 256, BP = 32, NST = 4;
   constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
-  constexpr int WTN = 128, WTK = 64, TN = 8, TK = 4;            // 16-wide fragments
+  constexpr int WTN = 128, WTK = 64;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -536,7 +337,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
   }
 
   const int prow = tid >> 5;                                    // my two LDS-DMA rows: pixel rows prow and prow + 16 of a stage
-  const int schunk = (tid & 31) ^ ((prow & 3) << 2) ^ (((prow >> 3) & 1) << 1);     // the source chunk that lands in LDS position tid & 31
+  // the source chunk that lands in LDS position tid & 31 of my rows: 64-byte blocks swizzled by (row & 3); MF16: + the half-block swap by bit 3 of the row
+  const int schunk = (tid & 31) ^ ((prow & 3) << 2) ^ (MF16 ? ((prow >> 3) & 1) << 1 : 0);
   const int kcol = k0 + schunk * 8;
   const bool k_ok = kcol < a.Ktot;
   const int tap = k_ok ? kcol / a.Cs : 0;
@@ -599,12 +401,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     dma16_lds(rs_x, sy + T_BYTES, vx);
   };
 
-  f32x4 acc[TK][TN];
-#pragma unroll
-  for (int j = 0; j < TK; ++j)
-#pragma unroll
-    for (int i = 0; i < TN; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
   unsigned vy, vx;
 #pragma unroll
   for (int st = 0; st < 3; ++st)
@@ -614,24 +410,12 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
       stage_half(st, i, vy, vx);
     }
   row_offsets(0, vy, vx);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stage 0 (both halves) has landed
+  if constexpr (MF16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stage 0 (both halves) has landed
+  else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                    // data phase 0 (half 0 of stage 0) has landed
   __builtin_amdgcn_s_barrier();
   if (wn == 1) __builtin_amdgcn_s_barrier();            // the second cout half runs one barrier behind
   asm volatile("" ::: "memory");
 
-  // LDS byte addresses of my fragment reads in the stage being multiplied: lane (i = lane & 15, g = lane >> 4; q = i >> 2, p = i & 3) reads
-  // 8 bytes of row 8 g + q (second read: + 4 rows), channels c0 + 4 p .. + 3 of a 16-channel block
-  unsigned fad[TN + TK];
-  {
-    const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
-    const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * g + q) * 512u + 8u * (pp & 1);
-#pragma unroll
-    for (int k = 0; k < TN + TK; ++k) {
-      const int c0 = k < TN ? wn * WTN + k * 16 : wk * WTK + (k - TN) * 16;
-      const int ch = ((c0 >> 3) + (pp >> 1)) ^ (q << 2) ^ ((g & 1) << 1);
-      fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)ch * 16u;
-    }
-  }
   typedef __attribute__((address_space(3))) s16x4 wgp_lds_v4;
   auto frag = [&](unsigned ad) {
     union { struct { s16x4 a, b; } s; bf16x8 f; } u;
@@ -639,99 +423,218 @@ __global__ __launch_bounds__(512) void conv_wgrad_p16_kernel(const WgradArgs a) 
     u.s.b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((wgp_lds_v4*)(uintptr_t)(ad + 4 * 512));
     return u.f;
   };
-  WG_STAMP_BEGIN();
-  int st_c = 0, st_i = 3;
-  for (int it = 0; it < nit; ++it) {
-    bf16x8 fx[TK], fy[4];
-    // ================= phase A: k-column fragments (kept) + cout fragments 0-3 =================
+  if constexpr (!MF16) {
+    constexpr int TN = 4, TK = 2;                                 // 32-wide fragments
+    f32x16 acc[TN][TK];
 #pragma unroll
-    for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j]);
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) fy[i] = frag(fad[i]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_half(st_i, 0, vy, vx);
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    row_offsets(1, vy, vx);
+      for (int j = 0; j < TK; ++j)
 #pragma unroll
-    for (int j = 0; j < TK; ++j)
-#pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][i], 0, 0, 0);
-#pragma unroll
-    for (int g_ = 0; g_ < 16; ++g_) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    // ================= phase B: cout fragments 4-7 (all 32 pixel rows: reads complete before the barrier) =================
-#pragma unroll
-    for (int i = 0; i < 4; ++i) fy[i] = frag(fad[4 + i]);
-    __builtin_amdgcn_sched_barrier(0);
-    stage_half(st_i, 1, vy, vx);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // every piece of the NEXT step's stage has landed (two steps' pieces stay in flight)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    row_offsets(0, vy, vx);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // LDS byte addresses of my fragment reads in the stage being multiplied (half 0; half 1 = 16 rows = + 8192), see wg_frag_sw; they move
+    // on to the next stage inside phase 1's MFMA segment
+    unsigned fad[TN + TK];
     {
-      const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
+      const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+      const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * (g >> 1) + q) * 512u;
 #pragma unroll
       for (int k = 0; k < TN + TK; ++k) {
-        fad[k] += d;
-        asm volatile("" : "+v"(fad[k]));
+        const int C = (k < TN ? wn * WTN + k * 32 : wk * WTK + (k - TN) * 32) + 16 * (g & 1) + 4 * pp;
+        fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)((((C >> 5) ^ q) << 6) | ((2 * C) & 63));
       }
     }
+    WG_STAMP_BEGIN();
+    int st_c = 0, st_i = 3;
+    for (int it = 0; it < nit; ++it) {
 #pragma unroll
-    for (int j = 0; j < TK; ++j)
+      for (int h = 0; h < 2; ++h) {
+        bf16x8 fy[TN], fx[TK];
+        // ---- load segment: fragments of half h, pieces of half h of step it+3, one counted wait ----
 #pragma unroll
-      for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][4 + i], 0, 0, 0);
+        for (int i = 0; i < TN; ++i) fy[i] = frag(fad[i] + h * 8192);
 #pragma unroll
-    for (int g_ = 0; g_ < 16; ++g_) {
-      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-      __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+        for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j] + h * 8192);
+        __builtin_amdgcn_sched_barrier(0);
+        stage_half(st_i, h, vy, vx);
+        asm volatile("s_waitcnt vmcnt(10)" ::: "memory");  // the half the NEXT phase reads has landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- MFMA segment: 8 MFMAs + the walk of the row the next phase issues (+ the next stage's read addresses) ----
+        row_offsets(h ^ 1, vy, vx);
+        if (h == 1) {
+          const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
+#pragma unroll
+          for (int k = 0; k < TN + TK; ++k) {
+            fad[k] += d;
+            asm volatile("" : "+v"(fad[k]));
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+          for (int j = 0; j < TK; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fy[i], fx[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int g_ = 0; g_ < 8; ++g_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      st_c = (st_c + 1) & 3;
+      st_i = (st_i + 1) & 3;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-    st_c = (st_c + 1) & 3;
-    st_i = (st_i + 1) & 3;
-  }
-  WG_STAMP_END();
-  if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
-  // D: lane & 15 = cout within the fragment, 4 (lane >> 4) + r = k column within the fragment
-  const int l15 = lane & 15, lg = lane >> 4;
-  if (a.ws) {
-    float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
+    WG_STAMP_END();
+    if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
+    const int l31 = lane & 31, lh = lane >> 5;
+    if (a.ws) {
+      float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-      const int nl = wn * WTN + i * 16 + l15;
+      for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const int kl = wk * WTK + j * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            slab[nl * 256 + kl] = acc[i][j][r];
+          }
+        }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
 #pragma unroll
       for (int j = 0; j < TK; ++j) {
-        const int kl = wk * WTK + j * 16 + 4 * lg;
-        *reinterpret_cast<f32x4*>(slab + nl * 256 + kl) = acc[j][i];
-      }
-    }
-    return;
-  }
+        const int k = k0 + wk * WTK + j * 32 + l31;
+        if (k >= a.Ktot) continue;
 #pragma unroll
-  for (int i = 0; i < TN; ++i) {
-    const int n = n0 + wn * WTN + i * 16 + l15;
-    if (n >= a.Cd) continue;
+        for (int r = 0; r < 16; ++r) {
+          const int n = n0 + wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (n < a.Cd) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[i][j][r]);
+        }
+      }
+  } else {
+    constexpr int TN = 8, TK = 4;                                 // 16-wide fragments
+    f32x4 acc[TK][TN];
 #pragma unroll
     for (int j = 0; j < TK; ++j)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = k0 + wk * WTK + j * 16 + 4 * lg + r;
-        if (k < a.Ktot) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[j][i][r]);
+      for (int i = 0; i < TN; ++i) acc[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // LDS byte addresses of my fragment reads in the stage being multiplied: lane (i = lane & 15, g = lane >> 4; q = i >> 2, p = i & 3) reads
+    // 8 bytes of row 8 g + q (second read: + 4 rows), channels c0 + 4 p .. + 3 of a 16-channel block
+    unsigned fad[TN + TK];
+    {
+      const int li = lane & 15, g = lane >> 4, q = li >> 2, pp = li & 3;
+      const unsigned base = (unsigned)(uintptr_t)(lds_void*)smem + (unsigned)(8 * g + q) * 512u + 8u * (pp & 1);
+#pragma unroll
+      for (int k = 0; k < TN + TK; ++k) {
+        const int c0 = k < TN ? wn * WTN + k * 16 : wk * WTK + (k - TN) * 16;
+        const int ch = ((c0 >> 3) + (pp >> 1)) ^ (q << 2) ^ ((g & 1) << 1);
+        fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)ch * 16u;
       }
+    }
+    WG_STAMP_BEGIN();
+    int st_c = 0, st_i = 3;
+    for (int it = 0; it < nit; ++it) {
+      bf16x8 fx[TK], fy[4];
+      // ================= phase A: k-column fragments (kept) + cout fragments 0-3 =================
+#pragma unroll
+      for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j]);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fy[i] = frag(fad[i]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_half(st_i, 0, vy, vx);
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      row_offsets(1, vy, vx);
+#pragma unroll
+      for (int j = 0; j < TK; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][i], 0, 0, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 16; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      // ================= phase B: cout fragments 4-7 (all 32 pixel rows: reads complete before the barrier) =================
+#pragma unroll
+      for (int i = 0; i < 4; ++i) fy[i] = frag(fad[4 + i]);
+      __builtin_amdgcn_sched_barrier(0);
+      stage_half(st_i, 1, vy, vx);
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // every piece of the NEXT step's stage has landed (two steps' pieces stay in flight)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      row_offsets(0, vy, vx);
+      {
+        const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
+#pragma unroll
+        for (int k = 0; k < TN + TK; ++k) {
+          fad[k] += d;
+          asm volatile("" : "+v"(fad[k]));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < TK; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][4 + i], 0, 0, 0);
+#pragma unroll
+      for (int g_ = 0; g_ < 16; ++g_) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 2, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      st_c = (st_c + 1) & 3;
+      st_i = (st_i + 1) & 3;
+    }
+    WG_STAMP_END();
+    if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
+    // D: lane & 15 = cout within the fragment, 4 (lane >> 4) + r = k column within the fragment
+    const int l15 = lane & 15, lg = lane >> 4;
+    if (a.ws) {
+      float* slab = a.ws + ((size_t)t * a.splits + zz) * (256 * 256);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) {
+        const int nl = wn * WTN + i * 16 + l15;
+#pragma unroll
+        for (int j = 0; j < TK; ++j) {
+          const int kl = wk * WTK + j * 16 + 4 * lg;
+          *reinterpret_cast<f32x4*>(slab + nl * 256 + kl) = acc[j][i];
+        }
+      }
+      return;
+    }
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+      const int n = n0 + wn * WTN + i * 16 + l15;
+      if (n >= a.Cd) continue;
+#pragma unroll
+      for (int j = 0; j < TK; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int k = k0 + wk * WTK + j * 16 + 4 * lg + r;
+          if (k < a.Ktot) atomicAdd(a.dw + (size_t)n * a.Ktot + k, acc[j][i][r]);
+        }
+    }
   }
 }
 
@@ -851,7 +754,8 @@ size_t css_wgrad_ws_bytes_(int M, int Ktot, int Cd, int dtype, int n_cu) {
   return (size_t)cdiv(Ktot, bn) * cdiv(Cd, bn) * splits * ((size_t)bn * bn * sizeof(float));
 }
 
-int css_wgrad_mfma_override_ = 0;     // harnesses: 16 / 32 forces the MFMA shape of the 256 x 256 kernel (0: CSS_WGRAD_MFMA, default 16)
+int css_wgrad_mfma_override_ = 0;     // harnesses: 16 / 32 forces the MFMA shape of the 256 x 256 kernel (0: CSS_WGRAD_MFMA, default 32)
+int css_wgrad_no_compact_override_ = 0;   // harnesses: 1 switches the live-row compaction off (as CSS_WGRAD_NO_COMPACT=1)
 int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchProf* prof) {
   if (a.M <= 0) return CSS_OK;
   a.fd_hw = make_fastdiv((uint32_t)(a.Hd * a.Wd));
@@ -885,10 +789,8 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.tiles_n = cdiv(a.Cd, bn);
   a.compact = 0;
   {
-    static const bool env32 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 32;
     static const bool no_compact = getenv("CSS_WGRAD_NO_COMPACT") != nullptr;
-    const bool mf32 = css_wgrad_mfma_override_ ? css_wgrad_mfma_override_ == 32 : env32;
-    if (big && !mf32 && !no_compact && a.R > 1 && a.R <= 3 && a.stride == 1 && a.Cs % 256 == 0) {
+    if (big && !no_compact && !css_wgrad_no_compact_override_ && a.R > 1 && a.R <= 3 && a.stride == 1 && a.Cs % 256 == 0) {
       bool any = false;
       for (int r = 0; r < a.R; ++r) {
         const int dh = r * a.dil - a.pad;
@@ -907,11 +809,11 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   if (prof) prof->begin(big, 1.0, false);
   if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
   if (big) {
-    // the MFMA shape of the 256 x 256 kernel: 16x16x32 (default since round 6: profiles/r06_wgrad_mfma_shape_ab.txt) or 32x32x16 (CSS_WGRAD_MFMA=32)
-    static const bool env32 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 32;
-    const bool mf32 = css_wgrad_mfma_override_ ? css_wgrad_mfma_override_ == 32 : env32;
-    if (mf32) hipLaunchKernelGGL(conv_wgrad_p8_kernel, g, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(conv_wgrad_p16_kernel<true>, g, dim3(512), 0, st, a);
+    // the MFMA shape of the 256 x 256 kernel: 32x32x16 (default: faster by wall, profiles/r06_wgrad_mfma_shape_ab.txt) or 16x16x32 (CSS_WGRAD_MFMA=16)
+    static const bool env16 = getenv("CSS_WGRAD_MFMA") && atoi(getenv("CSS_WGRAD_MFMA")) == 16;
+    const bool mf16 = css_wgrad_mfma_override_ ? css_wgrad_mfma_override_ == 16 : env16;
+    if (mf16) hipLaunchKernelGGL(conv_wgrad_p8_kernel<true>, g, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL(conv_wgrad_p8_kernel<false>, g, dim3(512), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
   } else if (n64) {

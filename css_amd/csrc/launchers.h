@@ -46,7 +46,7 @@ struct WgradArgs {
   int splits, tiles_k, tiles_n;
   float* ws;         // optional workspace for per-slice partial tiles (plain stores + ordered reduction instead of fp32 atomics), or null
   size_t ws_bytes;
-  // Live-row compaction (conv_wgrad_p16_kernel, filled by the launcher; compact = 0: off).  For a dilated R x S convolution the output rows
+  // Live-row compaction (conv_wgrad_p8_kernel, filled by the launcher; compact = 0: off).  For a dilated R x S convolution the output rows
   // whose source row lies in the padding for kernel row r contribute nothing to that row's weights: the pixel loop of a k-column tile of
   // kernel row r runs over the LIVE output rows [row_lo[r], row_lo[r] + row_n[r]) of every image only (row_mps[r] compacted pixels per slice).
   int compact;

@@ -5,7 +5,7 @@ OS-8 map): how many of the EXECUTED K steps multiply an A op
   * for each 64-pixel quarter / 16-pixel group  (what a column-aware skip could at best remove: a quarter is the finest unit the wave tiling could
                                                   skip without restructuring; 16 pixels = one MFMA row block, the theoretical limit),
 
-and for the weight gradient (conv_wgrad_p16_kernel: a tap is a k-column tile, the reduction runs over pixels): the share of 32-pixel steps whose
+and for the weight gradient (conv_wgrad_p8_kernel: a tap is a k-column tile, the reduction runs over pixels): the share of 32-pixel steps whose
 X rows are all padding for the tile's tap.  Tiles are 256 CONSECUTIVE output pixels of the [N][H][W] map (conv_p8.hip tile_info), K step = 64
 channels of one tap; forward and data gradient have the same geometry (the data gradient is the forward with flipped taps).
 Usage: python scripts/aspp_zero_taps.py [H=65] [N=32]   ->  stdout (committed as profiles/r06_aspp_zero_tap_share.txt)

@@ -24,10 +24,11 @@ res = []
 for dt in dts:
     for lr in lrs:
         t = time.time()
-        r = M.run(ds, torch.bfloat16 if dt == "bf16" else torch.float32, epochs, lr=lr, log=lambda s: print(dt, lr, s, flush=True))
+        r = M.run(ds, torch.bfloat16 if dt == "bf16" else torch.float32, epochs, lr=lr, log=lambda s: print(dt, lr, s, flush=True),
+                  workers=int(os.environ.get("MINI_WORKERS", "2")))
         r.pop("trainer")
         r.update(dtype=dt, lr=lr, seconds=time.time() - t, S=S, epochs=epochs)
-        print(dt, lr, "curve", [round(x, 3) for x in r["curve"]], "seconds", round(r["seconds"], 1), flush=True)
+        print(dt, lr, "curve", [round(x, 3) for x in r["curve"]], "seconds", round(r["seconds"], 1), "timing", r["timing"], flush=True)
         res.append(r)
         torch.cuda.empty_cache()
 json.dump(res, open(out, "w"))

@@ -11,7 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
-extern int css_wgrad_mfma_override_;
+extern int css_wgrad_mfma_override_, css_wgrad_no_compact_override_;
 struct Shape { const char* name; int N, H, Cin, Cout, R, dil, count; };
 static float bf2f(unsigned short v) { unsigned u = (unsigned)v << 16; float f; memcpy(&f, &u, 4); return f; }
 int main() {
@@ -21,7 +21,8 @@ int main() {
   std::vector<Shape> shapes = {
       {"l3 1x1 1024->256", NB, H8, 1024, 256, 1, 1, 22}, {"l3 3x3 d2 256->256", NB, H8, 256, 256, 3, 2, 22}, {"l3 1x1 256->1024", NB, H8, 256, 1024, 1, 1, 23},
       {"l4 1x1 2048->512", NB, H8, 2048, 512, 1, 1, 2},  {"l4 3x3 d4 512->512", NB, H8, 512, 512, 3, 4, 2},   {"l4 1x1 512->2048", NB, H8, 512, 2048, 1, 1, 3},
-      {"l4 ds 1024->2048", NB, H8, 1024, 2048, 1, 1, 1}, {"aspp 1x1 2048->256", NB, H8, 2048, 256, 1, 1, 1},  {"aspp 3x3 d12 2048->256", NB, H8, 2048, 256, 3, 12, 3},
+      {"l4 ds 1024->2048", NB, H8, 1024, 2048, 1, 1, 1}, {"aspp 1x1 2048->256", NB, H8, 2048, 256, 1, 1, 1},  {"aspp 3x3 d12 2048->256", NB, H8, 2048, 256, 3, 12, 1},
+      {"aspp 3x3 d24 2048->256", NB, H8, 2048, 256, 3, 24, 1}, {"aspp 3x3 d36 2048->256", NB, H8, 2048, 256, 3, 36, 1},
       {"aspp proj 1280->256", NB, H8, 1280, 256, 1, 1, 1}, {"head 3x3 304->256", NB, H4, 304, 256, 3, 1, 2},  {"l2 1x1 512->... l3 ds 512->1024", NB, H8, 512, 1024, 1, 1, 1},
   };
   const int reps = getenv("WB_REPS") ? atoi(getenv("WB_REPS")) : 20;
@@ -56,8 +57,10 @@ int main() {
     const double flops = 2.0 * M * s.Cout * K;
     if (check) {
       std::vector<float> out[2];
+      const bool ckc = getenv("WB_CHECK_COMPACT") != nullptr;        // compare live-row compaction off / on (32x32x16) instead of the two MFMA shapes
       for (int v = 0; v < 2; ++v) {
-        css_wgrad_mfma_override_ = v ? 16 : 32;
+        css_wgrad_mfma_override_ = ckc ? 32 : (v ? 16 : 32);
+        css_wgrad_no_compact_override_ = ckc ? (v ? 0 : 1) : 0;
         hipMemset(dw, 0, nw * 4);
         css_launch_wgrad(g, CSS_BF16, 256, 0);
         out[v].resize(nw);
@@ -80,10 +83,11 @@ int main() {
         scale = std::max(scale, std::fabs(acc));
         for (int v = 0; v < 2; ++v) worst[v] = std::max(worst[v], std::fabs(out[v][(size_t)n * K + k] - acc));
       }
-      printf("%-34s CHECK 32x32x16 vs 16x16x32: rel-L2 %.2e max %.2e | vs fp64 (64 samples, scale %.1f): 32x32x16 %.2e  16x16x32 %.2e\n", s.name, std::sqrt(d2 / n2), dmax,
-             scale, worst[0] / scale, worst[1] / scale);
+      printf("%-34s CHECK %s: rel-L2 %.2e max %.2e | vs fp64 (64 samples, scale %.1f): first %.2e  second %.2e\n", s.name,
+             ckc ? "compaction off vs on (32x32x16)" : "32x32x16 vs 16x16x32", std::sqrt(d2 / n2), dmax, scale, worst[0] / scale, worst[1] / scale);
     } else {
       css_wgrad_mfma_override_ = mf;
+      css_wgrad_no_compact_override_ = getenv("WB_NOCOMPACT") ? 1 : 0;
       for (int i = 0; i < 3; ++i) css_launch_wgrad(g, CSS_BF16, 256, 0);
       hipDeviceSynchronize();
       hipEvent_t e0, e1;
@@ -97,7 +101,7 @@ int main() {
       const double us = ms / reps * 1e3;
       int splits, mps;
       css_wgrad_plan_(M, K, s.Cout, CSS_BF16, 256, &splits, &mps);
-      printf("%-34s mfma %d  M=%d K=%d N=%d  slices %d  %8.1f us  %7.1f TFLOP/s  x%d", s.name, mf, M, K, s.Cout, splits, us, flops / us / 1e6, s.count);
+      printf("%-34s mfma %d%s  M=%d K=%d N=%d  slices %d  %8.1f us  %7.1f TFLOP/s  x%d", s.name, mf, getenv("WB_NOCOMPACT") ? " nocompact" : "", M, K, s.Cout, splits, us, flops / us / 1e6, s.count);
       tot_us += us * s.count; tot_fl += flops * s.count;
 #ifdef WG_STAMP
       {
@@ -118,6 +122,6 @@ int main() {
     hipFree(dx); hipFree(dy); hipFree(dw);
     if (g.ws) hipFree(g.ws);
   }
-  if (!check) printf("TOTAL mfma %d: %.1f us per step over these launches, %.1f TFLOP/s\n", mf, tot_us, tot_fl / tot_us / 1e6);
+  if (!check) printf("TOTAL mfma %d%s: %.1f us per step over these launches, %.1f TFLOP/s\n", mf, getenv("WB_NOCOMPACT") ? " nocompact" : "", tot_us, tot_fl / tot_us / 1e6);
   return 0;
 }

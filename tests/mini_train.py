@@ -18,6 +18,7 @@ epoch boundary is then the checkpoint alone, which is what makes "resume == neve
 """
 import os
 import random
+import time
 
 import numpy as np
 import torch
@@ -119,41 +120,60 @@ def run(ds, dtype, epochs, seed=1, B=4, lr=0.02, ema_alpha=0.95, perturb=None, c
     start_epoch = 0
     if resume:
         start_epoch = ck.load_checkpoint(resume, tr, exact_resume=True)
+    # pin_memory=True as at mix_label.py:43-58 - and a necessity on this stack: a batch that a worker hands over in shared memory (/dev/shm mapping)
+    # takes ~50 ms per `.to(device)` (800 KB!) when copied from there directly, 0.1 ms from the loader's pinned copy (profiles/r06_mini_training_timing.txt)
     mk = lambda dset, e, tag, shuffle=True: torch.utils.data.DataLoader(
-        dset, batch_size=B, drop_last=True, num_workers=workers, shuffle=shuffle,
+        dset, batch_size=B, drop_last=True, num_workers=workers, shuffle=shuffle, pin_memory=workers > 0,
         generator=torch.Generator().manual_seed(seed * 7919 + 31 * e + tag) if shuffle else None)
     gp = torch.Generator(device=dev).manual_seed(perturb) if perturb is not None else None
     curve, best, losses = [], 0.0, []
+    timing = dict(setup=0.0, data=0.0, h2d=0.0, steps=0.0, eval=0.0, save=0.0)      # seconds: where the wall time of a run goes
+    t_mark = time.time()
+
+    def lap(key, sync=False):
+        nonlocal t_mark
+        if sync:
+            torch.cuda.synchronize()
+        now = time.time()
+        timing[key] += now - t_mark
+        t_mark = now
     for epoch in range(start_epoch, epochs):
         seed_all(seed * 100003 + epoch)                                        # every stream of the epoch from (seed, epoch)
         m.model.train()
         m.ema_model.train()
         u_iter = iter(mk(train_u, epoch, 1))
         acc = None
+        lap("setup")
         for l_img, l_lab in mk(train_l, epoch, 0):                            # mix_label.py:156-165
             u_img, _ = next(u_iter)
+            lap("data")
             l_img, l_lab, u_img = l_img.to(dev), l_lab.to(dev), u_img.to(dev)
+            lap("h2d")
             if gp is not None:
                 l_img = l_img * (1 + 1e-7 * torch.randn(l_img.shape, generator=gp, device=dev))
                 u_img = u_img * (1 + 1e-7 * torch.randn(u_img.shape, generator=gp, device=dev))
             r = tr.step(l_img, l_lab, u_img)
             vec = torch.stack([r[k].float().reshape(()) for k in ("sup", "unsup", "contrast")])
             acc = vec if acc is None else acc + torch.nan_to_num(vec)
+            lap("steps")
         losses.append((acc / steps_per_epoch).tolist())
+        lap("steps", sync=True)
         miou = float(evaluate.test(mk(test_set, epoch, 2, shuffle=False), m.ema_model, cfg))    # mix_label.py:131 (every epoch here)
         curve.append(miou)
         best = max(best, miou)
+        lap("eval", sync=True)
         if log:
             log(f"epoch {epoch} it {tr.it} lr {tr.lr:.5f} losses {[round(x, 4) for x in losses[-1]]} mIoU {miou:.4f} best {best:.4f}")
         if ckpt_dir and miou == best:                                          # mix_label.py:137-147
             ck.save_checkpoint(os.path.join(ckpt_dir, "best_model.pth"), tr, epoch)
         if ckpt_dir and snapshot_epoch == epoch:
             ck.save_checkpoint(os.path.join(ckpt_dir, "snap.pth"), tr, epoch, exact_resume=True)
+        lap("save", sync=True)
     tr.finish()
     torch.cuda.synchronize()
     out = dict(curve=curve, best=best, losses=losses, it=tr.it, fp_student=fingerprint(tr.flat_p), fp_teacher=fingerprint(tr.flat_ema),
                fp_momentum=fingerprint(tr.flat_m), fp_proto=fingerprint(tr.prototypes),
                fp_bn=fingerprint(torch.cat([b.float().flatten() for b in m.ema_model.buffers()])))
-    out["seconds_per_step"] = None
+    out["timing"] = {k: round(v, 2) for k, v in timing.items()}
     out["trainer"] = tr
     return out

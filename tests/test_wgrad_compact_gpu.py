@@ -1,4 +1,4 @@
-"""conv_wgrad_p16_kernel (round 6): the 256 x 256 weight-gradient kernel on v_mfma_f32_16x16x32_bf16 with LIVE-ROW COMPACTION - for a dilated 3x3
+"""conv_wgrad_p8_kernel (round 6): the 256 x 256 weight-gradient kernel with LIVE-ROW COMPACTION - for a dilated 3x3
 convolution the pixel loop of a k-column tile of kernel row r runs only over the output rows whose source row is inside the image for r
 (profiles/r06_aspp_zero_tap_share.txt: 12 / 24 / 40 % of the pixel steps of the ASPP branches multiply all-padding rows otherwise).
 Geometry edge cases against torch-CPU fp32 on the same bf16-rounded operands: dilation >= map height (a kernel row entirely in the padding:
