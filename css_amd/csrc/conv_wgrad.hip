@@ -51,9 +51,25 @@ template <> struct WgFrag<float> {
 // run at the same time on ONE XCD and its slice of dY / X is fetched into a single L2 (measured before: 3.7x over-fetch) - a slice that
 // straddles two ranges is fetched by two.  Round 4: the number of slices is no longer a multiple of 8 (css_wgrad_plan_), so a launch fills
 // whole rounds of the CHIP, not of every XCD: 9 tiles x 28 slices = 252 workgroups in one round instead of 9 x 56 in two.
+// Live-row compaction with two classes of kernel rows (WgradArgs::compact == 2): class c holds nc = tiles_n x cls_nrows[c] x (tiles_k / R) tiles per
+// slice; XCD x takes [x W8c, (x + 1) W8c) of each class's slice-major list, the long class first.
 __device__ __forceinline__ bool wgrad_work_item(const WgradArgs& a, int per_z, int& zz, int& t) {
-  const int total = per_z * a.splits, w8 = (total + 7) >> 3;
   const int xcd = blockIdx.x & 7, j8 = blockIdx.x >> 3;
+  if (a.compact == 2) {
+    const int tpr = a.tiles_k / a.R;
+    const int n0c = a.tiles_n * a.cls_nrows[0] * tpr, n1c = a.tiles_n * a.cls_nrows[1] * tpr;
+    const int w80 = (n0c * a.splits + 7) >> 3, w81 = (n1c * a.splits + 7) >> 3;
+    const int c = j8 < w80 ? 0 : 1;
+    const int jj = c ? j8 - w80 : j8, w8c = c ? w81 : w80, nc = c ? n1c : n0c;
+    const int w = xcd * w8c + jj;
+    if (jj >= w8c || w >= nc * a.splits) return false;
+    zz = w / nc;
+    const int rem = w - zz * nc, per_nt = a.cls_nrows[c] * tpr;
+    const int nt = rem / per_nt, rem2 = rem - nt * per_nt, ri = rem2 / tpr;
+    t = nt * a.tiles_k + a.cls_rows[c][ri] * tpr + (rem2 - ri * tpr);
+    return true;
+  }
+  const int total = per_z * a.splits, w8 = (total + 7) >> 3;
   const int w = xcd * w8 + j8;
   if (j8 >= w8 || w >= total) return false;
   zz = w / per_z;
@@ -272,10 +288,11 @@ __device__ __forceinline__ bf16x8 wg_frag_sw(const unsigned char* tile, int kk0,
 // v_mfma_f32_16x16x32_bf16 - the shape the chip holds a higher clock on under load (MI355X_MICROARCH.md DVFS give-back item 7; the forward
 // kernel made this move in round 3).  An MFMA now reduces over ALL 32 pixels of a step, so the two phases of a step split the wave's
 // 128 (cout) x 64 (k column) tile by cout instead of by pixel:
-//     phase A [8 + 8 transposed reads: X fragments 0-3 (kept for phase B), dY fragments 0-3 | pieces of half 0 of step t+3]           s_barrier
-//             [lgkmcnt(0) | 16 MFMAs 16x16x32, the walk of pixel row 1 between them]                                                    s_barrier
-//     phase B [8 transposed reads: dY fragments 4-7 | pieces of half 1 of step t+3 | vmcnt(8): ALL of stage t+1 landed | lgkmcnt(0)]  s_barrier
-//             [16 MFMAs, the walk of pixel row 0 and the next stage's read addresses between them]                                      s_barrier
+//     phase A [12 transposed reads: X fragments 2, 3 + dY fragments 0-3 | pieces of half 0 of step t+4 | vmcnt(10): ALL of stage t+1 landed]        s_barrier
+//             [lgkmcnt(0) | 16 MFMAs 16x16x32, the walk of pixel row 1 between them]                                                              s_barrier
+//     phase B [12 transposed reads: dY fragments 4-7 + X fragments 0, 1 of step t+1 | pieces of half 1 of step t+4 | lgkmcnt(0)]                  s_barrier
+//             [16 MFMAs, the walk of pixel row 0 and the next stage's read addresses between them]                                                s_barrier
+// (five stages: the one read ahead by phase B must have landed one phase earlier than in the 32x32x16 form)
 // Phase B reads all 32 pixel rows of the stage, and the very next phase (phase A of the next step; for the other cout half of the workgroup,
 // which runs one barrier behind, the same barrier slot) restages its half 0: phase B therefore completes its reads BEFORE its barrier.
 // Operand roles: A = X^T (rows = k columns), B = dY (columns = cout), so D has cout on the lane and 4 consecutive k columns in the 4
@@ -308,7 +325,7 @@ __device__ unsigned long long* wg_stamp_buf = nullptr;
 #endif
 template <bool MF16>
 __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
-  constexpr int BKC = 256, BP = 32, NST = 4;
+  constexpr int BKC = 256, BP = 32, NST = MF16 ? 5 : 4;         // MF16: five 32 KiB stages (160 KiB: all of the CU's LDS), four steps in flight
   constexpr int T_BYTES = BP * 512, ST_BYTES = 2 * T_BYTES;     // Y tile then X tile
   constexpr int WTN = 128, WTK = 64;
   __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * ST_BYTES];
@@ -403,14 +420,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 
   unsigned vy, vx;
 #pragma unroll
-  for (int st = 0; st < 3; ++st)
+  for (int st = 0; st < NST - 1; ++st)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       row_offsets(i, vy, vx);
       stage_half(st, i, vy, vx);
     }
   row_offsets(0, vy, vx);
-  if constexpr (MF16) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");     // stage 0 (both halves) has landed
+  if constexpr (MF16) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");    // stage 0 (both halves) has landed
   else asm volatile("s_waitcnt vmcnt(10)" ::: "memory");                    // data phase 0 (half 0 of stage 0) has landed
   __builtin_amdgcn_s_barrier();
   if (wn == 1) __builtin_amdgcn_s_barrier();            // the second cout half runs one barrier behind
@@ -541,17 +558,26 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
         fad[k] = base + (k < TN ? 0u : (unsigned)T_BYTES) + (unsigned)ch * 16u;
       }
     }
+    // The k-column fragments 0 and 1 of a step are read one phase EARLY (phase B of the step before, from the next stage), so that both load
+    // segments issue 12 transposed reads (the first version read 16 + 8: the 16-read segment alone takes the LDS array ~256 cycles for the
+    // four waves of a CU that load at the same time - as long as the partner's whole MFMA segment; profiles/r06_wgrad_mfma_shape_ab.txt).
+    bf16x8 fxa[2], fxb[2];
+    fxa[0] = frag(fad[TN + 0]);
+    fxa[1] = frag(fad[TN + 1]);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WG_STAMP_BEGIN();
-    int st_c = 0, st_i = 3;
-    for (int it = 0; it < nit; ++it) {
-      bf16x8 fx[TK], fy[4];
-      // ================= phase A: k-column fragments (kept) + cout fragments 0-3 =================
-#pragma unroll
-      for (int j = 0; j < TK; ++j) fx[j] = frag(fad[TN + j]);
+    int st_c = 0, st_i = NST - 1;
+    // one step: `cur` = this step's k-column fragments 0, 1 (already in registers), `nxt` = where the next step's go
+    auto step = [&](bf16x8 (&cur)[2], bf16x8 (&nxt)[2]) {
+      bf16x8 fx23[2], fy[4];
+      // ================= phase A: k-column fragments 2, 3 + cout fragments 0-3 (12 reads) =================
+      fx23[0] = frag(fad[TN + 2]);
+      fx23[1] = frag(fad[TN + 3]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) fy[i] = frag(fad[i]);
       __builtin_amdgcn_sched_barrier(0);
       stage_half(st_i, 0, vy, vx);
+      asm volatile("s_waitcnt vmcnt(10)" ::: "memory");   // every piece of the NEXT step's stage has landed (phase B reads its k-column tile): 2.5 steps stay in flight
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -560,7 +586,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < TK; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? cur[j] : fx23[j - 2], fy[i], acc[j][i], 0, 0, 0);
 #pragma unroll
       for (int g_ = 0; g_ < 16; ++g_) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -570,29 +596,29 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      // ================= phase B: cout fragments 4-7 (all 32 pixel rows: reads complete before the barrier) =================
+      // ================= phase B: cout fragments 4-7 + the NEXT step's k-column fragments 0, 1 (12 reads; this stage's reads complete before
+      // the barrier: the next phase restages its half 0) =================
+      const unsigned dn = st_c == NST - 1 ? (unsigned)(-(NST - 1) * ST_BYTES) : (unsigned)ST_BYTES;
 #pragma unroll
       for (int i = 0; i < 4; ++i) fy[i] = frag(fad[4 + i]);
+      nxt[0] = frag(fad[TN + 0] + dn);
+      nxt[1] = frag(fad[TN + 1] + dn);
       __builtin_amdgcn_sched_barrier(0);
       stage_half(st_i, 1, vy, vx);
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");    // every piece of the NEXT step's stage has landed (two steps' pieces stay in flight)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
       row_offsets(0, vy, vx);
-      {
-        const unsigned d = st_c == 3 ? (unsigned)(-3 * ST_BYTES) : (unsigned)ST_BYTES;
 #pragma unroll
-        for (int k = 0; k < TN + TK; ++k) {
-          fad[k] += d;
-          asm volatile("" : "+v"(fad[k]));
-        }
+      for (int k = 0; k < TN + TK; ++k) {
+        fad[k] += dn;
+        asm volatile("" : "+v"(fad[k]));
       }
 #pragma unroll
       for (int j = 0; j < TK; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fx[j], fy[i], acc[j][4 + i], 0, 0, 0);
+        for (int i = 0; i < 4; ++i) acc[j][4 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(j < 2 ? cur[j] : fx23[j - 2], fy[i], acc[j][4 + i], 0, 0, 0);
 #pragma unroll
       for (int g_ = 0; g_ < 16; ++g_) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
@@ -602,9 +628,15 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
-      st_c = (st_c + 1) & 3;
-      st_i = (st_i + 1) & 3;
+      st_c = st_c == NST - 1 ? 0 : st_c + 1;
+      st_i = st_i == NST - 1 ? 0 : st_i + 1;
+    };
+    int it = 0;
+    for (; it + 1 < nit; it += 2) {          // (pairs: the fragments carried from step to step alternate between two register sets - no moves)
+      step(fxa, fxb);
+      step(fxb, fxa);
     }
+    if (it < nit) step(fxa, fxb);
     WG_STAMP_END();
     if (wn == 0) __builtin_amdgcn_s_barrier();            // the barrier the other half ran at the start
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // ghost DMAs must have landed before the workgroup's LDS is released
@@ -803,9 +835,22 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
         any = any || a.row_n[r] < a.Hd;
       }
       a.compact = any ? 1 : 0;
+      static const bool no_lpt = getenv("CSS_WGRAD_NO_LONGEST_FIRST") != nullptr;
+      if (any && !no_lpt && a.tiles_k % a.R == 0) {              // two classes: rows with every output row live / the others
+        a.cls_nrows[0] = a.cls_nrows[1] = 0;
+        for (int r = 0; r < a.R; ++r) {
+          const int c = a.row_n[r] == a.Hd ? 0 : 1;
+          a.cls_rows[c][a.cls_nrows[c]++] = r;
+        }
+        if (a.cls_nrows[0] > 0 && a.cls_nrows[1] > 0) a.compact = 2;
+      }
     }
   }
   dim3 g(cdiv((long)a.tiles_k * a.tiles_n * splits, 8) * 8);      // (wgrad_work_item: XCD x takes work items [x W8, (x + 1) W8))
+  if (a.compact == 2) {
+    const int tpr = a.tiles_k / a.R;
+    g = dim3(8 * (cdiv(a.tiles_n * a.cls_nrows[0] * tpr * splits, 8) + cdiv(a.tiles_n * a.cls_nrows[1] * tpr * splits, 8)));
+  }
   if (prof) prof->begin(big, 1.0, false);
   if ((size_t)a.tiles_k * a.tiles_n * a.splits * ((size_t)bn * bkc * sizeof(float)) > a.ws_bytes) a.ws = nullptr;   // atomics path (not reproducible)
   if (big) {

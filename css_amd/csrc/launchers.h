@@ -51,6 +51,10 @@ struct WgradArgs {
   // kernel row r runs over the LIVE output rows [row_lo[r], row_lo[r] + row_n[r]) of every image only (row_mps[r] compacted pixels per slice).
   int compact;
   int row_lo[3], row_n[3], row_mps[3];
+  // compact = 2: the kernel rows fall into a LONG class (all output rows live: the centre row) and a SHORT class; every XCD is dealt its share
+  // of the long work items first, then its share of the short ones (longest-first: the short items fill the round's tail).  cls_rows[c] lists
+  // the kernel rows of class c (cls_nrows[c] of them).
+  int cls_nrows[2], cls_rows[2][3];
   FastDiv fd_L[3];   // division by row_n[r] * Wd
 };
 

@@ -35,6 +35,7 @@ def _strip(r):
     return r
 
 
+@pytest.mark.timeout(600)      # (the whole test takes ~60 s; a loader that hands batches over in unpinned shared memory once stalled a copy for 20 minutes)
 def test_mini_training_reads_an_miou_in_fp32_and_bf16_and_resumes_bit_for_bit(tmp_path):
     from css_amd import evaluate
     ds = M.make_dataset(str(tmp_path / "voc"), str(tmp_path / "txt"))
