@@ -583,6 +583,19 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_sched_barrier(0);
       row_offsets(1, vy, vx);
+      // (the read addresses this phase is done with move on to the next stage here, the other half in phase B: the vector issue port has room for
+      // two VALU instructions per 16x16x32 MFMA - 32 per segment - and the walk of a pixel row takes ~22 of them)
+      const unsigned dn = st_c == NST - 1 ? (unsigned)(-(NST - 1) * ST_BYTES) : (unsigned)ST_BYTES;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        fad[k] += dn;
+        asm volatile("" : "+v"(fad[k]));
+      }
+#pragma unroll
+      for (int k = TN + 2; k < TN + 4; ++k) {
+        fad[k] += dn;
+        asm volatile("" : "+v"(fad[k]));
+      }
 #pragma unroll
       for (int j = 0; j < TK; ++j)
 #pragma unroll
@@ -598,7 +611,6 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       // ================= phase B: cout fragments 4-7 + the NEXT step's k-column fragments 0, 1 (12 reads; this stage's reads complete before
       // the barrier: the next phase restages its half 0) =================
-      const unsigned dn = st_c == NST - 1 ? (unsigned)(-(NST - 1) * ST_BYTES) : (unsigned)ST_BYTES;
 #pragma unroll
       for (int i = 0; i < 4; ++i) fy[i] = frag(fad[4 + i]);
       nxt[0] = frag(fad[TN + 0] + dn);
@@ -611,7 +623,7 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       row_offsets(0, vy, vx);
 #pragma unroll
-      for (int k = 0; k < TN + TK; ++k) {
+      for (int k = 4; k < TN + 2; ++k) {
         fad[k] += dn;
         asm volatile("" : "+v"(fad[k]));
       }

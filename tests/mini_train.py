@@ -96,7 +96,7 @@ def fingerprint(t):
 
 
 def run(ds, dtype, epochs, seed=1, B=4, lr=0.02, ema_alpha=0.95, perturb=None, ckpt_dir=None, snapshot_epoch=None, resume=None,
-        workers=2, device=None, log=None):
+        workers=0, device=None, log=None, mp_context=None):
     """The main loop of mix_label.py:86-147 for ``epochs`` epochs.  ``perturb``: seed of a 1-ulp relative perturbation of every input batch
     (the "another correct fp32 run" of the mIoU noise floor).  ``snapshot_epoch``: also save <ckpt_dir>/snap.pth after that epoch (exact-resume
     format).  ``resume``: path of a checkpoint to continue from.  Returns the mIoU curve, the best mIoU, fingerprints of the final state."""
@@ -120,10 +120,12 @@ def run(ds, dtype, epochs, seed=1, B=4, lr=0.02, ema_alpha=0.95, perturb=None, c
     start_epoch = 0
     if resume:
         start_epoch = ck.load_checkpoint(resume, tr, exact_resume=True)
-    # pin_memory=True as at mix_label.py:43-58 - and a necessity on this stack: a batch that a worker hands over in shared memory (/dev/shm mapping)
-    # takes ~50 ms per `.to(device)` (800 KB!) when copied from there directly, 0.1 ms from the loader's pinned copy (profiles/r06_mini_training_timing.txt)
+    # workers = 0 by default: with FORKED loader workers alive beside a live HIP context every step of the parent slows down 4-6x on this stack
+    # (170 ms instead of 31-50 per step, 5 s per 16-image evaluation, once a 20-minute stall; pinned or not: profiles/r06_mini_training_timing.txt) -
+    # a property of fork() next to the GPU runtime, not of this library; INTEGRATION.md 5 says what a training script should pass instead.
     mk = lambda dset, e, tag, shuffle=True: torch.utils.data.DataLoader(
         dset, batch_size=B, drop_last=True, num_workers=workers, shuffle=shuffle, pin_memory=workers > 0,
+        multiprocessing_context=mp_context if workers > 0 else None,
         generator=torch.Generator().manual_seed(seed * 7919 + 31 * e + tag) if shuffle else None)
     gp = torch.Generator(device=dev).manual_seed(perturb) if perturb is not None else None
     curve, best, losses = [], 0.0, []

@@ -2,8 +2,9 @@
 reference" clause, whose real form needs Pascal VOC and ImageNet weights this pool does not have).
 
 tests/mini_train.py runs the reference's main loop (mix_label.py:86-147) on a synthetic but learnable segmentation task, through every (f) row of
-SURVEY 8 at once: VOC-shaped tree -> VOC_BuildData -> DataLoaders (workers) -> MixTrainer.step (device_aug='pil', cutmix) -> evaluate.test on the
-EMA model -> save_checkpoint at the best mIoU -> load_checkpoint and continue.  129 x 129 crops, B = 4 + 4, 6 epochs of 32 steps, lr 0.01.
+SURVEY 8 at once: VOC-shaped tree -> VOC_BuildData -> DataLoaders -> MixTrainer.step (device_aug='pil', cutmix) -> evaluate.test on the
+EMA model -> save_checkpoint at the best mIoU -> load_checkpoint and continue.  129 x 129 crops, B = 4 + 4, 6 epochs of 32 steps, lr 0.01
+(loaders in the main process: see tests/mini_train.py on forked workers next to a live HIP context).
 
 Asserted:
   (i)   the validation mIoU of the EMA model rises from chance level (< 0.45 after the first epoch, 6 classes) to >= 0.80 - in fp32 AND in bf16;
