@@ -72,40 +72,26 @@ if world > 1:
 '''
 
 
-def _start(world, out, bf16=False, same=False, port="29577"):
+def _run(world, out, bf16=False, same=False):
     code = WORKER % ROOT
     procs = []
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
         if bf16:
             env["CSS_TEST_BF16"] = "1"
         if same:
             env["CSS_TEST_SAME_DATA"] = "1"
         procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
-    return procs
-
-
-def _wait(procs, timeout=600):
     for p in procs:
-        assert p.wait(timeout=timeout) == 0
-
-
-def _run(world, out, bf16=False, same=False):
-    _wait(_start(world, out, bf16, same))
-
-
-def _run_both(a, b, bf16=False, same=False):
-    """The single-process run and the two-rank run side by side on the one GPU (independent processes, their own rendezvous port): half the wall
-    time of one after the other."""
-    pa, pb = _start(1, a, bf16, same, "29577"), _start(2, b, bf16, same, "29587")
-    _wait(pa + pb)
+        assert p.wait(timeout=600) == 0
 
 
 def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
     import json
     import torch
     a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run_both(a, b)
+    _run(1, a)
+    _run(2, b)
     r1, r2 = json.load(open(a)), json.load(open(b))
     assert abs(r1["loss"] - r2["loss"]) < 1e-4 * abs(r1["loss"])
     p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"][: len(r1["pred"])])
@@ -128,7 +114,8 @@ def test_two_ranks_bf16_fused_statistics_path(tmp_path):
     import json
     import torch
     a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run_both(a, b, bf16=True)
+    _run(1, a, bf16=True)
+    _run(2, b, bf16=True)
     r1, r2 = json.load(open(a)), json.load(open(b))
     assert abs(r1["loss"] - r2["loss"]) < 2e-2 * abs(r1["loss"])
     n = len(r2["pred"])
@@ -171,7 +158,8 @@ def test_two_ranks_bf16_identical_halves_equal_one_rank(tmp_path):
     import json
     import torch
     a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run_both(a, b, bf16=True, same=True)
+    _run(1, a, bf16=True, same=True)
+    _run(2, b, bf16=True, same=True)
     r1, r2 = json.load(open(a)), json.load(open(b))
     assert abs(r1["loss"] - r2["loss"]) < 1e-5 * abs(r1["loss"])
     p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"])
@@ -228,38 +216,21 @@ dist.destroy_process_group()
 '''
 
 
-def _trainer_pair_start(tmp_path, bucket_mb, steps="3", port="29578"):
+def _trainer_pair(tmp_path, bucket_mb, steps="3"):
+    import json
     out = str(tmp_path / f"r{bucket_mb}_")
     code = TRAINER_WORKER % ROOT
     procs = []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port, CSS_GRAD_BUCKET_MB=bucket_mb,
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", CSS_GRAD_BUCKET_MB=bucket_mb,
                    CSS_TEST_STEPS=steps)
         procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
-    return procs, out
-
-
-def _trainer_pair_collect(started):
-    import json
-    procs, out = started
-    _wait(procs, 900)
+    for p in procs:
+        assert p.wait(timeout=900) == 0
     return json.load(open(out + "0")), json.load(open(out + "1"))
 
 
-_PAIRS = {}      # the three trainer pairs of the two tests below run side by side (six processes on the one GPU), started by whichever test comes first
-
-
-def _trainer_pairs(tmp_path_factory):
-    if not _PAIRS:
-        d = tmp_path_factory.mktemp("trainer_pairs")
-        started = {"8": _trainer_pair_start(d, "8", "2", "29578"), "0": _trainer_pair_start(d, "0", "2", "29588"),
-                   "48": _trainer_pair_start(d, "48", "3", "29598")}
-        for k, st in started.items():
-            _PAIRS[k] = _trainer_pair_collect(st)
-    return _PAIRS
-
-
-def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path_factory):
+def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
     """The gradient all-reduce overlapped with backward in buckets (train_step.MixTrainer._backward_and_reduce; DDP's buckets at
     mix_label.py:77) against ONE all-reduce after backward (CSS_GRAD_BUCKET_MB=0): two steps (the first records the readiness order,
     the second runs bucketed), replicas bit-identical in both modes, and the two modes equal up to run-to-run noise (the order of
@@ -268,8 +239,8 @@ def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path_fact
     or reduced one twice breaks the replica equality (the gradient of that range is then no longer the same sum on both ranks) or
     shows up as O(1))."""
     import torch
-    pairs = _trainer_pairs(tmp_path_factory)
-    (a8, b8), (a0, b0) = pairs["8"], pairs["0"]
+    a8, b8 = _trainer_pair(tmp_path, "8", "2")
+    a0, b0 = _trainer_pair(tmp_path, "0", "2")
     print("buckets / runs / parameters reported:", a8["buckets"])
     assert a8["buckets"][0] >= 10 and a8["buckets"][2] > 300 and a0["buckets"] == [0, 0, 0]
     assert a8["buckets"][1] <= a8["buckets"][0] + 4              # backward runs the layers in reverse: a bucket is one or two runs
@@ -281,12 +252,12 @@ def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path_fact
     assert err < 3e-2
 
 
-def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path_factory):
+def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
     """MixTrainer.step on two ranks (bf16, different data per rank): SyncBN statistics, the prototype class sums and the flat
     gradient are all-reduced, so after three steps both replicas hold the same parameters, EMA teacher, BN running statistics and
     prototypes (for the classes both ranks see) - the data-parallel contract of mix_label.py:76-77."""
     import torch
-    a, b = _trainer_pairs(tmp_path_factory)["48"]
+    a, b = _trainer_pair(tmp_path, "48")
     # (the unsupervised term is NaN-valued with zero gradient when no pseudo-label is confident, like the reference: SURVEY L2)
     assert all(v == v and abs(v) < 1e3 for l in a["losses"] + b["losses"] for v in l), (a["losses"], b["losses"])
     pa, pb = torch.tensor(a["p"]), torch.tensor(b["p"])
@@ -416,13 +387,12 @@ def test_rccl_collectives_on_one_rank_change_nothing(tmp_path):
     launch a multi-GPU node would use) instead of RCCL."""
     import json
     import torch
-    outs, started = [], []
-    for i, (force, mode) in enumerate((("0", "rccl"), ("1", "rccl"), ("1", "peer"))):       # (the three processes side by side, a port each)
+    outs = []
+    for force, mode in (("0", "rccl"), ("1", "rccl"), ("1", "peer")):
         out = str(tmp_path / f"r{force}{mode}.json")
-        env = dict(os.environ, CSS_FORCE_COLLECTIVES=force, CSS_SYNCBN=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29579 + 10 * i), RANK="0",
-                   WORLD_SIZE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-        started.append((subprocess.Popen([sys.executable, "-c", RCCL_WORKER % ROOT, out], env=env), out))
-    for p, out in started:
+        env = dict(os.environ, CSS_FORCE_COLLECTIVES=force, CSS_SYNCBN=mode, MASTER_ADDR="127.0.0.1", MASTER_PORT="29579", RANK="0", WORLD_SIZE="1",
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        p = subprocess.Popen([sys.executable, "-c", RCCL_WORKER % ROOT, out], env=env)
         assert p.wait(timeout=900) == 0
         outs.append(json.load(open(out)))
     a = outs[0]

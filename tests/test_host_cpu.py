@@ -867,3 +867,93 @@ def test_round4_host_logic():
         assert -(-ktot // 256) * -(-cd // 256) * s_ == want_wgs, (ktot, cd, s_)
     assert peer.enabled() is (os.environ.get("CSS_SYNCBN", "rccl") == "peer")
     assert _lib.query("css_peer_buffer_bytes", 100) == (4 * 100 + 4) * 8
+
+
+# ---- round 6: the live-row compaction of conv_wgrad_p8_kernel, replayed on the host -------------------------------------------------------------
+def _wgrad_compact_replay(N, H, W, dil, pad, splits, ldx=8, ldy=8, stride=1, BP=32):
+    """A line-by-line restatement of the index arithmetic of css_launch_wgrad (row_lo / row_n / row_mps) and of conv_wgrad_p8_kernel's prologue and
+    row walk (css_amd/csrc/conv_wgrad.hip: `row_offsets`): for every kernel row r, slice zz and LDS-DMA row (prow, i) it yields the sequence of
+    (compacted index, dY element offset, X element offset of tap column s = 1, in-range flag) the kernel would issue."""
+    Hs, Ws, Hd, Wd, R = H, W, H, W, 3
+    out = {}
+    for r in range(R):
+        dh = r * dil - pad
+        lo, hi = max(0, -dh), min(Hd - 1, Hs - 1 - dh)
+        if hi < lo:
+            lo, hi = 0, Hd - 1
+        nrows = hi - lo + 1
+        L = nrows * Wd
+        mps = -(-(-(-(N * L) // splits)) // BP) * BP
+        dw_ = 1 * dil - pad                                    # tap column s = 1
+        q_w = BP // Wd
+        d_w = BP - q_w * Wd
+        d_n = BP // L
+        d_h = q_w - d_n * nrows
+        sx_w, sx_h, sx_n = stride * ldx, stride * Ws * ldx, Hs * Ws * ldx
+        D0, Dw, Dh = d_n * sx_n + d_h * sx_h + d_w * sx_w, sx_h - Wd * sx_w, sx_n - nrows * sx_h
+        Yh = (Hd * Wd - L) * ldy
+        ystep = BP * ldy + d_n * Yh
+        hs_hi, ws_hi = (lo + nrows - 1) * stride + dh, (Wd - 1) * stride + dw_
+        for zz in range(splits):
+            m_begin, m_end = zz * mps, min(N * L, zz * mps + mps)
+            nit = max(0, -(-(m_end - m_begin) // BP))
+            for prow in range(16):
+                for i in range(2):
+                    m = m_begin + prow + 16 * i
+                    n_img, rem = divmod(m, L)
+                    hq, wd = divmod(rem, Wd)
+                    hd = lo + hq
+                    hs, ws = hd * stride + dh, wd * stride + dw_
+                    xo = ((n_img * Hs * Ws + hs * Ws + ws) * ldx)
+                    yo = (((n_img * Hd + hd) * Wd + wd) * ldy)
+                    seq = []
+                    for _ in range(nit):
+                        ok = m < m_end and 0 <= hs < Hs and 0 <= ws < Ws
+                        seq.append((m, yo if m < m_end else None, xo if ok else None))
+                        m += BP
+                        ws2, hs2, dx = ws + d_w * stride, hs + d_h * stride, D0
+                        cw = ws2 > ws_hi
+                        ws2 -= Wd * stride if cw else 0
+                        hs2 += stride if cw else 0
+                        dx += Dw if cw else 0
+                        ch = hs2 > hs_hi
+                        hs2 -= nrows * stride if ch else 0
+                        dx += Dh if ch else 0
+                        ws, hs = ws2, hs2
+                        xo += dx
+                        yo += ystep + (Yh if ch else 0)
+                    out[(r, zz, prow, i)] = (lo, nrows, seq)
+    return out
+
+
+@pytest.mark.parametrize("N,H,W,dil,splits", [(3, 17, 17, 12, 2), (5, 33, 29, 6, 3), (4, 65, 65, 36, 7), (7, 5, 5, 2, 1), (2, 40, 70, 1, 4), (2, 9, 9, 12, 2)])
+def test_wgrad_live_row_compaction_walk_visits_exactly_the_live_pixels(N, H, W, dil, splits):
+    """Every live output pixel of kernel row r (and no other) is visited exactly once across the slices, in increasing order inside a DMA row, with
+    the dY / X offsets of that pixel - the invariant the weight gradient of a dilated 3x3 convolution rests on."""
+    ldx = ldy = 8
+    rep = _wgrad_compact_replay(N, H, W, dil, dil, splits, ldx, ldy)
+    for r in range(3):
+        seen = {}
+        lo = nrows = None
+        for (rr, zz, prow, i), (lo_r, nrows_r, seq) in rep.items():
+            if rr != r:
+                continue
+            lo, nrows = lo_r, nrows_r
+            for m, yo, xo in seq:
+                if yo is None:
+                    continue
+                assert m not in seen, (r, m)
+                seen[m] = (yo, xo)
+        L = nrows * W
+        assert sorted(seen) == list(range(N * L)), (r, len(seen), N * L)
+        dh, dw_ = r * dil - dil, 0
+        for m, (yo, xo) in seen.items():
+            n_img, rem = divmod(m, L)
+            hd, wd = lo + rem // W, rem % W
+            assert yo == ((n_img * H + hd) * W + wd) * ldy, (r, m)
+            hs, ws = hd + dh, wd + dw_
+            want = ((n_img * H + hs) * W + ws) * ldx if (0 <= hs < H and 0 <= ws < W) else None
+            assert xo == want, (r, m, xo, want)
+        # the compaction drops exactly the rows whose source row is in the padding (or nothing, when the whole kernel row is: computed as zeros)
+        live = [h for h in range(H) if 0 <= h + dh < H]
+        assert (lo, nrows) == ((live[0], len(live)) if live else (0, H))
