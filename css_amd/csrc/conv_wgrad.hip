@@ -833,7 +833,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.tiles_n = cdiv(a.Cd, bn);
   a.compact = 0;
   {
-    static const bool no_compact = getenv("CSS_WGRAD_NO_COMPACT") != nullptr;
+    static const bool no_compact = getenv("CSS_WGRAD_NO_COMPACT") && atoi(getenv("CSS_WGRAD_NO_COMPACT")) != 0;
     if (big && !no_compact && !css_wgrad_no_compact_override_ && a.R > 1 && a.R <= 3 && a.stride == 1 && a.Cs % 256 == 0) {
       bool any = false;
       for (int r = 0; r < a.R; ++r) {
@@ -847,7 +847,7 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
         any = any || a.row_n[r] < a.Hd;
       }
       a.compact = any ? 1 : 0;
-      static const bool no_lpt = getenv("CSS_WGRAD_NO_LONGEST_FIRST") != nullptr;
+      static const bool no_lpt = getenv("CSS_WGRAD_NO_LONGEST_FIRST") && atoi(getenv("CSS_WGRAD_NO_LONGEST_FIRST")) != 0;
       if (any && !no_lpt && a.tiles_k % a.R == 0) {              // two classes: rows with every output row live / the others
         a.cls_nrows[0] = a.cls_nrows[1] = 0;
         for (int r = 0; r < a.R; ++r) {
