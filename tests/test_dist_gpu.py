@@ -29,70 +29,81 @@ dev = torch.device("cuda:0")
 if world > 1:
     dist.init_process_group("gloo", rank=rank, world_size=world)
 K, S, seed = 21, 65, 5
-net = DeepLabv3Plus_with_rep(resnet.resnet101_tv(), dilate_scale=8, num_classes=K)
-net.load_state_dict(O.init_state("tv", K, 256, seed, 0.25))
-net = net.to(dev).train()
-if os.environ.get("CSS_TEST_BF16"):
-    net.set_compute_dtype(torch.bfloat16)    # bf16: batch-norm statistics come from the conv epilogue (slab rows) before the all-reduce
-g = torch.Generator().manual_seed(1)
-x = torch.randn(4, 3, S, S, generator=g)
-lab = torch.randint(0, K, (4, S, S), generator=g)
-if os.environ.get("CSS_TEST_SAME_DATA"):
-    x, lab = x[:2], lab[:2]                  # every rank (and the single process) holds the SAME two images: a deterministic comparison
-elif world > 1:
-    x, lab = x[2 * rank: 2 * rank + 2], lab[2 * rank: 2 * rank + 2]
-pred, rep = net(x.to(dev))
-large = ops.bilinear(pred.permute(0, 2, 3, 1).contiguous(), S, S, torch.float32).permute(0, 3, 1, 2)
-loss = CrossEntropyLoss(-1)(large, lab.to(dev)) + rep.float().pow(2).mean()
-loss.backward()
-grads = torch.cat([p.grad.flatten() for p in net.parameters()])
-if world > 1:
-    dist.all_reduce(grads)
-    grads /= world
-    l = loss.detach().clone()
-    dist.all_reduce(l)
-    loss = l / world
-probe = grads[:: grads.numel() // 4096][:4096].cpu()
-# per-parameter samples along the backward chain (16 parameters, evenly spread; <= 512 elements each)
-layers, o = {}, 0
-plist = list(net.named_parameters())
-for i, (n_, p_) in enumerate(plist):
-    if i %% max(len(plist) // 16, 1) == 0:
-        gsl = grads[o:o + p_.numel()]
-        layers[n_] = gsl[:: max(gsl.numel() // 509, 1) | 1][:512].cpu().tolist()      # (odd stride: no aliasing with the [Cout][R][S][Cin] layout)
-    o += p_.numel()
-tail = grads[-(grads.numel() // 4):]                       # ASPP + decoder heads: the layers closest to the loss
-tail = tail[:: tail.numel() // 4096][:4096].cpu()
-out = dict(loss=float(loss), pred=pred.detach().float().cpu().flatten()[::97].tolist(), grad=probe.tolist(), grad_tail=tail.tolist(),
-           rm=net.resnet_bn1.running_mean.cpu().tolist(), layers=layers)
-if rank == 0:
-    json.dump(out, open(sys.argv[1], "w"))
+sd = O.init_state("tv", K, 256, seed, 0.25)
+
+
+def run(mode):                               # mode: "fp32" | "bf16" | "bf16same" (one process serves all three: start-up and imports paid once)
+    net = DeepLabv3Plus_with_rep(resnet.resnet101_tv(), dilate_scale=8, num_classes=K)
+    net.load_state_dict(sd)
+    net = net.to(dev).train()
+    if mode != "fp32":
+        net.set_compute_dtype(torch.bfloat16)    # bf16: batch-norm statistics come from the conv epilogue (slab rows) before the all-reduce
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(4, 3, S, S, generator=g)
+    lab = torch.randint(0, K, (4, S, S), generator=g)
+    if mode == "bf16same":
+        x, lab = x[:2], lab[:2]                  # every rank (and the single process) holds the SAME two images: a deterministic comparison
+    elif world > 1:
+        x, lab = x[2 * rank: 2 * rank + 2], lab[2 * rank: 2 * rank + 2]
+    pred, rep = net(x.to(dev))
+    large = ops.bilinear(pred.permute(0, 2, 3, 1).contiguous(), S, S, torch.float32).permute(0, 3, 1, 2)
+    loss = CrossEntropyLoss(-1)(large, lab.to(dev)) + rep.float().pow(2).mean()
+    loss.backward()
+    grads = torch.cat([p.grad.flatten() for p in net.parameters()])
+    if world > 1:
+        dist.all_reduce(grads)
+        grads /= world
+        l = loss.detach().clone()
+        dist.all_reduce(l)
+        loss = l / world
+    probe = grads[:: grads.numel() // 4096][:4096].cpu()
+    # per-parameter samples along the backward chain (16 parameters, evenly spread; <= 512 elements each)
+    layers, o = {}, 0
+    plist = list(net.named_parameters())
+    for i, (n_, p_) in enumerate(plist):
+        if i %% max(len(plist) // 16, 1) == 0:
+            gsl = grads[o:o + p_.numel()]
+            layers[n_] = gsl[:: max(gsl.numel() // 509, 1) | 1][:512].cpu().tolist()      # (odd stride: no aliasing with the [Cout][R][S][Cin] layout)
+        o += p_.numel()
+    tail = grads[-(grads.numel() // 4):]                       # ASPP + decoder heads: the layers closest to the loss
+    tail = tail[:: tail.numel() // 4096][:4096].cpu()
+    out = dict(loss=float(loss), pred=pred.detach().float().cpu().flatten()[::97].tolist(), grad=probe.tolist(), grad_tail=tail.tolist(),
+               rm=net.resnet_bn1.running_mean.cpu().tolist(), layers=layers)
+    if rank == 0:
+        json.dump(out, open(sys.argv[1] + mode + ".json", "w"))
+    del net
+    torch.cuda.empty_cache()
+
+
+for mode in os.environ["CSS_TEST_MODES"].split(","):
+    run(mode)
 if world > 1:
     dist.destroy_process_group()
 '''
 
-
-def _run(world, out, bf16=False, same=False):
-    code = WORKER % ROOT
-    procs = []
-    for r in range(world):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-        if bf16:
-            env["CSS_TEST_BF16"] = "1"
-        if same:
-            env["CSS_TEST_SAME_DATA"] = "1"
-        procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
-    for p in procs:
-        assert p.wait(timeout=600) == 0
+_W12 = {}      # mode -> (single-process result, two-rank result): ONE single process and ONE pair of ranks serve the three tests below (round 6)
 
 
-def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
+def _world_1_and_2(tmp_path_factory, mode):
     import json
+    if not _W12:
+        d = tmp_path_factory.mktemp("w12")
+        modes = "fp32,bf16,bf16same"
+        for world in (1, 2):
+            procs = []
+            for r in range(world):
+                env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT="29577", CSS_TEST_MODES=modes)
+                procs.append(subprocess.Popen([sys.executable, "-c", WORKER % ROOT, str(d / f"w{world}_")], env=env))
+            for p in procs:
+                assert p.wait(timeout=900) == 0
+        for m in modes.split(","):
+            _W12[m] = (json.load(open(d / f"w1_{m}.json")), json.load(open(d / f"w2_{m}.json")))
+    return _W12[mode]
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path_factory):
     import torch
-    a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run(1, a)
-    _run(2, b)
-    r1, r2 = json.load(open(a)), json.load(open(b))
+    r1, r2 = _world_1_and_2(tmp_path_factory, "fp32")
     assert abs(r1["loss"] - r2["loss"]) < 1e-4 * abs(r1["loss"])
     p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"][: len(r1["pred"])])
     # rank 0 of the 2-rank run holds the first two images: compare against the first half of the single-process output
@@ -108,15 +119,11 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
     assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 1e-4     # SyncBN running statistics = global batch statistics
 
 
-def test_two_ranks_bf16_fused_statistics_path(tmp_path):
+def test_two_ranks_bf16_fused_statistics_path(tmp_path_factory):
     """Same experiment on the bf16 throughput path: SyncBN there all-reduces the (sum, sum of squares) that stage 2 extracts from
     the convolution epilogue's slab rows (css_bn_reduce_finalize_slabs with sums_out).  bf16 tolerance."""
-    import json
     import torch
-    a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run(1, a, bf16=True)
-    _run(2, b, bf16=True)
-    r1, r2 = json.load(open(a)), json.load(open(b))
+    r1, r2 = _world_1_and_2(tmp_path_factory, "bf16")
     assert abs(r1["loss"] - r2["loss"]) < 2e-2 * abs(r1["loss"])
     n = len(r2["pred"])
     p1, p2 = torch.tensor(r1["pred"][:n]), torch.tensor(r2["pred"])
@@ -149,18 +156,14 @@ def test_two_ranks_bf16_fused_statistics_path(tmp_path):
     assert ((rm1 - rm2).abs().max() / rm1.abs().max()).item() < 2e-2
 
 
-def test_two_ranks_bf16_identical_halves_equal_one_rank(tmp_path):
+def test_two_ranks_bf16_identical_halves_equal_one_rank(tmp_path_factory):
     """The tight gradient gate of the bf16 path (advisor, round 2): when both ranks hold the SAME two images, SyncBN's global statistics are
     exactly the single process's (sums and counts double), every rank computes the same gradient and their mean is that gradient - so
     world 2 must reproduce world 1 along the WHOLE backward chain up to the order of fp32 atomic adds, although the chain is chaotic
     between different data (test above).  A wrong count, a missed all-reduce or a scaling error anywhere in SyncBN's forward or backward
     shows here as a factor, not as noise."""
-    import json
     import torch
-    a, b = str(tmp_path / "w1.json"), str(tmp_path / "w2.json")
-    _run(1, a, bf16=True, same=True)
-    _run(2, b, bf16=True, same=True)
-    r1, r2 = json.load(open(a)), json.load(open(b))
+    r1, r2 = _world_1_and_2(tmp_path_factory, "bf16same")
     assert abs(r1["loss"] - r2["loss"]) < 1e-5 * abs(r1["loss"])
     p1, p2 = torch.tensor(r1["pred"]), torch.tensor(r2["pred"])
     assert float((p1 - p2).abs().max()) <= 1e-3 * float(p1.abs().max())
@@ -183,6 +186,7 @@ TRAINER_WORKER = r'''
 import os, sys, json
 sys.path.insert(0, %r)
 import torch, torch.distributed as dist
+import numpy as np
 from css_amd.networks import resnet
 from css_amd.networks.ddp_model import Model_mix
 from css_amd.train_step import MixTrainer
@@ -190,47 +194,56 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dev = torch.device("cuda:0")
 dist.init_process_group("gloo", rank=rank, world_size=world)
 K, S = 21, 65
-torch.manual_seed(11)                                   # same initial weights on every rank (DDP broadcasts rank 0's)
 cfg = {"Dataset": {"crop_size": [S, S], "scale_size": [1.0, 1.0], "mix_mode": "cutmix", "device_aug": "identity"}}
-m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
-m.model.train(); m.ema_model.train()
-m.set_compute_dtype(torch.bfloat16)
-tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
-g = torch.Generator().manual_seed(100 + rank)           # different data per rank
-losses = []
-import numpy as np
-np.random.seed(5)                                        # cutmix boxes (host draws)
-for it in range(int(os.environ.get("CSS_TEST_STEPS", "3"))):
-    l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
-    u = torch.randn(2, 3, S, S, generator=g).to(dev)
-    out = tr.step(l, y, u)
-    losses.append([float(out["sup"]), float(out["contrast"])])
-probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
-ema = tr.flat_ema[:: tr.flat_ema.numel() // 4096][:4096].double().cpu()
-proto = tr.prototypes.double().cpu()
-rm = m.model.resnet_bn1.running_mean.double().cpu()
-nb = [len(tr._buckets), sum(len(r) for r, _ in tr._buckets), len(tr._ready_order)] if tr._buckets else [0, 0, 0]
-json.dump(dict(losses=losses, p=probe.tolist(), ema=ema.tolist(), proto=proto.flatten().tolist(), rm=rm.tolist(), buckets=nb),
-          open(sys.argv[1] + str(rank), "w"))
+for conf in os.environ["CSS_TEST_CONFIGS"].split(","):       # "bucket MB:steps" - one pair of processes serves every configuration (round 6)
+    bucket_mb, steps = conf.split(":")
+    os.environ["CSS_GRAD_BUCKET_MB"] = bucket_mb            # (read by MixTrainer.__init__)
+    torch.manual_seed(11)                                   # same initial weights on every rank (DDP broadcasts rank 0's)
+    m = Model_mix(resnet.resnet101_tv(), num_classes=K, output_dim=256, config=cfg, temp=0.25).to(dev)
+    m.model.train(); m.ema_model.train()
+    m.set_compute_dtype(torch.bfloat16)
+    tr = MixTrainer(m, num_classes=K, lr=6.4e-3, total_iter=100, num_queries=32, num_negatives=64)
+    g = torch.Generator().manual_seed(100 + rank)           # different data per rank
+    losses = []
+    np.random.seed(5)                                        # cutmix boxes (host draws)
+    for it in range(int(steps)):
+        l = torch.randn(2, 3, S, S, generator=g).to(dev); y = torch.randint(-1, K, (2, S, S), generator=g).to(dev)
+        u = torch.randn(2, 3, S, S, generator=g).to(dev)
+        out = tr.step(l, y, u)
+        losses.append([float(out["sup"]), float(out["contrast"])])
+    tr.finish()
+    probe = tr.flat_p[:: tr.flat_p.numel() // 4096][:4096].double().cpu()
+    ema = tr.flat_ema[:: tr.flat_ema.numel() // 4096][:4096].double().cpu()
+    proto = tr.prototypes.double().cpu()
+    rm = m.model.resnet_bn1.running_mean.double().cpu()
+    nb = [len(tr._buckets), sum(len(r) for r, _ in tr._buckets), len(tr._ready_order)] if tr._buckets else [0, 0, 0]
+    json.dump(dict(losses=losses, p=probe.tolist(), ema=ema.tolist(), proto=proto.flatten().tolist(), rm=rm.tolist(), buckets=nb),
+              open(sys.argv[1] + bucket_mb + "_" + str(rank), "w"))
+    del tr, m
+    torch.cuda.empty_cache()
 dist.destroy_process_group()
 '''
 
+_PAIRS = {}      # bucket MB -> (rank 0 result, rank 1 result): one pair of processes runs the three configurations of the two tests below
 
-def _trainer_pair(tmp_path, bucket_mb, steps="3"):
+
+def _trainer_pairs(tmp_path_factory):
     import json
-    out = str(tmp_path / f"r{bucket_mb}_")
-    code = TRAINER_WORKER % ROOT
-    procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", CSS_GRAD_BUCKET_MB=bucket_mb,
-                   CSS_TEST_STEPS=steps)
-        procs.append(subprocess.Popen([sys.executable, "-c", code, out], env=env))
-    for p in procs:
-        assert p.wait(timeout=900) == 0
-    return json.load(open(out + "0")), json.load(open(out + "1"))
+    if not _PAIRS:
+        d = tmp_path_factory.mktemp("trainer_pairs")
+        out = str(d / "r")
+        procs = []
+        for r in range(2):
+            env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29578", CSS_TEST_CONFIGS="8:2,0:2,48:3")
+            procs.append(subprocess.Popen([sys.executable, "-c", TRAINER_WORKER % ROOT, out], env=env))
+        for p in procs:
+            assert p.wait(timeout=900) == 0
+        for k in ("8", "0", "48"):
+            _PAIRS[k] = (json.load(open(out + k + "_0")), json.load(open(out + k + "_1")))
+    return _PAIRS
 
 
-def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
+def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path_factory):
     """The gradient all-reduce overlapped with backward in buckets (train_step.MixTrainer._backward_and_reduce; DDP's buckets at
     mix_label.py:77) against ONE all-reduce after backward (CSS_GRAD_BUCKET_MB=0): two steps (the first records the readiness order,
     the second runs bucketed), replicas bit-identical in both modes, and the two modes equal up to run-to-run noise (the order of
@@ -239,8 +252,8 @@ def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
     or reduced one twice breaks the replica equality (the gradient of that range is then no longer the same sum on both ranks) or
     shows up as O(1))."""
     import torch
-    a8, b8 = _trainer_pair(tmp_path, "8", "2")
-    a0, b0 = _trainer_pair(tmp_path, "0", "2")
+    pairs = _trainer_pairs(tmp_path_factory)
+    (a8, b8), (a0, b0) = pairs["8"], pairs["0"]
     print("buckets / runs / parameters reported:", a8["buckets"])
     assert a8["buckets"][0] >= 10 and a8["buckets"][2] > 300 and a0["buckets"] == [0, 0, 0]
     assert a8["buckets"][1] <= a8["buckets"][0] + 4              # backward runs the layers in reverse: a bucket is one or two runs
@@ -252,12 +265,12 @@ def test_bucketed_gradient_all_reduce_equals_the_single_collective(tmp_path):
     assert err < 3e-2
 
 
-def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path):
+def test_two_rank_trainer_keeps_replicas_in_sync(tmp_path_factory):
     """MixTrainer.step on two ranks (bf16, different data per rank): SyncBN statistics, the prototype class sums and the flat
     gradient are all-reduced, so after three steps both replicas hold the same parameters, EMA teacher, BN running statistics and
     prototypes (for the classes both ranks see) - the data-parallel contract of mix_label.py:76-77."""
     import torch
-    a, b = _trainer_pair(tmp_path, "48")
+    a, b = _trainer_pairs(tmp_path_factory)["48"]
     # (the unsupervised term is NaN-valued with zero gradient when no pseudo-label is confident, like the reference: SURVEY L2)
     assert all(v == v and abs(v) < 1e3 for l in a["losses"] + b["losses"] for v in l), (a["losses"], b["losses"])
     pa, pb = torch.tensor(a["p"]), torch.tensor(b["p"])
