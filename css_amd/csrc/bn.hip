@@ -357,6 +357,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     sh[p] = f32x2{shift[g * C + c + 2 * p], shift[g * C + c + 2 * p + 1]};
   }
   const int gbase = g * Mg;
+  // (experiment switch CSS_BN_NT, round 6: bits 1 / 2 / 3 of `rev` = non-temporal loads of y / of the residual / non-temporal stores of the output)
+  const int nt = rev >> 1;
+  rev &= 1;
   const int bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;      // (bn_pass_order: last rows first)
   const int row0 = gbase + bx * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   // EW_UNROLL rows per trip, all loads issued before the first use: a thread's trips are a serial chain of ~2 us memory
@@ -367,8 +370,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
     for (int u = 0; u < EW_UNROLL; ++u) {
       const int ru = r + u * RPB;
       if (ru < row1) {
-        v[u].load(y + (size_t)ru * ldy + c);
-        if (RES) rr[u].load(res + (size_t)ru * ldr + c);
+        v[u].load(y + (size_t)ru * ldy + c, (nt & 1) != 0);
+        if (RES) rr[u].load(res + (size_t)ru * ldr + c, (nt & 2) != 0);
       }
     }
 #pragma unroll
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
           if (RELU) x = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
           P::set(o, p, x);
         }
-        o.store(out + (size_t)ru * ldo + c);
+        o.store(out + (size_t)ru * ldo + c, (nt & 4) != 0);
         if (MASK) {      // ReLU mask for the backward passes: one byte per vector, of the STORED values (what reading `out` back would give)
           unsigned bits = 0;
 #pragma unroll
@@ -423,11 +426,13 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* __restrict_
     sc[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{scale[ch], scale[ch + 1]} : f32x2{0.f, 0.f};
     sh[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{shift[ch], shift[ch + 1]} : f32x2{0.f, 0.f};
   }
+  const int nt = rev >> 1;       // (CSS_BN_NT_BWDR: bit 0 = non-temporal loads of the gradient, bit 1 = of y, bit 2 = of the activation)
+  rev &= 1;
   auto f = [&](int r, int c, float* s0, float* s1) {
     Vec16<T> gv, av, yv;
-    gv.load(da + (size_t)r * ldda + c);
-    yv.load(y + (size_t)r * ldy + c);
-    if (MODE == BN_MASK_ACT) av.load(a + (size_t)r * lda + c);
+    gv.load(da + (size_t)r * ldda + c, (nt & 1) != 0);
+    yv.load(y + (size_t)r * ldy + c, (nt & 2) != 0);
+    if (MODE == BN_MASK_ACT) av.load(a + (size_t)r * lda + c, (nt & 4) != 0);
     unsigned bits = 0;
     if (MODE == BN_MASK_BITS) bits = mask[(size_t)r * CV + cv];
 #pragma unroll
@@ -484,6 +489,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
     sh[p] = MODE == BN_MASK_RECOMPUTE ? f32x2{shift[ch], shift[ch + 1]} : f32x2{0.f, 0.f};
   }
   const int gbase = g * Mg;
+  const int nt = rev >> 1;       // (CSS_BN_NT_BWDA: bit 0 = non-temporal loads of the gradient, bit 1 = of y / the activation, bit 2 = non-temporal stores)
+  rev &= 1;
   const int bx = rev ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;      // (bn_pass_order: last rows first)
   const int row0 = gbase + bx * rows_per_block, row1 = min(gbase + Mg, row0 + rows_per_block);
   for (int r = row0 + rg; r < row1; r += EW_UNROLL * RPB) {
@@ -494,9 +501,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
       const int ru = r + u * RPB;
       bits[u] = 0;
       if (ru < row1) {
-        gv[u].load(da + (size_t)ru * ldda + c);
-        yv[u].load(y + (size_t)ru * ldy + c);
-        if (MODE == BN_MASK_ACT) av[u].load(a + (size_t)ru * lda + c);
+        gv[u].load(da + (size_t)ru * ldda + c, (nt & 1) != 0);
+        yv[u].load(y + (size_t)ru * ldy + c, (nt & 2) != 0);
+        if (MODE == BN_MASK_ACT) av[u].load(a + (size_t)ru * lda + c, (nt & 2) != 0);
         if (MODE == BN_MASK_BITS) bits[u] = mask[(size_t)ru * CV + cv];
       }
     }
@@ -522,8 +529,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
           P::set(o, p, gi[p] * (dz - m1[p] - xh * m2[p]));
           P::set(dr, p, dz);
         }
-        o.store(dy + (size_t)ru * lddy + c);
-        if (dres) dr.store(dres + (size_t)ru * lddr + c);
+        o.store(dy + (size_t)ru * lddy + c, (nt & 4) != 0);
+        if (dres) dr.store(dres + (size_t)ru * lddr + c, (nt & 4) != 0);
       }
     }
   }
@@ -535,6 +542,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // traffic before it gets there.  Bit 0: bn_apply walks the rows downwards (its producer is the convolution), bit 1: bn_bwd_reduce
 // (producer: the data-gradient convolution), bit 2: bn_bwd_apply (producer of what the cache holds: bn_bwd_reduce itself - if that
 // ran downwards, the cache holds the first rows and this pass should walk upwards).  CSS_BN_PASS_ORDER overrides.
+static inline int bn_nt_bwd_reduce() {
+  static const int v = getenv("CSS_BN_NT_BWDR") ? atoi(getenv("CSS_BN_NT_BWDR")) & 7 : 2;      // (y non-temporal; the gradient stays cached for bn_bwd_apply)
+  return v;
+}
+static inline int bn_nt_bwd_apply() {
+  static const int v = getenv("CSS_BN_NT_BWDA") ? atoi(getenv("CSS_BN_NT_BWDA")) & 7 : 3;      // (last readers of the gradient and of y)
+  return v;
+}
 static inline int bn_pass_order() {
   static const int v = getenv("CSS_BN_PASS_ORDER") ? atoi(getenv("CSS_BN_PASS_ORDER")) : 1;      // (measured, profiles/r03_dres_mask_and_bn_order.txt: bit 0 -0.25 ms per step, bits 1 and 2 nothing)
   return v;
@@ -641,11 +656,12 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   // (r02, templated kernel, in the step on one box: 256 blocks 18.1 ms per step, 2048 17.7, 8192 16.7)
   static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 8192;
+  static const int apply_nt = getenv("CSS_BN_NT") ? atoi(getenv("CSS_BN_NT")) & 7 : 3;      // (non-temporal loads of y and of the residual: bn_apply_kernel)
   const int rpb = pick_rows_ew(Mg, G, C, VEC, EW_UNROLL, apply_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
 #define CSS_BN_APPLY_LAUNCH(MASK, RES, RELU)                                                                                               \
   hipLaunchKernelGGL((bn_apply_kernel<T, MASK, RES, RELU>), g, dim3(256), 0, st, (const T*)y, ldy, (const T*)res, ldr, (T*)out, ldo, scale, shift, \
-                     Mg, C, rpb, mask, bn_pass_order() & 1)
+                     Mg, C, rpb, mask, (bn_pass_order() & 1) | (apply_nt << 1))
   // (the elementwise kernels sit close to instruction-bound: mask / residual / ReLU are compile-time choices)
   if (mask) {
     if (!res || !relu) return CSS_ERR_ARG;                 // the bit mask exists for residual + ReLU layers
@@ -757,7 +773,7 @@ static int bn_bwd_reduce_T(const void* da, int ldda, const void* a, int lda, con
   const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
 #define CSS_BN_RED_LAUNCH(MODE)                                                                                                      \
   hipLaunchKernelGGL((bn_bwd_reduce_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, mean, invstd, \
-                     scale, shift, Mg, C, rpb, partial, mask, (bn_pass_order() >> 1) & 1)
+                     scale, shift, Mg, C, rpb, partial, mask, ((bn_pass_order() >> 1) & 1) | (bn_nt_bwd_reduce() << 1))
   if (mode == BN_NORELU) CSS_BN_RED_LAUNCH(BN_NORELU);
   else if (mode == BN_MASK_RECOMPUTE) CSS_BN_RED_LAUNCH(BN_MASK_RECOMPUTE);
   else if (mode == BN_MASK_ACT) CSS_BN_RED_LAUNCH(BN_MASK_ACT);
@@ -793,7 +809,7 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
   const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
 #define CSS_BN_APP_LAUNCH(MODE)                                                                                                       \
   hipLaunchKernelGGL((bn_bwd_apply_kernel<T, MODE>), g, dim3(256), 0, st, (const T*)da, ldda, (const T*)a, lda, (const T*)y, ldy, (T*)dy, lddy, \
-                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, rpb, mask, (bn_pass_order() >> 2) & 1)
+                     (T*)dres, lddr, mean, invstd, gamma, sums, scale, shift, count, count_dev, Mg, C, rpb, mask, ((bn_pass_order() >> 2) & 1) | (bn_nt_bwd_apply() << 1))
   if (mode == BN_NORELU) CSS_BN_APP_LAUNCH(BN_NORELU);
   else if (mode == BN_MASK_RECOMPUTE) CSS_BN_APP_LAUNCH(BN_MASK_RECOMPUTE);
   else if (mode == BN_MASK_ACT) CSS_BN_APP_LAUNCH(BN_MASK_ACT);

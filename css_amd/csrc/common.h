@@ -75,6 +75,25 @@ template <typename T> struct Vec16 {
   __device__ __forceinline__ void zero() { raw = make_uint4(0, 0, 0, 0); }
   __device__ __forceinline__ void load(const T* p) { raw = *reinterpret_cast<const uint4*>(p); }
   __device__ __forceinline__ void store(T* p) const { *reinterpret_cast<uint4*>(p) = raw; }
+  // non-temporal forms (round 6): a streaming pass that reads a tensor ONCE should not allocate it in the caches on its way through -
+  // bn_apply ran 15 % faster with them (profiles/r06_bn_nontemporal_ab.txt); `nt` false = the plain access (a uniform branch)
+  typedef __attribute__((ext_vector_type(4))) unsigned int nt_u32x4;
+  __device__ __forceinline__ void load(const T* p, bool nt) {
+    if (nt) {
+      const nt_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u32x4*>(p));
+      raw = make_uint4(t[0], t[1], t[2], t[3]);
+    } else {
+      load(p);
+    }
+  }
+  __device__ __forceinline__ void store(T* p, bool nt) const {
+    if (nt) {
+      const nt_u32x4 t = {raw.x, raw.y, raw.z, raw.w};
+      __builtin_nontemporal_store(t, reinterpret_cast<nt_u32x4*>(p));
+    } else {
+      store(p);
+    }
+  }
   __device__ __forceinline__ float f(int i) const { return ElemT<T>::to_f(e[i]); }
   __device__ __forceinline__ void set(int i, float v) { e[i] = ElemT<T>::from_f(v); }
 };

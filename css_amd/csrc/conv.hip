@@ -836,6 +836,12 @@ int css_launch_conv(const ConvArgs& a_in, int dtype, int n_cu, hipStream_t st, L
   auto P1 = [&]() { if (prof) prof->end(); };
   ConvArgs a = a_in;
   a.m_begin = 0;
+  {
+    // CSS_CONV_NT (experiment, round 6): bit 1 = conv_ws_kernel's output stores non-temporal (bit 0, the same in conv_igemm_p8_kernel, sent its
+    // residual-add instance to scratch - tests/test_host_cpu.py::test_conv_p8_kernel_isa - and was taken out again)
+    static const int conv_nt = getenv("CSS_CONV_NT") ? atoi(getenv("CSS_CONV_NT")) & 3 : 0;
+    a.st_nt = conv_nt;
+  }
   if (a.M <= 0 || a.Cd <= 0) return CSS_OK;
   if (a.stats && (dtype != CSS_BF16 || a.stat_Mg < 128 || a.addend)) return CSS_ERR_ARG;   // slab statistics: bf16 forward only
   a.stat_nslab = cdiv(a.M, 128);

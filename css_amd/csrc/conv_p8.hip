@@ -39,6 +39,19 @@ typedef __attribute__((ext_vector_type(4))) unsigned int p8_u32x4;
 typedef __attribute__((ext_vector_type(4))) float p8_f32x4;
 typedef __attribute__((ext_vector_type(2))) float p8_f32x2;
 
+// (-DP8_A_NT=1 / -DP8_B_NT=1, A/B builds only - CSS_HIP_LIB: the pixel / weight operand fetched with the non-temporal policy, aux = 2)
+#ifndef P8_A_NT
+#define P8_A_NT 0
+#endif
+#ifndef P8_B_NT
+#define P8_B_NT 0
+#endif
+#ifndef P8_ADD_AUX
+#define P8_ADD_AUX 0      // cache policy of the residual-gradient addend loads (2 = nt: read exactly once)
+#endif
+__device__ __forceinline__ void p8_dma16_nt(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (p8_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 2);
+}
 __device__ __forceinline__ void p8_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (p8_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
 }
@@ -297,8 +310,13 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
   };
   auto stage = [&](__amdgpu_buffer_rsrc_t rs, int par, int slot, const unsigned (&v)[2]) {      // slot: 0 = A0, 1 = A1, 2 = B0, 3 = B1
     unsigned char* const d = st_base + (par * 4 + slot) * HALF;
-    p8_dma16(rs, d, v[0]);
-    p8_dma16(rs, d + 8192, v[1]);
+    if ((P8_A_NT && slot < 2) || (P8_B_NT && slot >= 2)) {
+      p8_dma16_nt(rs, d, v[0]);
+      p8_dma16_nt(rs, d + 8192, v[1]);
+    } else {
+      p8_dma16(rs, d, v[0]);
+      p8_dma16(rs, d + 8192, v[1]);
+    }
   };
 
   // ---- consumer state ----
@@ -503,7 +521,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int m = mrow0 + 16 * i + l15, n = nl + 32 * h;
-          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a_M && n < a_Cd) ? ((unsigned)m * (unsigned)a_ld_add + (unsigned)n) * 2u : P8_OOB), 0, 0);
+          radd[i][h] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)((m < a_M && n < a_Cd) ? ((unsigned)m * (unsigned)a_ld_add + (unsigned)n) * 2u : P8_OOB), 0, P8_ADD_AUX);
           if (has_mask) rmk[i][h] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rs_k, (int)((m < a_M && n < a_Cd) ? (unsigned)m * ((unsigned)a_Cd >> 3) + ((unsigned)n >> 3) : P8_OOB), 0, 0);
           else rmk[i][h] = 0xFFu;
         }

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          slab[nl * BKC + kl] = acc[i][j][r];
+          if (a.nt & 1) __builtin_nontemporal_store(acc[i][j][r], slab + nl * BKC + kl);
+          else slab[nl * BKC + kl] = acc[i][j][r];
         }
       }
     return;
@@ -520,7 +521,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int nl = wn * WTN + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            slab[nl * 256 + kl] = acc[i][j][r];
+            if (a.nt & 1) __builtin_nontemporal_store(acc[i][j][r], slab + nl * 256 + kl);
+            else slab[nl * 256 + kl] = acc[i][j][r];
           }
         }
       return;
@@ -662,7 +664,8 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 #pragma unroll
         for (int j = 0; j < TK; ++j) {
           const int kl = wk * WTK + j * 16 + 4 * lg;
-          *reinterpret_cast<f32x4*>(slab + nl * 256 + kl) = acc[j][i];
+          if (a.nt & 1) __builtin_nontemporal_store(acc[j][i], reinterpret_cast<f32x4*>(slab + nl * 256 + kl));
+          else *reinterpret_cast<f32x4*>(slab + nl * 256 + kl) = acc[j][i];
         }
       }
       return;
@@ -684,8 +687,14 @@ __global__ __launch_bounds__(512) void conv_wgrad_p8_kernel(const WgradArgs a) {
 
 // dw[n][k] += sum over the pixel slices of ws[tile][slice][n - n0][k - k0] (fixed order: the weight gradient is bit-reproducible).
 // grid = (64, tiles): block (bx, t) owns rows 4 bx .. 4 bx + 3 of tile t; thread = 4 consecutive k columns.
+typedef __attribute__((ext_vector_type(4))) float wg_f32x4;
+__device__ __forceinline__ float4 wg_ld4(const float4* p, bool nt) {      // (CSS_WGRAD_NT bit 1: the slabs are read exactly once)
+  if (!nt) return *p;
+  const wg_f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const wg_f32x4*>(p));
+  return make_float4(t[0], t[1], t[2], t[3]);
+}
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
-                                                                int Cd, int Ktot) {
+                                                                int Cd, int Ktot, int nt) {
   const int t = blockIdx.y;
   const int k0 = (t % tiles_k) * 256, n0 = (t / tiles_k) * 256;
   const int nl = blockIdx.x * 4 + (threadIdx.x >> 6), kl = (threadIdx.x & 63) * 4;
@@ -695,15 +704,15 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   int z = 0;
   for (; z + 3 < splits; z += 4) {        // four slabs in flight
-    const float4 v0 = p[(size_t)(z + 0) * (256 * 256 / 4)], v1 = p[(size_t)(z + 1) * (256 * 256 / 4)];
-    const float4 v2 = p[(size_t)(z + 2) * (256 * 256 / 4)], v3 = p[(size_t)(z + 3) * (256 * 256 / 4)];
+    const float4 v0 = wg_ld4(p + (size_t)(z + 0) * (256 * 256 / 4), nt), v1 = wg_ld4(p + (size_t)(z + 1) * (256 * 256 / 4), nt);
+    const float4 v2 = wg_ld4(p + (size_t)(z + 2) * (256 * 256 / 4), nt), v3 = wg_ld4(p + (size_t)(z + 3) * (256 * 256 / 4), nt);
     s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
     s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
     s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
     s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
   }
   for (; z < splits; ++z) {
-    const float4 v0 = p[(size_t)z * (256 * 256 / 4)];
+    const float4 v0 = wg_ld4(p + (size_t)z * (256 * 256 / 4), nt);
     s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
   }
   const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
@@ -717,7 +726,7 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_kernel(const float* __r
 // k columns of one row (BKC / 4 threads per row, 1024 / BKC rows per block), slices in order.
 template <int BN_, int BKC>
 __global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float* __restrict__ ws, float* __restrict__ dw, int splits, int tiles_k,
-                                                                    int Cd, int Ktot) {
+                                                                    int Cd, int Ktot, int nt) {
   constexpr int TPR = BKC / 4, RPB = 256 / TPR;            // threads per tile row, rows per block
   const int t = blockIdx.y;
   const int k0 = (t % tiles_k) * BKC, n0 = (t / tiles_k) * BN_;
@@ -729,14 +738,15 @@ __global__ __launch_bounds__(256) void wgrad_slab_reduce_gen_kernel(const float*
   float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
   int z = 0;
   for (; z + 3 < splits; z += 4) {
-    const float4 v0 = p[(size_t)(z + 0) * SL], v1 = p[(size_t)(z + 1) * SL], v2 = p[(size_t)(z + 2) * SL], v3 = p[(size_t)(z + 3) * SL];
+    const float4 v0 = wg_ld4(p + (size_t)(z + 0) * SL, nt), v1 = wg_ld4(p + (size_t)(z + 1) * SL, nt), v2 = wg_ld4(p + (size_t)(z + 2) * SL, nt),
+                 v3 = wg_ld4(p + (size_t)(z + 3) * SL, nt);
     s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
     s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
     s2.x += v2.x; s2.y += v2.y; s2.z += v2.z; s2.w += v2.w;
     s3.x += v3.x; s3.y += v3.y; s3.z += v3.z; s3.w += v3.w;
   }
   for (; z < splits; ++z) {
-    const float4 v0 = p[(size_t)z * SL];
+    const float4 v0 = wg_ld4(p + (size_t)z * SL, nt);
     s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
   }
   const float r[4] = {(s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w)};
@@ -831,6 +841,11 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
   a.splits = splits;
   a.tiles_k = cdiv(a.Ktot, bkc);
   a.tiles_n = cdiv(a.Cd, bn);
+  // CSS_WGRAD_NT: bit 0 = non-temporal slab stores (no gain), bit 1 = non-temporal slab loads in the reduction (read exactly once: -0.45 ms per step,
+  // most of it in the batch-norm backward reduction that follows - profiles/r06_nontemporal_ab.txt)
+  static const int wg_nt = getenv("CSS_WGRAD_NT") ? atoi(getenv("CSS_WGRAD_NT")) & 3 : 2;
+  a.nt = wg_nt & 1;
+  const int rnt = (wg_nt >> 1) & 1;
   a.compact = 0;
   {
     static const bool no_compact = getenv("CSS_WGRAD_NO_COMPACT") && atoi(getenv("CSS_WGRAD_NO_COMPACT")) != 0;
@@ -872,23 +887,23 @@ int css_launch_wgrad(WgradArgs a, int dtype, int n_cu, hipStream_t st, LaunchPro
     if (mf16) hipLaunchKernelGGL(conv_wgrad_p8_kernel<true>, g, dim3(512), 0, st, a);
     else hipLaunchKernelGGL(conv_wgrad_p8_kernel<false>, g, dim3(512), 0, st, a);
     if (a.ws)
-      hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot);
+      hipLaunchKernelGGL(wgrad_slab_reduce_kernel, dim3(64, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits, a.tiles_k, a.Cd, a.Ktot, rnt);
   } else if (n64) {
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 64, 64, 64>), g, dim3(256), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<64, 64>), dim3(64 / 16, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
-                         a.tiles_k, a.Cd, a.Ktot);
+                         a.tiles_k, a.Cd, a.Ktot, rnt);
   } else if (dtype == CSS_BF16) {
     // (32 pixels per step - 40 KiB of LDS, four workgroups per CU instead of two - was measured and is slower: profiles/r04_small64_nst2_ab.txt)
     hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, 128, 128, 64>), g, dim3(256), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<128, 128>), dim3(128 / 8, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
-                         a.tiles_k, a.Cd, a.Ktot);
+                         a.tiles_k, a.Cd, a.Ktot, rnt);
   } else {
     hipLaunchKernelGGL((conv_wgrad_kernel<float, 64, 64, 16>), g, dim3(256), 0, st, a);
     if (a.ws)
       hipLaunchKernelGGL((wgrad_slab_reduce_gen_kernel<64, 64>), dim3(64 / 16, a.tiles_k * a.tiles_n), dim3(256), 0, st, a.ws, a.dw, a.splits,
-                         a.tiles_k, a.Cd, a.Ktot);
+                         a.tiles_k, a.Cd, a.Ktot, rnt);
   }
   if (prof) prof->end();
   CSS_CHECK_LAUNCH();

@@ -43,6 +43,12 @@
 #ifndef WS_STORE_AUX
 #define WS_STORE_AUX 0      // cache policy of the output stores (timing ablation: 2 = nt)
 #endif
+#ifndef WS_PIX_AUX
+#define WS_PIX_AUX 0        // ... of the pixel stream (LDS-DMA)
+#endif
+#ifndef WS_ADD_AUX
+#define WS_ADD_AUX 0        // ... of the residual-gradient addend loads
+#endif
 namespace {
 typedef __attribute__((address_space(3))) void ws_lds_void;
 constexpr unsigned WS_OOB = 0x80000000u;
@@ -51,7 +57,7 @@ typedef __attribute__((ext_vector_type(4))) float ws_f32x4;
 typedef __attribute__((ext_vector_type(2))) float ws_f32x2;
 
 __device__ __forceinline__ void ws_dma16(__amdgpu_buffer_rsrc_t r, void* lds_wave_base, unsigned off) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ws_lds_void*)lds_wave_base, 16, (int)off, 0, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (ws_lds_void*)lds_wave_base, 16, (int)off, 0, 0, WS_PIX_AUX);
 }
 __device__ __forceinline__ float ws_row16_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));   // row_ror:8
@@ -367,6 +373,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
           for (int e = 0; e < 4; ++e) v[e] = ws_pack2(ws_lo(v[e]) + ws_lo(q[e]), ws_hi(v[e]) + ws_hi(q[e]));
         }
         if (ABL_NOSTORE) asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
+        else if (a.st_nt & 2) __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)(panel * BN + 8 * ch)) * 2u : WS_OOB), 0, 2);
         else __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ldd + (unsigned)(panel * BN + 8 * ch)) * 2u : WS_OOB), 0, WS_STORE_AUX);
       }
     } else {
@@ -449,7 +456,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
       for (int i = 0; i < (ADD ? 8 : 0); ++i) {
         const int m = m0e + 16 * wave + 2 * i + (lane >> 5);
-        radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)(panel * BN + 8 * (lane & 31))) * 2u : WS_OOB), 0, 0);
+        radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)(panel * BN + 8 * (lane & 31))) * 2u : WS_OOB), 0, WS_ADD_AUX);
       }
       return;
     }
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(512) void conv_ws_kernel(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < (ADD ? 8 : 0); ++i) {
       const int m = m0e + 16 * i + l15;
-      radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)nl) * 2u : WS_OOB), 0, 0);
+      radd[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_r, (int)(m < a.M ? ((unsigned)m * (unsigned)a.ld_add + (unsigned)nl) * 2u : WS_OOB), 0, WS_ADD_AUX);
     }
   };
   auto mfma_half = [&](const bf16x8 (&fa)[8], int q, bool first) {

@@ -31,6 +31,7 @@ struct ConvArgs {
   unsigned mask_bytes;            // size of add_mask
   int korder;                     // order of the K steps (conv_pp.hip: issue())
   int tab_da[63], tab_kb[63], tab_tap[63];   // conv_p8.hip: tap lists per set of valid kernel rows (7 x 9)
+  int st_nt;                      // non-zero: the output tile leaves with non-temporal stores (filled by the launcher: CSS_CONV_NT; conv_p8.hip, conv_ws.hip)
 };
 
 struct WgradArgs {
@@ -49,6 +50,7 @@ struct WgradArgs {
   // Live-row compaction (conv_wgrad_p8_kernel, filled by the launcher; compact = 0: off).  For a dilated R x S convolution the output rows
   // whose source row lies in the padding for kernel row r contribute nothing to that row's weights: the pixel loop of a k-column tile of
   // kernel row r runs over the LIVE output rows [row_lo[r], row_lo[r] + row_n[r]) of every image only (row_mps[r] compacted pixels per slice).
+  int nt;            // bit 0: non-temporal slab stores (filled by the launcher: CSS_WGRAD_NT)
   int compact;
   int row_lo[3], row_n[3], row_mps[3];
   // compact = 2: the kernel rows fall into a LONG class (all output rows live: the centre row) and a SHORT class; every XCD is dealt its share

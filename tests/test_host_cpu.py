@@ -222,7 +222,8 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     lines = open(out).read().split("\n")
     assert not any(l.startswith("_Z24conv_wgrad_dma256_kernel") for l in lines)
     # conv_wgrad_p8_kernel: two phases per 32-pixel step, each with its own counted wait; five phases' pieces stay in flight
-    start = next(i for i, l in enumerate(lines) if l.startswith("_Z20conv_wgrad_p8_kernel"))
+    # (round 6: a template over the MFMA shape - <false> = the 32x32x16 form the launcher takes by default)
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z20conv_wgrad_p8_kernelILb0EE"))
     end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
     body = lines[start:end]
     mfma = [i for i, l in enumerate(body) if "v_mfma_f32_32x32x16_bf16" in l]
@@ -232,6 +233,18 @@ def test_dma_conv_main_loop_keeps_counted_vmcnt(tmp_path):
     assert sum("ds_read_b64_tr_b16" in l for l in body) == 24
     n_dma = sum("buffer_load_dwordx4" in l and " lds" in l for l in body)
     assert n_dma == 16 and sum("m0" in l.split(";")[0] for l in body) == n_dma, n_dma
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
+    # <true>: the 16x16x32 form (CSS_WGRAD_MFMA=16): five stages = all 160 KiB of LDS, the step written three times (pairs + an odd tail) with
+    # 32 MFMAs and 12 + 12 transposed reads each, ONE counted wait per step (in phase A: 2.5 steps of LDS-DMA stay in flight), no scratch
+    start = next(i for i, l in enumerate(lines) if l.startswith("_Z20conv_wgrad_p8_kernelILb1EE"))
+    end = next(i for i in range(start, len(lines)) if "s_endpgm" in lines[i])
+    body = lines[start:end]
+    mfma = [i for i, l in enumerate(body) if "v_mfma_f32_16x16x32_bf16" in l]
+    assert len(mfma) == 96 and not any("v_mfma_f32_32x32x16_bf16" in l for l in body), len(mfma)
+    assert not any("vmcnt(0)" in l for l in body[mfma[0]:mfma[-1] + 1])
+    assert sum("s_waitcnt vmcnt(10)" in l for l in body) == 3 and sum("s_waitcnt vmcnt(12)" in l for l in body) == 1
+    assert sum("ds_read_b64_tr_b16" in l for l in body) in (3 * 24, 3 * 24 + 4)      # (+ the four reads ahead of the loop when they sit before the first s_endpgm)
+    assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; LDSByteSize:")) == 5 * 32768
     assert next(int(l.split()[2]) for l in lines[end:] if l.startswith("; ScratchSize:")) == 0
 
 
