@@ -46,6 +46,9 @@ typedef __attribute__((ext_vector_type(2))) float p8_f32x2;
 #ifndef P8_B_NT
 #define P8_B_NT 0
 #endif
+#ifndef P8_STORE_AUX
+#define P8_STORE_AUX 0    // cache policy of the output stores (A/B builds: 2 = nt)
+#endif
 #ifndef P8_ADD_AUX
 #define P8_ADD_AUX 0      // cache policy of the residual-gradient addend loads (2 = nt: read exactly once)
 #endif
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(512) void conv_igemm_p8_kernel(const ConvArgs a) {
 #if defined(P8_ABL_NOSTORE)       // timing ablation (scripts/p8_bench.hip): keep the values alive, drop the stores
         asm volatile("" ::"v"(v[0]), "v"(v[1]), "v"(v[2]), "v"(v[3]));
 #else
-        __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(ok ? rowb + (unsigned)n * 2u : P8_OOB), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs_d, (int)(ok ? rowb + (unsigned)n * 2u : P8_OOB), 0, P8_STORE_AUX);
 #endif
         if constexpr (MSTAT) {
           if (whole_m) {

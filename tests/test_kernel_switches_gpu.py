@@ -57,7 +57,9 @@ SWITCHES = [{}, {"CSS_NO_P8_CONV": "1"}, {"CSS_NO_SMALL_SPLITK": "1"}, {"CSS_NO_
             {"CSS_PP_KORDER": "0"}, {"CSS_NO_DMA256_CONV": "1"}, {"CSS_NO_DMA_CONV": "1"}, {"CSS_WGRAD_ATOMICS": "1"},
             {"CSS_NO_DMA256_WGRAD": "1"}, {"CSS_REM_N64": "1"}, {"CSS_BN_RED_BLOCKS": "256"}, {"CSS_SMALL_NST2": "0", "CSS_SMALL64_NST2": "0"}, {"CSS_N128_SMALL_ONLY": "0"},
             # round 6 (conv_wgrad.hip): the 16x16x32 form of the 256x256 weight-gradient kernel, live-row compaction off, slice-major dealing
-            {"CSS_WGRAD_MFMA": "16"}, {"CSS_WGRAD_NO_COMPACT": "1"}, {"CSS_WGRAD_NO_LONGEST_FIRST": "1"}]
+            {"CSS_WGRAD_MFMA": "16"}, {"CSS_WGRAD_NO_COMPACT": "1"}, {"CSS_WGRAD_NO_LONGEST_FIRST": "1"},
+            # round 6: cache policies (non-temporal slab stores + loads on / everything plain)
+            {"CSS_WGRAD_NT": "3"}, {"CSS_WGRAD_NT": "0", "CSS_CONV_NT": "2"}]
 
 
 @pytest.mark.parametrize("env", SWITCHES, ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()) or "default")
@@ -80,10 +82,13 @@ def test_bn_activation_mask_switch_is_a_shipped_configuration():
     assert r.returncode == 0, r.stdout[-800:]
 
 
-@pytest.mark.parametrize("env", [{"CSS_BN_PASS_ORDER": "1"}, {"CSS_BN_PASS_ORDER": "2"}, {"CSS_BN_PASS_ORDER": "4"}, {"CSS_BN_PASS_ORDER": "7"}, {"CSS_BN_PASS_ORDER": "0"}],
+@pytest.mark.parametrize("env", [{"CSS_BN_PASS_ORDER": "1"}, {"CSS_BN_PASS_ORDER": "2"}, {"CSS_BN_PASS_ORDER": "4"}, {"CSS_BN_PASS_ORDER": "7"}, {"CSS_BN_PASS_ORDER": "0"},
+                                 # round 6: the non-temporal load / store switches of the three streaming batch-norm kernels, all off and all on
+                                 {"CSS_BN_NT": "0", "CSS_BN_NT_BWDR": "0", "CSS_BN_NT_BWDA": "0"}, {"CSS_BN_NT": "7", "CSS_BN_NT_BWDR": "7", "CSS_BN_NT_BWDA": "7"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_bn_pass_order_switch_is_a_shipped_configuration(env):
-    """CSS_BN_PASS_ORDER (css_amd/csrc/bn.hip: which of the three streaming batch-norm passes walk the rows downwards): same results."""
+    """CSS_BN_PASS_ORDER (css_amd/csrc/bn.hip: which of the three streaming batch-norm passes walk the rows downwards) and CSS_BN_NT* (their cache
+    policies): same results."""
     e = dict(os.environ)
     e.update(env)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_ops_gpu.py"), "-q", "-x", "-k", "bn_act_train", "-m", "gpu"],
