@@ -562,7 +562,7 @@ static inline int pick_rows_per_block(int Mg, int G, int C, int vec) {
   const int ybl = (CV + TPC - 1) / TPC;
   const long bytes = (long)Mg * C * (16 / vec);
   long want = bytes / (64 * 1024) / ybl;
-  static const long total_cap = getenv("CSS_BN_RED_BLOCKS") ? atol(getenv("CSS_BN_RED_BLOCKS")) : 1024;   // (one block per CU wins the stand-alone microbenchmark by up to 22 % but loses 0.4 ms in the step, where the tensors come from the Infinity Cache)
+  static const long total_cap = getenv("CSS_BN_RED_BLOCKS") ? atol(getenv("CSS_BN_RED_BLOCKS")) : 512;   // (one block per CU wins the stand-alone microbenchmark by up to 22 % but loses 0.4 ms in the step, where the tensors come from the Infinity Cache)
   const long cap = total_cap / ((long)ybl * G) > 0 ? total_cap / ((long)ybl * G) : 1;
   if (want > cap) want = cap;
   if (want < 1) want = 1;
@@ -655,7 +655,7 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
   if (C % VEC || ldy % VEC || ldo % VEC || (res && ldr % VEC)) return CSS_ERR_ARG;
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   // (r02, templated kernel, in the step on one box: 256 blocks 18.1 ms per step, 2048 17.7, 8192 16.7)
-  static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 8192;
+  static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 32768;
   static const int apply_nt = getenv("CSS_BN_NT") ? atoi(getenv("CSS_BN_NT")) & 7 : 3;      // (non-temporal loads of y and of the residual: bn_apply_kernel)
   const int rpb = pick_rows_ew(Mg, G, C, VEC, EW_UNROLL, apply_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
@@ -803,7 +803,8 @@ static int bn_bwd_apply_T(const void* da, int ldda, const void* a, int lda, cons
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   // amortise the 7-coefficient prologue (measured: 44 -> 30 us at 135200x128), and ONE block per CU: with 3-5 streams per block the
   // backward kernel is 5-25 % faster on 256 blocks than on 2048 (bn_bench.py; the forward apply kernel is the opposite)
-  static const long bwd_blocks = getenv("CSS_BN_BWD_EW_BLOCKS") ? atol(getenv("CSS_BN_BWD_EW_BLOCKS")) : 256;
+  // (round 6, after the non-temporal loads: 1024 blocks here, 32768 in bn_apply, 512 in bn_bwd_reduce: -1.7 ms per c2 step together, profiles/r06_bn_blocks_ab.txt)
+  static const long bwd_blocks = getenv("CSS_BN_BWD_EW_BLOCKS") ? atol(getenv("CSS_BN_BWD_EW_BLOCKS")) : 1024;
   const int rpb = pick_rows_ew(Mg, G, C, VEC, 16, bwd_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
   const int mode = !relu ? BN_NORELU : mask ? BN_MASK_BITS : a ? BN_MASK_ACT : BN_MASK_RECOMPUTE;
