@@ -7,7 +7,7 @@ EMA model -> save_checkpoint at the best mIoU -> load_checkpoint and continue.  
 (loaders in the main process: see tests/mini_train.py on forked workers next to a live HIP context).
 
 Asserted:
-  (i)   the validation mIoU of the EMA model rises from chance level (< 0.45 after the first epoch, 6 classes) to >= 0.80 - in fp32 AND in bf16;
+  (i)   the validation mIoU of the EMA model rises from near chance level (< 0.60 after the first epoch of 32 steps - measured 0.19 ... 0.36 over the builds of the round; 6 classes) to >= 0.80 - in fp32 AND in bf16;
   (ii)  |mIoU_bf16 - mIoU_fp32| is within max(0.03, 3 x d), d = |mIoU of two fp32 runs whose input batches differ by a 1-ulp relative perturbation|
         - the chaos floor of the problem itself (two correct fp32 runs), measured in the same test from the same seeds;
   (iii) a run resumed from the epoch-3 checkpoint (exact-resume format, css_amd/checkpoint.py) reproduces the un-interrupted run BIT FOR BIT:
@@ -75,7 +75,7 @@ def test_mini_training_reads_an_miou_in_fp32_and_bf16_and_resumes_bit_for_bit(tm
     # (i) it learns, in both dtypes
     for name, run in (("bf16", a), ("fp32", f), ("fp32 + 1 ulp", g)):
         print(name, "mIoU per epoch:", [round(x, 4) for x in run["curve"]])
-        assert run["curve"][0] < 0.45 and run["best"] >= 0.80 and run["curve"][-1] >= 0.75, (name, run["curve"])
+        assert run["curve"][0] < 0.60 and run["best"] >= 0.80 and run["curve"][-1] >= 0.75, (name, run["curve"])
     # (ii) bf16 sits inside the problem's own fp32 noise
     d_floor = max(abs(f["curve"][-1] - g["curve"][-1]), abs(f["best"] - g["best"]))
     bound = max(0.03, 3 * d_floor)
