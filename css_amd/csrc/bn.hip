@@ -386,7 +386,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ y, 
           if (RELU) x = f32x2{fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
           P::set(o, p, x);
         }
-        o.store(out + (size_t)ru * ldo + c, (nt & 4) != 0);
+        if (nt & 8) o.store_sc1(out + (size_t)ru * ldo + c);      // (CSS_BN_NT bit 3: write-through output stores, -0.5 ms per step)
+        else o.store(out + (size_t)ru * ldo + c, (nt & 4) != 0);
         if (MASK) {      // ReLU mask for the backward passes: one byte per vector, of the STORED values (what reading `out` back would give)
           unsigned bits = 0;
 #pragma unroll
@@ -529,8 +530,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
           P::set(o, p, gi[p] * (dz - m1[p] - xh * m2[p]));
           P::set(dr, p, dz);
         }
-        o.store(dy + (size_t)ru * lddy + c, (nt & 4) != 0);
-        if (dres) dr.store(dres + (size_t)ru * lddr + c, (nt & 4) != 0);
+        if (nt & 8) {
+          o.store_sc1(dy + (size_t)ru * lddy + c);
+          if (dres) dr.store_sc1(dres + (size_t)ru * lddr + c);
+        } else {
+          o.store(dy + (size_t)ru * lddy + c, (nt & 4) != 0);
+          if (dres) dr.store(dres + (size_t)ru * lddr + c, (nt & 4) != 0);
+        }
       }
     }
   }
@@ -547,7 +553,7 @@ static inline int bn_nt_bwd_reduce() {
   return v;
 }
 static inline int bn_nt_bwd_apply() {
-  static const int v = getenv("CSS_BN_NT_BWDA") ? atoi(getenv("CSS_BN_NT_BWDA")) & 7 : 3;      // (last readers of the gradient and of y)
+  static const int v = getenv("CSS_BN_NT_BWDA") ? atoi(getenv("CSS_BN_NT_BWDA")) & 15 : 11;     // (last readers of the gradient and of y; write-through stores)
   return v;
 }
 static inline int bn_pass_order() {
@@ -656,7 +662,7 @@ static int bn_apply_T(const void* y, int ldy, const void* res, int ldr, void* ou
   const int CV = C / VEC, TPC = CV < 256 ? CV : 256, G = M / Mg;
   // (r02, templated kernel, in the step on one box: 256 blocks 18.1 ms per step, 2048 17.7, 8192 16.7)
   static const long apply_blocks = getenv("CSS_BN_APPLY_BLOCKS") ? atol(getenv("CSS_BN_APPLY_BLOCKS")) : 32768;
-  static const int apply_nt = getenv("CSS_BN_NT") ? atoi(getenv("CSS_BN_NT")) & 7 : 3;      // (non-temporal loads of y and of the residual: bn_apply_kernel)
+  static const int apply_nt = getenv("CSS_BN_NT") ? atoi(getenv("CSS_BN_NT")) & 15 : 11;     // (non-temporal loads of y and of the residual, write-through stores: bn_apply_kernel)
   const int rpb = pick_rows_ew(Mg, G, C, VEC, EW_UNROLL, apply_blocks);
   dim3 g(cdiv(Mg, rpb), cdiv(CV, TPC), G);
 #define CSS_BN_APPLY_LAUNCH(MASK, RES, RELU)                                                                                               \

@@ -84,7 +84,8 @@ def test_bn_activation_mask_switch_is_a_shipped_configuration():
 
 @pytest.mark.parametrize("env", [{"CSS_BN_PASS_ORDER": "1"}, {"CSS_BN_PASS_ORDER": "2"}, {"CSS_BN_PASS_ORDER": "4"}, {"CSS_BN_PASS_ORDER": "7"}, {"CSS_BN_PASS_ORDER": "0"},
                                  # round 6: the non-temporal load / store switches of the three streaming batch-norm kernels, all off and all on
-                                 {"CSS_BN_NT": "0", "CSS_BN_NT_BWDR": "0", "CSS_BN_NT_BWDA": "0"}, {"CSS_BN_NT": "7", "CSS_BN_NT_BWDR": "7", "CSS_BN_NT_BWDA": "7"}],
+                                 {"CSS_BN_NT": "0", "CSS_BN_NT_BWDR": "0", "CSS_BN_NT_BWDA": "0"}, {"CSS_BN_NT": "7", "CSS_BN_NT_BWDR": "7", "CSS_BN_NT_BWDA": "7"},
+                                 {"CSS_BN_NT": "15", "CSS_BN_NT_BWDA": "15"}],
                          ids=lambda e: "+".join(f"{k}={v}" for k, v in e.items()))
 def test_bn_pass_order_switch_is_a_shipped_configuration(env):
     """CSS_BN_PASS_ORDER (css_amd/csrc/bn.hip: which of the three streaming batch-norm passes walk the rows downwards) and CSS_BN_NT* (their cache
