@@ -50,8 +50,11 @@ def test_ten_steps_twice_bit_identical(dtype):
         assert _same_bits(a["hist"][i], b["hist"][i]), (i, a["hist"][i].tolist(), b["hist"][i].tolist())
     for key in ("p", "m", "ema", "proto"):
         assert _same_bits(a[key], b[key]), (key, int((a[key] != b[key]).sum()), float((a[key] - b[key]).abs().max()))
-    # (finite; that the run LEARNS is asserted on the median of ten runs in tests/test_bf16_trajectory_gpu.py - a single run of this chaotic problem may
-    # sit on a bump at step 10: the 64 x 64 weight-gradient tiles of round 5, another fixed summation order, put the bf16 run at 8.17 > 7.05 there)
+    # it trains (the assertion was dropped in round 5 with a justification that held for the opt-in 64 x 64 weight-gradient tiles only; on
+    # the default build - measured in round 6, scripts/det_probe.py - the supervised loss of this run falls 7.03 -> 0.80 in fp32 and 7.06 -> 0.80
+    # in bf16 over the ten steps, the total 12.8 -> 6.9 / 7.2): the supervised loss must at least halve
+    assert float(a["hist"][-1, 0]) < 0.5 * float(a["hist"][0, 0]), a["hist"][:, 0].tolist()
+    assert float(a["hist"][-1, 3]) < float(a["hist"][0, 3]), a["hist"][:, 3].tolist()
     assert torch.isfinite(a["hist"][:, [0, 2, 3]]).all()
 
 
