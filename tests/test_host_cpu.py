@@ -970,3 +970,83 @@ def test_wgrad_live_row_compaction_walk_visits_exactly_the_live_pixels(N, H, W, 
         # the compaction drops exactly the rows whose source row is in the padding (or nothing, when the whole kernel row is: computed as zeros)
         live = [h for h in range(H) if 0 <= h + dh < H]
         assert (lo, nrows) == ((live[0], len(live)) if live else (0, H))
+
+
+def _wgrad_work_items(tiles_k, tiles_n, R, splits, cls_rows, grid):
+    """Host restatement of wgrad_work_item (css_amd/csrc/conv_wgrad.hip) for compact == 2: blockIdx -> (slice, tile) or None."""
+    tpr = tiles_k // R
+    n0c, n1c = tiles_n * len(cls_rows[0]) * tpr, tiles_n * len(cls_rows[1]) * tpr
+    w80, w81 = (n0c * splits + 7) >> 3, (n1c * splits + 7) >> 3
+    out = []
+    for b in range(grid):
+        xcd, j8 = b & 7, b >> 3
+        c = 0 if j8 < w80 else 1
+        jj, w8c, nc = (j8 - w80, w81, n1c) if c else (j8, w80, n0c)
+        w = xcd * w8c + jj
+        if jj >= w8c or w >= nc * splits:
+            out.append(None)
+            continue
+        zz, rem = divmod(w, nc)
+        per_nt = len(cls_rows[c]) * tpr
+        nt, rem2 = divmod(rem, per_nt)
+        ri, kin = divmod(rem2, tpr)
+        out.append((zz, nt * tiles_k + cls_rows[c][ri] * tpr + kin, c, xcd, j8))
+    return out, w80, w81
+
+
+@pytest.mark.parametrize("tiles_k,tiles_n,splits", [(72, 1, 7), (9, 1, 28), (18, 2, 7), (9, 4, 3), (27, 1, 1)])
+def test_wgrad_longest_first_dealing_covers_every_work_item_once(tiles_k, tiles_n, splits):
+    """The two-class dealing of the compacted weight-gradient launches (conv_wgrad.hip: wgrad_work_item, compact == 2): every (slice, tile) exactly
+    once, the grid is exactly what the launcher sizes, every XCD gets its long items (centre kernel row) at lower block indices than its short ones,
+    and the slices of one class stay contiguous per XCD (the slice-major order the L2 sharing of a slice's operands relies on)."""
+    R = 3
+    cls_rows = ([1], [0, 2])                       # centre row: all output rows live; rows 0 and 2: compacted
+    tpr = tiles_k // R
+    grid = 8 * (-(-tiles_n * 1 * tpr * splits // 8) + -(-tiles_n * 2 * tpr * splits // 8))
+    items, w80, w81 = _wgrad_work_items(tiles_k, tiles_n, R, splits, cls_rows, grid)
+    got = [(zz, t) for it in items if it for zz, t, *_ in [it]]
+    assert sorted(got) == [(zz, t) for zz in range(splits) for t in range(tiles_k * tiles_n)]
+    for it in items:
+        if it:
+            zz, t, c, xcd, j8 = it
+            row = (t % tiles_k) // tpr
+            assert (row == 1) == (c == 0) and (j8 < w80) == (c == 0)
+    for xcd in range(8):
+        for c in (0, 1):
+            zs = [it[0] for it in items if it and it[3] == xcd and it[2] == c]
+            assert zs == sorted(zs)                  # slice-major inside a class on every XCD
+
+
+def test_wgrad_mf16_lds_image_is_conflict_free_and_complete():
+    """The LDS image of conv_wgrad_p8_kernel<true> (the 16x16x32 form): (1) the LDS-DMA of a 32-pixel x 256-channel tile puts source chunk c of
+    pixel row r at 16-byte position c ^ ((r & 3) << 2) ^ (((r >> 3) & 1) << 1) of LDS row r, every (row, chunk) exactly once; (2) a transposed
+    fragment read (ds_read_b64_tr_b16: lane group g = lane >> 4 takes rows 8 g + q and, second read, + 4; lane 4 q + p of a group supplies the
+    address of 4 channels) returns channels c0 .. c0 + 15 of pixel rows 8 g .. 8 g + 7 - the K = 32 operand of v_mfma_f32_16x16x32_bf16 - and
+    (3) the 32 lanes of each half of a read touch 64 distinct banks: conflict-free."""
+    # (1) issue side: thread tid of 512 -> rows prow, prow + 16; LDS position tid & 31 of those rows; source chunk schunk
+    image = {}
+    for tid in range(512):
+        prow = tid >> 5
+        schunk = (tid & 31) ^ ((prow & 3) << 2) ^ (((prow >> 3) & 1) << 1)
+        for i in range(2):
+            row = prow + 16 * i
+            assert (row, tid & 31) not in image
+            image[(row, tid & 31)] = schunk            # LDS (row, position) holds source chunk schunk of that row
+            assert (tid & 31) == schunk ^ ((row & 3) << 2) ^ (((row >> 3) & 1) << 1)
+    assert len(image) == 32 * 32 and all(sorted(image[(r, p)] for p in range(32)) == list(range(32)) for r in range(32))
+    # (2) + (3): fragment reads for every 16-channel block c0
+    for c0 in range(0, 256, 16):
+        for second in (0, 1):
+            for half in (0, 1):
+                banks = []
+                for lane in range(32 * half, 32 * half + 32):
+                    li, g = lane & 15, lane >> 4
+                    q, pp = li >> 2, li & 3
+                    row = 8 * g + q + 4 * second
+                    ch = ((c0 >> 3) + (pp >> 1)) ^ (q << 2) ^ ((g & 1) << 1)
+                    addr = row * 512 + ch * 16 + 8 * (pp & 1)
+                    # what lives there: source chunk image[(row, ch)], bytes 8 (pp & 1) .. + 7 = channels 8 chunk + 4 (pp & 1) .. + 3
+                    src_chunk = image[(row, ch)]
+                    assert src_chunk * 8 + 4 * (pp & 1) == c0 + 4 * pp, (c0, lane)
+                    banks += [(addr // 4 + k) % 64 for k in range(2)]
+                assert len(set(banks)) == 64, (c0, second, half)
